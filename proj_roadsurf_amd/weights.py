@@ -1,0 +1,269 @@
+"""Weight I/O for the engine (host Python only, as BASELINE.json:north_star allows).
+
+* ``synthetic_weights``  -- seeded random weights in detectron2's checkpoint key layout
+  (SURVEY.md §8c key list).  No trained weights exist offline (R:config/config_obj_detec.yaml:86
+  is a training artefact, R:config/detectron2_config_3bands.yaml:265 a URL), so benches and parity
+  tests use these.
+* ``load_checkpoint``    -- reads a detectron2 ``.pth`` (``torch.save({'model': state_dict, ...})``)
+  with ``weights_only=True``.  The model-zoo ``.pkl`` is a pickle and is NOT loaded (executing
+  pickles from outside is forbidden here); convert it to ``.pth``/``.npz`` elsewhere.
+* ``pack_weights``       -- folds FrozenBN into conv scale/bias, converts to the engine's
+  kernel-ready layout (fp16 ``[Cout][KH][KW][Cin]``, K padded to 64, fp32 bias) and serialises to
+  the flat blob ``rs_engine_create`` consumes (format: include/rs_engine.h "weight blob").
+"""
+from __future__ import annotations
+
+import math
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .spec import EngineSpec
+
+BLOB_MAGIC = 0x52534557  # 'RSEW'
+BLOB_VERSION = 1
+DT_F16, DT_F32, DT_I32 = 1, 2, 3
+ALIGN = 256
+K_ALIGN = 64          # GEMM K padding (elements) -- one LDS K-step of the conv kernel
+STEM_CIN_PAD = 8      # stem input channels padded to one 16-byte chunk
+
+
+# ----------------------------------------------------------------------------- topology
+def conv_layers(spec: EngineSpec) -> List[Tuple[str, int, int, int, bool]]:
+    """(name, cin, cout, k, has_norm) for every conv of the model in execution order."""
+    L: List[Tuple[str, int, int, int, bool]] = []
+    p = "backbone.bottom_up."
+    L.append((p + "stem.conv1", spec.in_channels, spec.stem_out_channels, 7, True))
+    cin = spec.stem_out_channels
+    bott = spec.num_groups * spec.width_per_group
+    cout = spec.res2_out_channels
+    for si, nb in enumerate(spec.res_blocks):
+        for bi in range(nb):
+            n = f"{p}res{si + 2}.{bi}"
+            if cin != cout:
+                L.append((n + ".shortcut", cin, cout, 1, True))
+            L.append((n + ".conv1", cin, bott, 1, True))
+            L.append((n + ".conv2", bott, bott, 3, True))
+            L.append((n + ".conv3", bott, cout, 1, True))
+            cin = cout
+        bott *= 2
+        cout *= 2
+    res_c = [spec.res2_out_channels * (2 ** i) for i in range(4)]
+    for l, c in zip((2, 3, 4, 5), res_c):
+        L.append((f"backbone.fpn_lateral{l}", c, spec.fpn_out_channels, 1, False))
+        L.append((f"backbone.fpn_output{l}", spec.fpn_out_channels, spec.fpn_out_channels, 3, False))
+    A = spec.num_anchors
+    f = spec.fpn_out_channels
+    L.append(("proposal_generator.rpn_head.conv", f, f, 3, False))
+    L.append(("proposal_generator.rpn_head.objectness_logits", f, A, 1, False))
+    L.append(("proposal_generator.rpn_head.anchor_deltas", f, 4 * A, 1, False))
+    if spec.mask_on:
+        c = f
+        for i in range(spec.mask_num_conv):
+            L.append((f"roi_heads.mask_head.mask_fcn{i + 1}", c, spec.mask_conv_dim, 3, False))
+            c = spec.mask_conv_dim
+    return L
+
+
+# ----------------------------------------------------------------------------- synthetic
+def synthetic_weights(spec: EngineSpec, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random weights, detectron2 key names, fp32 numpy.
+
+    The init is chosen so that activations stay O(1) through all 16 bottlenecks (fp16-safe, like a
+    trained net) and so that objectness / class / mask logits are well spread (std ~1.5-2): with
+    detectron2's own tiny head inits (std 0.01/0.001) every score would tie at 1/(K+1) and any
+    fp difference would reshuffle NMS, which tests nothing.  Documented in DESIGN.md "Synthetic
+    workload"."""
+    rng = np.random.default_rng(seed)
+    W: Dict[str, np.ndarray] = {}
+
+    def conv(name: str, cin: int, cout: int, k: int, gain: float, bias: bool) -> None:
+        std = gain / math.sqrt(cin * k * k)
+        W[name + ".weight"] = (rng.standard_normal((cout, cin, k, k)) * std).astype(np.float32)
+        if bias:
+            W[name + ".bias"] = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+
+    def bn(name: str, c: int, scale: float) -> None:
+        W[name + ".weight"] = (rng.uniform(0.7, 1.3, c) * scale).astype(np.float32)
+        W[name + ".bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        W[name + ".running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        W[name + ".running_var"] = rng.uniform(0.6, 1.4, c).astype(np.float32)
+
+    s2 = math.sqrt(2.0)
+    for name, cin, cout, k, has_norm in conv_layers(spec):
+        if has_norm:
+            if name.endswith("stem.conv1"):
+                conv(name, cin, cout, k, 1.0, False)
+                bn(name + ".norm", cout, 1.0 / 64.0)          # pixels are O(100) -> O(1)
+            elif name.endswith(".conv3"):
+                conv(name, cin, cout, k, s2, False)
+                bn(name + ".norm", cout, 0.35)                # small residual branch
+            elif name.endswith(".shortcut"):
+                conv(name, cin, cout, k, 1.0, False)
+                bn(name + ".norm", cout, 1.0)
+            else:
+                conv(name, cin, cout, k, s2, False)
+                bn(name + ".norm", cout, 1.0)
+        elif "fpn_lateral" in name:
+            conv(name, cin, cout, k, 0.35, True)
+        elif "fpn_output" in name:
+            conv(name, cin, cout, k, 0.6, True)
+        elif name.endswith("rpn_head.conv"):
+            conv(name, cin, cout, k, s2, True)
+        elif name.endswith("objectness_logits"):
+            conv(name, cin, cout, k, 1.0, True)
+        elif name.endswith("anchor_deltas"):
+            conv(name, cin, cout, k, 0.35, True)
+        else:                                                  # mask_fcn*
+            conv(name, cin, cout, k, s2, True)
+
+    def linear(name: str, cin: int, cout: int, gain: float) -> None:
+        W[name + ".weight"] = (rng.standard_normal((cout, cin)) * (gain / math.sqrt(cin))).astype(np.float32)
+        W[name + ".bias"] = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+
+    r = spec.box_pooler_resolution
+    K = spec.num_classes
+    linear("roi_heads.box_head.fc1", spec.fpn_out_channels * r * r, spec.box_fc_dim, s2)
+    linear("roi_heads.box_head.fc2", spec.box_fc_dim, spec.box_fc_dim, s2)
+    linear("roi_heads.box_predictor.cls_score", spec.box_fc_dim, K + 1, 1.6)
+    linear("roi_heads.box_predictor.bbox_pred", spec.box_fc_dim, 4 * K, 0.5)
+    if spec.mask_on:
+        d = spec.mask_conv_dim
+        # ConvTranspose2d weight is (Cin, Cout, 2, 2)
+        W["roi_heads.mask_head.deconv.weight"] = (rng.standard_normal((d, d, 2, 2)) * (s2 / math.sqrt(d))).astype(np.float32)
+        W["roi_heads.mask_head.deconv.bias"] = (rng.standard_normal(d) * 0.05).astype(np.float32)
+        W["roi_heads.mask_head.predictor.weight"] = (rng.standard_normal((K, d, 1, 1)) * (2.0 / math.sqrt(d))).astype(np.float32)
+        W["roi_heads.mask_head.predictor.bias"] = (rng.standard_normal(K) * 0.05).astype(np.float32)
+    return W
+
+
+def load_checkpoint(path: str) -> Dict[str, np.ndarray]:
+    """Read a detectron2-style checkpoint: ``.pth`` (``{'model': state_dict}``) via
+    ``torch.load(weights_only=True)`` or ``.npz``.  Returns fp32 numpy arrays by key."""
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
+    if path.endswith(".pkl"):
+        raise ValueError("model-zoo .pkl files are pickles and are not loaded here; convert to .pth/.npz")
+    import torch
+
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+    return {k: v.detach().float().numpy() for k, v in sd.items() if hasattr(v, "detach")}
+
+
+def infer_num_classes(W: Dict[str, np.ndarray]) -> int:
+    return int(W["roi_heads.box_predictor.cls_score.weight"].shape[0]) - 1
+
+
+# ----------------------------------------------------------------------------- packing
+def _fold_bn(W: Dict[str, np.ndarray], name: str, eps: float) -> Tuple[np.ndarray, np.ndarray]:
+    w = W[name + ".weight"].astype(np.float32)
+    g = W[name + ".norm.weight"].astype(np.float32)
+    b = W[name + ".norm.bias"].astype(np.float32)
+    m = W[name + ".norm.running_mean"].astype(np.float32)
+    v = W[name + ".norm.running_var"].astype(np.float32)
+    scale = g / np.sqrt(v + np.float32(eps))
+    return w * scale[:, None, None, None], b - m * scale
+
+
+def _ohwi(w: np.ndarray, cin_pad: int) -> np.ndarray:
+    """(Cout,Cin,KH,KW) fp32 -> (Cout, KH*KW*cin_pad) with K padded to K_ALIGN, fp16."""
+    cout, cin, kh, kw = w.shape
+    t = np.zeros((cout, kh, kw, cin_pad), np.float32)
+    t[..., :cin] = w.transpose(0, 2, 3, 1)
+    t = t.reshape(cout, kh * kw * cin_pad)
+    kpad = (t.shape[1] + K_ALIGN - 1) // K_ALIGN * K_ALIGN
+    out = np.zeros((cout, kpad), np.float32)
+    out[:, : t.shape[1]] = t
+    return out.astype(np.float16)
+
+
+def _pad_rows(w: np.ndarray, b: np.ndarray, mult: int) -> Tuple[np.ndarray, np.ndarray]:
+    cout = w.shape[0]
+    cp = (cout + mult - 1) // mult * mult
+    if cp == cout:
+        return w, b
+    w2 = np.zeros((cp,) + w.shape[1:], w.dtype)
+    w2[:cout] = w
+    b2 = np.zeros(cp, b.dtype)
+    b2[:cout] = b
+    return w2, b2
+
+
+def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Kernel-ready tensors keyed ``<layer>.w`` (fp16 [Cout_pad][Kpad]) / ``<layer>.b`` (fp32)."""
+    T: Dict[str, np.ndarray] = {}
+    for name, cin, cout, k, has_norm in conv_layers(spec):
+        if name.endswith("objectness_logits") or name.endswith("anchor_deltas"):
+            continue
+        if has_norm:
+            w, b = _fold_bn(W, name, spec.bn_eps)
+        else:
+            w, b = W[name + ".weight"].astype(np.float32), W[name + ".bias"].astype(np.float32)
+        cin_pad = STEM_CIN_PAD if name.endswith("stem.conv1") else cin
+        T[name + ".w"] = _ohwi(w, cin_pad)
+        T[name + ".b"] = b.astype(np.float32)
+    # RPN heads fused into one 1x1 conv: rows [0,A) objectness, [A,5A) deltas (a*4+d), padded to 16
+    p = "proposal_generator.rpn_head."
+    w = np.concatenate([W[p + "objectness_logits.weight"], W[p + "anchor_deltas.weight"]], 0).astype(np.float32)
+    b = np.concatenate([W[p + "objectness_logits.bias"], W[p + "anchor_deltas.bias"]], 0).astype(np.float32)
+    wp, bp = _pad_rows(_ohwi(w, w.shape[1]), b, 16)
+    T[p + "heads.w"], T[p + "heads.b"] = wp, bp
+    # box head: fc1 consumes RoI features laid out [7][7][C] (channels fastest) on the device,
+    # detectron2 flattens (C,7,7): permute the K axis once here.
+    r = spec.box_pooler_resolution
+    c = spec.fpn_out_channels
+    fc1 = W["roi_heads.box_head.fc1.weight"].astype(np.float32).reshape(-1, c, r, r).transpose(0, 2, 3, 1).reshape(-1, r * r * c)
+    T["roi_heads.box_head.fc1.w"] = _ohwi(fc1[:, :, None, None], fc1.shape[1])
+    T["roi_heads.box_head.fc1.b"] = W["roi_heads.box_head.fc1.bias"].astype(np.float32)
+    fc2 = W["roi_heads.box_head.fc2.weight"].astype(np.float32)
+    T["roi_heads.box_head.fc2.w"] = _ohwi(fc2[:, :, None, None], fc2.shape[1])
+    T["roi_heads.box_head.fc2.b"] = W["roi_heads.box_head.fc2.bias"].astype(np.float32)
+    # predictor: rows [0,K+1) class logits, [K+1, K+1+4K) box deltas, padded to 16
+    w = np.concatenate([W["roi_heads.box_predictor.cls_score.weight"], W["roi_heads.box_predictor.bbox_pred.weight"]], 0).astype(np.float32)
+    b = np.concatenate([W["roi_heads.box_predictor.cls_score.bias"], W["roi_heads.box_predictor.bbox_pred.bias"]], 0).astype(np.float32)
+    wp, bp = _pad_rows(_ohwi(w[:, :, None, None], w.shape[1]), b, 16)
+    T["roi_heads.box_predictor.w"], T["roi_heads.box_predictor.b"] = wp, bp
+    if spec.mask_on:
+        # deconv 2x2 s2 == 4 independent 1x1 convs: row (g*Cout + co), g = dy*2+dx
+        dw = W["roi_heads.mask_head.deconv.weight"].astype(np.float32)          # (Cin, Cout, 2, 2)
+        g = dw.transpose(2, 3, 1, 0).reshape(4 * dw.shape[1], dw.shape[0])      # (dy,dx,co) x ci
+        T["roi_heads.mask_head.deconv.w"] = _ohwi(g[:, :, None, None], g.shape[1])
+        T["roi_heads.mask_head.deconv.b"] = np.tile(W["roi_heads.mask_head.deconv.bias"].astype(np.float32), 4)
+        pw = W["roi_heads.mask_head.predictor.weight"].astype(np.float32)[:, :, 0, 0]      # (K, C)
+        T["roi_heads.mask_head.predictor.w"] = pw.astype(np.float32)           # fp32: tiny, used by a VALU dot
+        T["roi_heads.mask_head.predictor.b"] = W["roi_heads.mask_head.predictor.bias"].astype(np.float32)
+    return T
+
+
+def serialize(tensors: Dict[str, np.ndarray]) -> bytes:
+    """Flat blob: header (magic,u32 version,u32 n,u32 data_offset) + n entries
+    {char name[96]; u32 dtype; u32 ndim; u64 dims[4]; u64 offset; u64 nbytes} + aligned data."""
+    names = sorted(tensors)
+    ent_size = 96 + 4 + 4 + 32 + 8 + 8
+    hdr = 16
+    data_off = (hdr + ent_size * len(names) + ALIGN - 1) // ALIGN * ALIGN
+    entries = []
+    chunks = []
+    off = data_off
+    for n in names:
+        a = np.ascontiguousarray(tensors[n])
+        dt = {np.dtype(np.float16): DT_F16, np.dtype(np.float32): DT_F32, np.dtype(np.int32): DT_I32}[a.dtype]
+        dims = list(a.shape) + [1] * (4 - a.ndim)
+        nb = a.nbytes
+        entries.append(struct.pack("<96sII4QQQ", n.encode(), dt, a.ndim, *dims, off, nb))
+        chunks.append((off, a.tobytes()))
+        off = (off + nb + ALIGN - 1) // ALIGN * ALIGN
+    buf = bytearray(off)
+    buf[0:16] = struct.pack("<IIII", BLOB_MAGIC, BLOB_VERSION, len(names), data_off)
+    for i, e in enumerate(entries):
+        buf[hdr + i * ent_size: hdr + (i + 1) * ent_size] = e
+    for o, b in chunks:
+        buf[o: o + len(b)] = b
+    return bytes(buf)
+
+
+def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray]) -> bytes:
+    return serialize(engine_tensors(spec, W))
