@@ -1,0 +1,170 @@
+/* rs_engine.h -- C ABI of librs_engine.so, the MI355X (gfx950) Mask R-CNN R50-FPN inference engine.
+ *
+ * Drop-in boundary.  The reference has no FFI for this path: proj-roadsurf calls
+ * the STDL object-detector CLI (R:README.md:77-78), whose make_detections.py does, per tile,
+ *     outputs = DefaultPredictor(cfg)(cv2.imread(file))        [EXT d2: engine/defaults.py]
+ * configured by R:config/config_obj_detec.yaml:74-90 and R:config/detectron2_config_3bands.yaml.
+ * rs_engine_infer() replaces exactly that call (batched): HWC uint8 BGR tiles in, per-tile
+ * `Instances` fields out (pred_boxes XYXY in tile pixels, scores, pred_classes, pred_masks).
+ * Everything behind it -- resize, normalisation, ResNet-50/FPN, RPN, RoIAlign, box head, NMS, mask
+ * head, mask paste -- runs as hand-written HIP kernels; there is no CPU fallback.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 (RS_OK) or
+ * a negative error code and sets a message readable through rs_last_error().  An engine belongs
+ * to one process and one GPU and is NOT thread-safe.  The caller owns all host buffers; the
+ * engine owns its device memory; the weight blob may be freed after rs_engine_create().
+ */
+#ifndef RS_ENGINE_H
+#define RS_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_ABI_VERSION 1
+#define RS_SPEC_MAX_LEVELS 5
+#define RS_SPEC_MAX_ANCHORS 8
+#define RS_MASK_SIDE 28 /* 2 * ROI_MASK_HEAD.POOLER_RESOLUTION (R:219) */
+
+/* POD mirror of the detectron2 YAML fields the inference path reads
+ * (R:config/detectron2_config_3bands.yaml; line numbers per field). */
+typedef struct rs_spec {
+  int32_t struct_size;            /* sizeof(rs_spec), ABI check */
+  int32_t in_channels;            /* len(MODEL.PIXEL_MEAN) :81-84 (3; 4 = RGB+NIR tiles) */
+  int32_t flip_channels;          /* INPUT.FORMAT == "RGB" :26 -> reverse the channel axis of the BGR input */
+  float pixel_mean[4];            /* :81-84, applied in model-channel order (the BGR-listed quirk is preserved) */
+  float pixel_std[4];             /* :85-88 */
+  int32_t min_size_test;          /* :30 */
+  int32_t max_size_test;          /* :28 */
+  int32_t size_divisibility;      /* 32 (FPN) */
+  int32_t res_blocks[4];          /* RESNETS.DEPTH 50 -> 3,4,6,3 :100 */
+  int32_t stem_out_channels;      /* :110 */
+  int32_t res2_out_channels;      /* :108 */
+  int32_t stride_in_1x1;          /* :111 */
+  int32_t fpn_out_channels;       /* :69 */
+  int32_t num_levels;             /* len(RPN.IN_FEATURES) :231-236 */
+  int32_t num_anchors;            /* len(ASPECT_RATIOS) x len(SIZES[l]) :45-56 */
+  float cell_anchors[RS_SPEC_MAX_LEVELS][RS_SPEC_MAX_ANCHORS][4]; /* generate_cell_anchors, fp32 */
+  float anchor_offset;            /* :50 */
+  float rpn_bbox_reg_weights[4];  /* :224-228 */
+  int32_t rpn_pre_nms_topk;       /* :249 */
+  int32_t rpn_post_nms_topk;      /* :247 */
+  float rpn_nms_thresh;           /* :245 */
+  float rpn_min_size;             /* :90 */
+  int32_t num_classes;            /* :191 (CLI overrides from the COCO categories) */
+  float box_reg_weights[4];       /* :160-164 */
+  float score_thresh_test;        /* :194 / R:config/config_obj_detec.yaml:90 */
+  float nms_thresh_test;          /* :190 */
+  int32_t detections_per_image;   /* :321 */
+  int32_t box_fc_dim;             /* :167 */
+  int32_t box_pooler_resolution;  /* :172 */
+  int32_t mask_on;                /* :72 */
+  int32_t mask_pooler_resolution; /* :219 */
+  int32_t mask_num_conv;          /* :218 */
+  int32_t mask_conv_dim;          /* :215 */
+  float mask_threshold;           /* detector_postprocess default 0.5 */
+  float scale_clamp;              /* Box2BoxTransform: log(1000/16) */
+} rs_spec;
+
+/* Caller-allocated result block for n tiles, D = detections_per_image slots per tile.
+ * Entries [0, count[i]) of tile i are valid and sorted by score (descending). Any pointer except
+ * `count` may be NULL to skip that field. */
+typedef struct rs_dets {
+  int32_t* count;     /* [n] */
+  float* boxes;       /* [n][D][4]  x1,y1,x2,y2 in tile pixels   (Instances.pred_boxes) */
+  float* scores;      /* [n][D]                                  (Instances.scores) */
+  int32_t* classes;   /* [n][D]     0-based contiguous class id  (Instances.pred_classes) */
+  uint8_t* masks;     /* [n][D][h][ceil(w/8)] bit-packed rows, bit b of a byte = pixel 8*byte+b
+                         (Instances.pred_masks, >= mask_threshold) */
+  float* mask_probs;  /* [n][D][28][28] sigmoid probabilities before pasting */
+} rs_dets;
+
+typedef struct rs_engine rs_engine;
+
+/* Build an engine for tiles of one fixed shape (h, w, c) and batches of up to max_batch tiles.
+ * `weights` is the blob written by proj_roadsurf_amd.weights.pack_weights() (see "weight blob").
+ * `stream` is a hipStream_t to run on, or NULL to let the engine create its own. */
+int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, int device_ordinal,
+                     int max_batch, int tile_h, int tile_w, int tile_c, void* stream, rs_engine** out);
+void rs_engine_destroy(rs_engine* e);
+
+/* DefaultPredictor.__call__ for n tiles: tiles = [n][h][w][c] uint8, channel order as cv2.imread
+ * returns it (BGR).  Host buffers; does H2D, the forward, D2H, and waits. */
+int rs_engine_infer(rs_engine* e, const uint8_t* tiles_host, int n, rs_dets* out_host);
+
+/* Same forward with tiles already resident in device memory; enqueues on the engine's stream and
+ * returns without waiting.  Results stay on the device until rs_engine_fetch(). */
+int rs_engine_infer_device(rs_engine* e, const uint8_t* tiles_dev, int n);
+int rs_engine_sync(rs_engine* e);
+int rs_engine_fetch(rs_engine* e, int n, rs_dets* out_host);
+
+/* Stream the engine launches on (hipStream_t), for event timing by the caller. */
+void* rs_engine_stream(rs_engine* e);
+
+/* Per-stage timing with HIP events on the engine's stream (serialises the host per stage). */
+int rs_engine_set_profiling(rs_engine* e, int enabled);
+int rs_engine_stage_count(rs_engine* e);
+/* name_out: >= 96 bytes.  ms_total / calls accumulate since the last rs_engine_set_profiling().
+ * flops = algorithmic FLOPs of one call at the last batch size (0 for non-GEMM stages),
+ * bytes = algorithmic HBM bytes of one call (inputs read once + outputs written once). */
+int rs_engine_stage_info(rs_engine* e, int i, char* name_out, double* ms_total, int* calls, double* flops, double* bytes);
+
+/* Intermediate tensors by name (parity tests): device pointer, dtype (1 f16, 2 f32, 3 i32, 4 u8),
+ * up to 5 dims (dims[ndim..] = 1) and the spatial halo of NHWC activations. */
+int rs_engine_tensor(rs_engine* e, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo);
+int rs_engine_tensor_count(rs_engine* e);
+int rs_engine_tensor_name(rs_engine* e, int i, char* name_out /* >= 96 bytes */);
+
+/* Network input geometry chosen by ResizeShortestEdge for this tile shape. */
+int rs_engine_net_shape(rs_engine* e, int* resized_h, int* resized_w, int* padded_h, int* padded_w);
+
+/* -------- stand-alone operators on caller-owned device memory (unit parity tests) -------- */
+
+/* NHWC fp16 convolution / GEMM with fused epilogue.  in: [n][hi+2*in_halo][wi+2*in_halo][cin],
+ * w: [cout_rows][kpad] fp16 (k = (kh,kw,cin), cin fastest, kpad multiple of 64), bias fp32,
+ * out: [n][ho+2*out_halo][wo+2*out_halo][cout] fp16, or fp32 when out_f32.
+ * residual (optional) has the geometry of out; upsample_add (optional) is
+ * [n][ho/2+2*out_halo][wo/2+2*out_halo][cout] and is added at (y/2, x/2).
+ * variant: -1 auto, 0 = 128x128 tile, 1 = 256x64, 2 = 256x16 (fp32 out). use_glds: 1 = direct
+ * global->LDS staging (production), 0 = register staging (cross-check). */
+int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual,
+                 const void* upsample_add, int n, int hi, int wi, int cin, int in_halo, int kh, int kw,
+                 int stride, int pad, int cout, int kpad, int out_halo, int relu, int out_f32, int deconv2x,
+                 int variant, int use_glds, void* stream);
+
+/* Greedy NMS over `segments` independent lists of up to 1024 boxes in priority order
+ * (torchvision.ops.nms semantics: IoU > thresh suppresses). keep: [segments][cap] 0/1. */
+int rs_op_nms(const float* boxes, const int32_t* counts, const uint8_t* valid, uint8_t* keep,
+              int segments, int cap, float thresh, void* stream);
+
+/* ROIPooler + ROIAlign(aligned=True, sampling_ratio=0) over up to 4 NHWC fp16 levels (halo 1,
+ * 256 channels). rois: [n_rois][4] image coordinates, batch_index = roi / rois_per_image.
+ * out: [n_rois][P+2*out_halo][P+2*out_halo][256] fp16; levels_out optional [n_rois]. */
+int rs_op_roi_align(const void* const feats[4], const int32_t heights[4], const int32_t widths[4],
+                    const float scales[4], int nlevels, const float* rois, int n_rois, int rois_per_image,
+                    int P, int out_halo, void* out, int32_t* levels_out, void* stream);
+
+/* -------- host-only helpers (no GPU needed) -------- */
+/* detectron2 ResizeShortestEdge.get_output_shape. */
+void rs_resize_shape(int h, int w, int short_edge, int max_size, int* new_h, int* new_w);
+/* Pillow bilinear coefficient tables for in_size -> out_size: bounds[out][2] = (first, count),
+ * coeffs[out][ksize] 22-bit fixed point.  Returns ksize; pass NULL pointers to query it. */
+int rs_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs);
+
+int rs_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes);
+int rs_memcpy_h2d(void* dst_dev, const void* src_host, size_t nbytes);
+const char* rs_last_error(void);
+int rs_abi_version(void);
+
+/* Weight blob: little-endian; header {u32 magic 'RSEW', u32 version, u32 n, u32 data_offset};
+ * n entries {char name[96]; u32 dtype; u32 ndim; u64 dims[4]; u64 offset; u64 nbytes}; data
+ * 256-byte aligned.  Entries "<layer>.w" (fp16 [Cout_pad][Kpad], FrozenBN folded) and
+ * "<layer>.b" (fp32) for every conv/linear layer, detectron2 layer names. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RS_ENGINE_H */

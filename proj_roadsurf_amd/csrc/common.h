@@ -1,0 +1,88 @@
+// Shared declarations for the gfx950 engine (device + host side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RS_OK 0
+#define RS_ERR_ARG -1
+#define RS_ERR_HIP -2
+#define RS_ERR_BLOB -3
+#define RS_ERR_UNSUPPORTED -4
+
+// Set by the failing call; read through rs_last_error().
+void rs_set_error(const char* fmt, ...);
+
+#define RS_HIP(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      rs_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+      return RS_ERR_HIP;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+#define RS_CHECK(cond, code, ...)  \
+  do {                             \
+    if (!(cond)) {                 \
+      rs_set_error(__VA_ARGS__);   \
+      return (code);               \
+    }                              \
+  } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ conv / GEMM
+// Activations are NHWC fp16 with a zero halo: a tensor of logical size (N,H,W,C) is stored as
+// [N][H+2*pad][W+2*pad][Cs] and only the interior is ever written, so 3x3/7x7 convolutions need
+// no bounds checks and the loader is a pure strided gather.
+struct ConvParams {
+  const half_t* in;
+  const half_t* w;      // [Cout_pad][Kpad] fp16, K = (kh,kw,cin) with cin fastest
+  const float* bias;    // [Cout_pad]
+  void* out;            // fp16 (or fp32 if out_f32)
+  const half_t* res;    // residual, same geometry as out (nullptr = none)
+  const half_t* up;     // coarser map added at (y/2,x/2) (FPN top-down), nullptr = none
+  const int* m_count;   // optional device counter: rows = min(M, *m_count * m_mul)
+  const int* koff;      // SMALLC only: element offset of every 8-element K chunk
+  int m_mul;
+  int M;                // N*Ho*Wo
+  int Ho, Wo;
+  int in_Hp, in_Wp, in_Cs, in_off;   // in_off = in_pad - conv_pad
+  int stride;
+  int KH, KW, Cin;
+  int Kpad;
+  int Cout;             // channels actually stored
+  int out_Hp, out_Wp, out_Cs, out_pad;
+  int up_Hp, up_Wp, up_Cs, up_pad;
+  int relu;
+  int mode;             // 0 = conv, 1 = 2x2 stride-2 transposed conv as 4 GEMMs + pixel shuffle
+  int out_f32;
+};
+
+int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant /* -1 auto */, int use_glds);
+
+// ------------------------------------------------------------------ tile ingest / pooling
+struct PreprocParams {
+  const uint8_t* tiles;   // [N][H][W][C] uint8, channel order as cv2.imread (BGR)
+  half_t* out;            // [N][Hp+6][Wp+6][8] fp16, halo 3
+  const int* hb;          // [new_w][2]  (first source column, tap count)
+  const int* hk;          // [new_w][ksh] Pillow fixed-point coefficients (22 bit)
+  const int* vb;          // [new_h][2]
+  const int* vk;          // [new_h][ksv]
+  int N, H, W, C;
+  int new_h, new_w;       // resized image size
+  int out_Hp, out_Wp;     // padded dims incl. halo
+  int ksh, ksv;
+  int need_h, need_v;
+  int flip;               // 1: model channel c reads source channel C-1-c
+  float mean[4], stdv[4];
+};
+int launch_preprocess(const PreprocParams& p, hipStream_t s);
+int launch_maxpool(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
+int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);

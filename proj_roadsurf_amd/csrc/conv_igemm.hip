@@ -1,0 +1,320 @@
+// Implicit-GEMM convolution / GEMM for gfx950 (MI355X), fp16 in, fp32 accumulate on MFMA.
+//
+// Replaces, on the hot path: cuDNN conv fwd, cuBLAS sgemm and the
+// cuDNN 2x2 transposed conv that detectron2 0.6 reaches through ATen
+// ([EXT d2: layers/wrappers.py Conv2d, modeling/backbone/{resnet,fpn}.py,
+//   modeling/roi_heads/{box_head,mask_head}.py]; layer list fixed by
+//   R:config/detectron2_config_3bands.yaml:57-112,159-221).
+//
+// Formulation: D[channel][pixel] = sum_k W[channel][k] * X[pixel][k], k = (kh, kw, cin).
+//   * weights are the MFMA "A" operand, activations the "B" operand, so each lane ends up with
+//     4*MI CONSECUTIVE output channels of one pixel -> the epilogue stores 16-byte NHWC pieces
+//     straight from registers (bias + residual + FPN top-down add + ReLU fused, fp32 math).
+//   * both operands are staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip),
+//     128-byte LDS rows, XOR swizzle applied on the per-lane SOURCE address and on the ds_read
+//     (LDS destination stays lane-linear), double buffered, one barrier per 64-deep K step.
+//   * activations carry a zero halo (common.h), so the gather has no bounds checks.
+// Tile variants (pixels x channels per workgroup): 128x128 (4 waves 2x2), 256x64 (4 waves 4x1),
+// 256x16 fp32-out (small heads).  Each wave owns NJ*16 pixels x MI*16 channels.
+#include "common.h"
+
+namespace {
+
+template <int WPX, int WCH, int MI, int NJ>
+struct Tile {
+  static constexpr int NW = WPX * WCH;
+  static constexpr int NT = NW * 64;
+  static constexpr int BM = WPX * NJ * 16;   // pixels
+  static constexpr int BN = WCH * MI * 16;   // channels
+  static constexpr int STAGE = (BM + BN) * 128;
+  static constexpr int LDS = 2 * STAGE + 1024;   // + K-chunk offset table (small-Cin path)
+};
+
+__device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int WPX, int WCH, int MI, int NJ, bool SMALLC, bool GLDS>
+__global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvParams p) {
+  using T = Tile<WPX, WCH, MI, NJ>;
+  constexpr int NW = T::NW, BM = T::BM, BN = T::BN;
+  constexpr int PA = BM / (NW * 8);               // activation staging passes per K step
+  constexpr int PW = (BN + NW * 8 - 1) / (NW * 8);  // weight staging passes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wpx = wave / WCH, wch = wave % WCH;
+
+  int M = p.M;
+  if (p.m_count) {
+    long long mc = (long long)(*p.m_count) * p.m_mul;
+    if (mc < M) M = (int)mc;
+  }
+  // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of
+  // logical tiles, channel tiles fastest, so the tiles that re-read one activation panel (other
+  // channel tile, neighbouring rows of a 3x3) hit the same L2.
+  const int tiles_n = (p.Cout * (p.mode == 1 ? 4 : 1) + BN - 1) / BN;
+  const int nblk = gridDim.x;
+  int L;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7;
+    L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const int tile_n = L % tiles_n;
+  const int tile_m = L / tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+  if (m0 >= M) return;
+
+  // ---- per-lane staging source pointers -------------------------------------------------
+  const int lrow = lane >> 3;      // row inside an 8-row glds piece
+  const int lchk = lane & 7;       // 16-byte slot inside the 128-byte LDS row
+  const half_t* aptr[PA];
+#pragma unroll
+  for (int ps = 0; ps < PA; ++ps) {
+    int m = m0 + ps * NW * 8 + wave * 8 + lrow;
+    if (m >= M) m = M - 1;
+    const int x = m % p.Wo;
+    const int t = m / p.Wo;
+    const int y = t % p.Ho;
+    const int n = t / p.Ho;
+    const long long base =
+        ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x * p.stride + p.in_off) * p.in_Cs;
+    // LDS slot lchk of row r holds data chunk (lchk ^ (r & 7)); r & 7 == lrow here.
+    aptr[ps] = p.in + base + (SMALLC ? 0 : ((lchk ^ lrow) * 8));
+  }
+  const half_t* wptr[PW];
+#pragma unroll
+  for (int ps = 0; ps < PW; ++ps) {
+    const int row = ps * NW * 8 + wave * 8 + lrow;
+    const int key = (row & 3) | (((row / (4 * MI)) & 1) << 2);
+    const int rr = row < BN ? row : BN - 1;
+    wptr[ps] = p.w + (long long)(n0 + rr) * p.Kpad + (lchk ^ key) * 8;
+  }
+
+  const int nk = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> 6));
+  int* koff_s = (int*)(smem + 2 * T::STAGE);
+  if constexpr (SMALLC) {
+    for (int i = tid; i < (p.Kpad >> 3); i += T::NT) koff_s[i] = p.koff[i];
+    __syncthreads();
+  }
+
+  auto stage = [&](int buf, int t, int a_off) {
+    char* abase = smem + buf * T::STAGE;
+    char* wbase = abase + BM * 128;
+#pragma unroll
+    for (int ps = 0; ps < PA; ++ps) {
+      const half_t* g;
+      if constexpr (SMALLC) {
+        g = aptr[ps] + koff_s[t * 8 + (lchk ^ lrow)];
+      } else {
+        g = aptr[ps] + a_off;
+      }
+      char* dst = abase + (ps * NW * 8 + wave * 8) * 128;
+      if constexpr (GLDS) {
+        glds16(g, dst);
+      } else {
+        *(half8*)(dst + lane * 16) = *(const half8*)g;
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < PW; ++ps) {
+      if (ps * NW * 8 + wave * 8 < BN) {   // wave-uniform
+        const half_t* g = wptr[ps] + t * 64;
+        char* dst = wbase + (ps * NW * 8 + wave * 8) * 128;
+        if constexpr (GLDS) {
+          glds16(g, dst);
+        } else {
+          *(half8*)(dst + lane * 16) = *(const half8*)g;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment read offsets (bytes inside a stage) ---------------------------------------
+  const int fi = lane & 15;        // MFMA row (weights) / column (pixels) index of this lane
+  const int fq = lane >> 4;        // k-slice of this lane
+  const int fkey = lane & 7;       // == key of every row this lane reads
+  int w_off[MI], x_off[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wch * MI * 16 + (fi >> 2) * 4 * MI + i * 4 + (fi & 3);
+    w_off[i] = BM * 128 + row * 128;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) x_off[j] = (wpx * NJ * 16 + j * 16 + fi) * 128;
+  const int c0_off = ((fq) ^ fkey) * 16;        // kk = 0
+  const int c1_off = ((4 + fq) ^ fkey) * 16;    // kk = 1
+
+  // ---- K loop ------------------------------------------------------------------------------
+  int kh = 0, kw = 0, c0 = 0;   // position of the NEXT K step to stage
+  auto next_off = [&]() {
+    const int off = (kh * p.in_Wp + kw) * p.in_Cs + c0;
+    c0 += 64;
+    if (c0 >= p.Cin) {
+      c0 = 0;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+    return off;
+  };
+  stage(0, 0, SMALLC ? 0 : next_off());
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nk) stage((t + 1) & 1, t + 1, SMALLC ? 0 : next_off());
+    const char* sb = smem + (t & 1) * T::STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int co = kk ? c1_off : c0_off;
+      half8 wf[MI], xf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) wf[i] = *(const half8*)(sb + w_off[i] + co);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xf[j] = *(const half8*)(sb + x_off[j] + co);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds channels cb .. cb+4*MI-1 of pixel (nj, fi) ------------------------
+  const int ch_local = wch * MI * 16 + fq * 4 * MI;
+  const int crow = n0 + ch_local;                 // row in the (possibly 4x grouped) weight matrix
+  int g = 0, cb = crow;
+  if (p.mode == 1) { g = crow / p.Cout; cb = crow % p.Cout; }
+  float bias[4 * MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
+    bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int m = m0 + wpx * NJ * 16 + j * 16 + fi;
+    if (m >= M) continue;
+    const int x = m % p.Wo;
+    const int t = m / p.Wo;
+    const int y = t % p.Ho;
+    const int n = t / p.Ho;
+    int oy = y, ox = x;
+    if (p.mode == 1) { oy = 2 * y + (g >> 1); ox = 2 * x + (g & 1); }
+    const long long opix = (long long)(n * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad;
+    float v[4 * MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+    if (p.res) {
+      const half_t* rp = p.res + opix * p.out_Cs + cb;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const half4 h = *(const half4*)(rp + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+      }
+    }
+    if (p.up) {
+      const long long upix = (long long)(n * p.up_Hp + (y >> 1) + p.up_pad) * p.up_Wp + (x >> 1) + p.up_pad;
+      const half_t* up = p.up + upix * p.up_Cs + cb;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const half4 h = *(const half4*)(up + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+      }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 4 * MI; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    if (p.out_f32) {
+      float* op = (float*)p.out + opix * p.out_Cs + cb;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) *(f32x4*)(op + i * 4) = f32x4{v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+    } else {
+      half_t* op = (half_t*)p.out + opix * p.out_Cs + cb;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float f = v[i * 4 + r];
+          f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+          h[r] = (half_t)f;
+        }
+        *(half4*)(op + i * 4) = h;
+      }
+    }
+  }
+}
+
+template <int WPX, int WCH, int MI, int NJ, bool SMALLC>
+int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
+  using T = Tile<WPX, WCH, MI, NJ>;
+  const int rows = p.Cout * (p.mode == 1 ? 4 : 1);
+  const int tiles_n = cdiv(rows, T::BN);
+  const int tiles_m = cdiv(p.M, T::BM);
+  const long long nblk = (long long)tiles_n * tiles_m;
+  RS_CHECK(nblk > 0 && nblk < (1ll << 31), RS_ERR_ARG, "conv: bad grid %lld", nblk);
+  RS_CHECK(rows % T::BN == 0 || T::BN <= 16, RS_ERR_ARG, "conv: Cout rows %d not a multiple of tile %d", rows, T::BN);
+  auto kg = conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, true>;
+  auto kr = conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, false>;
+  auto k = use_glds ? kg : kr;
+  static bool attr_g = false, attr_r = false;
+  bool& done = use_glds ? attr_g : attr_r;
+  if (!done) {
+    RS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS));
+    done = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS, stream, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+}  // namespace
+
+// variant: 0 = 128x128, 1 = 256x64, 2 = 256x16 (small heads), -1 = choose
+int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant, int use_glds) {
+  RS_CHECK(p.M > 0, RS_ERR_ARG, "conv: M=%d", p.M);
+  RS_CHECK(p.Kpad % 64 == 0, RS_ERR_ARG, "conv: Kpad %d not a multiple of 64", p.Kpad);
+  const bool smallc = p.Cin < 64;
+  if (smallc) {
+    RS_CHECK(p.Cin == 8 && p.koff != nullptr, RS_ERR_ARG, "conv: small-Cin path needs Cin == 8 and a koff table");
+  } else {
+    RS_CHECK(p.Cin % 64 == 0, RS_ERR_ARG, "conv: Cin %d not a multiple of 64", p.Cin);
+    RS_CHECK(p.KH * p.KW * p.Cin <= p.Kpad, RS_ERR_ARG, "conv: K exceeds Kpad");
+  }
+  const int rows = p.Cout * (p.mode == 1 ? 4 : 1);
+  int v = force_variant;
+  if (v < 0) v = rows <= 16 ? 2 : (rows % 128 == 0 ? 0 : 1);
+  RS_CHECK(!(p.mode == 1 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
+  if (smallc) {
+    RS_CHECK(v == 1, RS_ERR_ARG, "conv: small-Cin path is built for the 256x64 tile only (Cout=%d)", p.Cout);
+    return launch_variant<4, 1, 4, 4, true>(p, stream, use_glds);
+  }
+  switch (v) {
+    case 0:
+      RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 0 needs Cout %% 128 == 0");
+      return launch_variant<2, 2, 4, 4, false>(p, stream, use_glds);
+    case 1:
+      RS_CHECK(rows % 64 == 0, RS_ERR_ARG, "conv: variant 1 needs Cout %% 64 == 0");
+      return launch_variant<4, 1, 4, 4, false>(p, stream, use_glds);
+    case 2:
+      RS_CHECK(rows % 16 == 0 && p.out_f32, RS_ERR_ARG, "conv: variant 2 is the 16-channel-tile fp32-out head kernel");
+      return launch_variant<4, 1, 1, 4, false>(p, stream, use_glds);
+    default:
+      rs_set_error("conv: unknown variant %d", v);
+      return RS_ERR_ARG;
+  }
+}

@@ -1,0 +1,120 @@
+// Parameter blocks of the proposal / detection kernels (detect_kernels.hip).
+#pragma once
+#include "common.h"
+
+#define RS_MAX_LEVELS 5
+#define RS_MAX_ANCHORS 8
+
+struct RpnParams {
+  const float* head[RS_MAX_LEVELS];   // [N][H][W][cs] fp32: channels [0,A) logits, [A,5A) deltas (a*4+d)
+  uint32_t* keys[RS_MAX_LEVELS];      // scratch [N][H*W*A]
+  int H[RS_MAX_LEVELS], W[RS_MAX_LEVELS], stride[RS_MAX_LEVELS];
+  float base[RS_MAX_LEVELS][RS_MAX_ANCHORS][4];   // cell anchors (fp32 of the float64 formula)
+  float offset;
+  int L, A, N, cs;
+  int topk;                 // PRE_NMS_TOPK_TEST (<= 1024)
+  float img_h, img_w;       // clip size = resized image size
+  float wx, wy, ww, wh, scale_clamp, min_size;
+  float* cand_boxes;        // [N][L][1024][4]
+  float* cand_scores;       // [N][L][1024]
+  uint8_t* cand_valid;      // [N][L][1024]
+  int* cand_count;          // [N][L]
+  int* cand_index;          // optional [N][L][1024]: anchor index (y*W+x)*A+a
+};
+
+struct NmsParams {
+  const float* boxes;       // [S][cap][4], priority order
+  const int* count;         // [S]
+  const uint8_t* valid;     // [S][cap] or nullptr
+  uint8_t* keep;            // [S][cap]
+  int cap;                  // 1024
+  float thresh;
+};
+
+struct RpnMergeParams {
+  const float* cand_boxes;
+  const float* cand_scores;
+  const uint8_t* keep;
+  const int* cand_count;
+  int L, post_topk, cap;
+  float* prop_boxes;        // [N][cap][4]
+  float* prop_scores;       // [N][cap]
+  int* prop_level;          // optional [N][cap]
+  int* prop_count;          // [N]
+};
+
+struct RoiAlignParams {
+  const half_t* feat[4];    // p2..p5, NHWC fp16, halo 1, 256 channels
+  int H[4], W[4];
+  float scale[4];
+  int nlevels, C;
+  const float* rois;        // [slots][4]
+  const int* slot_list;     // optional entry -> slot
+  const int* n_entries;     // optional device count of entries
+  const int* per_image_count;   // optional: slot valid iff rank < count[image]
+  int S;                    // entry capacity (grid size)
+  int slots_per_image;
+  half_t* out;              // [entry][P+2*out_pad][P+2*out_pad][256]
+  int P, out_pad;
+  int* out_level;           // optional [entry]
+};
+
+struct BoxCandParams {
+  const float* pred;        // [N][cap][cs]: [0,K] class logits, then 4K deltas
+  const float* prop_boxes;  // [N][cap][4]
+  const int* prop_count;    // [N]
+  int K, cap, cs;
+  float wx, wy, ww, wh, scale_clamp, img_h, img_w, score_thresh;
+  float* dec_boxes;         // [N][cap][K][4]
+  float* dec_scores;        // [N][cap][K]
+  float* seg_boxes;         // [N][K][1024][4]
+  int* seg_roi;             // [N][K][1024]
+  int* seg_count;           // [N][K]
+};
+
+struct DetMergeParams {
+  const float* dec_boxes;
+  const float* dec_scores;
+  const int* seg_roi;
+  const int* seg_count;
+  const uint8_t* keep;      // [N][K][1024]
+  int K, cap, dets_per_image;
+  float scale_x, scale_y, out_w, out_h;
+  float* det_boxes_net;     // [N][D][4] network-input coordinates (mask RoIs)
+  float* det_boxes;         // [N][D][4] tile coordinates
+  float* det_scores;        // [N][D]
+  int* det_classes;         // [N][D]
+  int* det_roi;             // optional [N][D]
+  int* det_count;           // [N]
+};
+
+struct MaskPredictParams {
+  const half_t* in;         // [entry][S][S][256]
+  const float* w;           // [K][256]
+  const float* b;           // [K]
+  const int* slot_list;
+  const int* det_classes;   // [slots]
+  const int* n_entries;
+  float* out;               // [slots][S][S]
+  int S;
+};
+
+struct PasteParams {
+  const float* probs;       // [slots][S][S]
+  const float* det_boxes;   // [slots][4] tile coordinates
+  const int* slot_list;
+  const int* n_entries;
+  uint8_t* out;             // [slots][out_h][ceil(out_w/8)], bit b of byte = pixel 8*byte+b
+  int S, out_h, out_w;
+  float threshold;
+};
+
+int launch_rpn_select(const RpnParams& p, hipStream_t s);
+int launch_nms(const NmsParams& p, int segments, hipStream_t s);
+int launch_rpn_merge(const RpnMergeParams& p, int N, hipStream_t s);
+int launch_roi_align(const RoiAlignParams& p, hipStream_t s);
+int launch_box_candidates(const BoxCandParams& p, int N, hipStream_t s);
+int launch_det_merge(const DetMergeParams& p, int N, hipStream_t s);
+int launch_det_compact(const int* det_count, int N, int D, int* slot_list, int* total, hipStream_t s);
+int launch_mask_predict(const MaskPredictParams& p, int capacity_entries, hipStream_t s);
+int launch_paste_masks(const PasteParams& p, int capacity_entries, hipStream_t s);

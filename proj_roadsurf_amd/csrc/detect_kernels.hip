@@ -1,0 +1,682 @@
+// Proposal / detection "glue" of the Mask R-CNN forward on gfx950: everything between the conv
+// GEMMs.  All box and score arithmetic is fp32 in the same operation order as detectron2 0.6 /
+// torchvision 0.11.3 (this file is compiled with -ffp-contract=off so no mul+add is fused), all
+// index work is exact; capacities are fixed and counts stay on the device (no host sync).
+//
+//   rpn_select_kernel   RPN.predict_proposals / find_top_rpn_proposals, per (image, level):
+//                       radix-select top-k logits (ties: lower anchor index first), bitonic sort,
+//                       anchor-free decode (anchors recomputed from the index), clip, non-empty.
+//                       [EXT d2: modeling/proposal_generator/{rpn,proposal_utils}.py,
+//                        modeling/anchor_generator.py, modeling/box_regression.py]  R:40-56,222-251
+//   nms_kernel          torchvision nms (IoU > thr suppresses), one workgroup per (image, level) or
+//                       (image, class): 64-bit suppression bitmask in LDS + single-wave scan.
+//                       [EXT tv: csrc/ops/cuda/nms_kernel.cu]
+//   rpn_merge_kernel    batched_nms result order (score desc) + POST_NMS_TOPK.   R:247
+//   roi_align_kernel    ROIPooler level assignment + ROIAlign(aligned=True, sampling_ratio=0)
+//                       [EXT d2: modeling/poolers.py; EXT tv: csrc/ops/cuda/roi_align_kernel.cu] R:172-174,219-221
+//   box_candidates_kernel / det_merge_kernel   fast_rcnn_inference_single_image + the box part of
+//                       detector_postprocess  [EXT d2: modeling/roi_heads/fast_rcnn.py,
+//                       modeling/postprocessing.py]  R:160-165,190,194,321
+//   mask_predict_kernel mask predictor 1x1 on the predicted class + sigmoid (mask_rcnn_inference)
+//   paste_masks_kernel  paste_masks_in_image (grid_sample bilinear, zeros, align_corners=False) >= thr,
+//                       bit-packed output  [EXT d2: layers/mask_ops.py]
+#include "detect.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t fkey(float f) {
+  f = f + 0.0f;   // -0 -> +0 so that equal floats have equal keys
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// descending bitonic sort of n (power of two) 64-bit keys in LDS
+template <int T>
+__device__ void bitonic_sort_desc(unsigned long long* s, int n, int tid) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n; i += T) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = s[i], b = s[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) { s[i] = b; s[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Box2BoxTransform.apply_deltas for one box, one delta quadruple (fp32, detectron2 op order).
+__device__ __forceinline__ void apply_deltas(const float b[4], const float d[4], float wx, float wy, float ww, float wh,
+                                             float scale_clamp, float out[4]) {
+  const float widths = b[2] - b[0];
+  const float heights = b[3] - b[1];
+  const float ctr_x = b[0] + 0.5f * widths;
+  const float ctr_y = b[1] + 0.5f * heights;
+  const float dx = d[0] / wx, dy = d[1] / wy;
+  float dw = d[2] / ww, dh = d[3] / wh;
+  dw = dw > scale_clamp ? scale_clamp : dw;
+  dh = dh > scale_clamp ? scale_clamp : dh;
+  const float pcx = dx * widths + ctr_x;
+  const float pcy = dy * heights + ctr_y;
+  const float pw = expf(dw) * widths;
+  const float ph = expf(dh) * heights;
+  out[0] = pcx - 0.5f * pw;
+  out[1] = pcy - 0.5f * ph;
+  out[2] = pcx + 0.5f * pw;
+  out[3] = pcy + 0.5f * ph;
+}
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// ---------------------------------------------------------------------------------------------
+// RPN: select + decode
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
+  __shared__ unsigned long long list[1024];
+  __shared__ int hist[256];
+  __shared__ unsigned int sh_prefix, sh_need, sh_cnt, sh_idx_thr;
+  const int l = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int H = p.H[l], W = p.W[l], A = p.A;
+  const int HW = H * W;
+  const int n_el = HW * A;
+  const int k = n_el < p.topk ? n_el : p.topk;
+  const float* head = p.head[l] + (long long)n * HW * p.cs;
+  uint32_t* keys = p.keys[l] + (long long)n * n_el;
+
+  // pass 0: ordered keys to scratch + histogram of the top digit
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  for (int e = tid; e < n_el; e += 1024) {
+    const int pix = e / A, a = e - pix * A;
+    const uint32_t key = fkey(head[(long long)pix * p.cs + a]);
+    keys[e] = key;
+    atomicAdd(&hist[key >> 24], 1);
+  }
+  __syncthreads();
+  if (tid == 0) { sh_prefix = 0; sh_need = (unsigned)k; }
+  __syncthreads();
+  for (int d = 0; d < 4; ++d) {
+    const int shift = 24 - 8 * d;
+    if (d > 0) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const uint32_t prefix = sh_prefix;
+      for (int e = tid; e < n_el; e += 1024) {
+        const uint32_t key = keys[e];
+        if ((key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      unsigned need = sh_need, acc = 0;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (acc + (unsigned)hist[b] >= need) break;
+        acc += (unsigned)hist[b];
+      }
+      sh_need = need - acc;            // still to take from bin b
+      sh_prefix |= ((unsigned)b) << shift;
+      sh_cnt = (unsigned)hist[b];      // elements in bin b under the current prefix
+    }
+    __syncthreads();
+  }
+  const uint32_t T = sh_prefix;       // k-th largest key
+  // ties on the threshold key: take the lowest anchor indices (radix select on the index)
+  if (tid == 0) sh_idx_thr = 0xFFFFFFFFu;
+  __syncthreads();
+  if (sh_cnt > sh_need) {              // uniform
+    if (tid == 0) sh_prefix = 0;
+    __syncthreads();
+    for (int d = 0; d < 3; ++d) {
+      const int shift = 16 - 8 * d;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const uint32_t prefix = sh_prefix;
+      for (int e = tid; e < n_el; e += 1024) {
+        if (keys[e] == T && (d == 0 || ((uint32_t)e >> (shift + 8)) == (prefix >> (shift + 8))))
+          atomicAdd(&hist[((uint32_t)e >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned need = sh_need, acc = 0;
+        int b = 0;
+        for (; b < 255; ++b) {
+          if (acc + (unsigned)hist[b] >= need) break;
+          acc += (unsigned)hist[b];
+        }
+        sh_need = need - acc;
+        sh_prefix |= ((unsigned)b) << shift;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) sh_idx_thr = sh_prefix;   // largest index taken among the ties
+    __syncthreads();
+  }
+  const uint32_t idx_thr = sh_idx_thr;
+  if (tid == 0) sh_cnt = 0;
+  list[tid] = 0ull;
+  __syncthreads();
+  for (int e = tid; e < n_el; e += 1024) {
+    const uint32_t key = keys[e];
+    if (key > T || (key == T && (uint32_t)e <= idx_thr)) {
+      const unsigned pos = atomicAdd(&sh_cnt, 1u);
+      if (pos < 1024u) list[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e);
+    }
+  }
+  __syncthreads();
+  bitonic_sort_desc<1024>(list, 1024, tid);
+
+  const long long ob = ((long long)n * p.L + l) * 1024;
+  if (tid == 0) p.cand_count[n * p.L + l] = k;
+  if (tid < k) {
+    const unsigned long long c = list[tid];
+    const uint32_t e = 0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull);
+    const float score = fkey_inv((uint32_t)(c >> 32));
+    const int pix = e / A, a = e - pix * A;
+    const int y = pix / W, x = pix - y * W;
+    const float sx = (float)(x * p.stride[l]) + p.offset * (float)p.stride[l];
+    const float sy = (float)(y * p.stride[l]) + p.offset * (float)p.stride[l];
+    float anc[4] = {sx + p.base[l][a][0], sy + p.base[l][a][1], sx + p.base[l][a][2], sy + p.base[l][a][3]};
+    const float* dp = head + (long long)pix * p.cs + A + a * 4;
+    float d[4] = {dp[0], dp[1], dp[2], dp[3]};
+    float b[4];
+    apply_deltas(anc, d, p.wx, p.wy, p.ww, p.wh, p.scale_clamp, b);
+    b[0] = clampf(b[0], 0.f, p.img_w);
+    b[1] = clampf(b[1], 0.f, p.img_h);
+    b[2] = clampf(b[2], 0.f, p.img_w);
+    b[3] = clampf(b[3], 0.f, p.img_h);
+    float* ob4 = p.cand_boxes + (ob + tid) * 4;
+    ob4[0] = b[0]; ob4[1] = b[1]; ob4[2] = b[2]; ob4[3] = b[3];
+    p.cand_scores[ob + tid] = score;
+    p.cand_valid[ob + tid] = ((b[2] - b[0]) > p.min_size && (b[3] - b[1]) > p.min_size) ? 1 : 0;
+    if (p.cand_index) p.cand_index[ob + tid] = (int)e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NMS over a segment of <= 1024 boxes already in priority order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* sbox = (float4*)smem;                                       // 1024 * 16
+  float* sarea = (float*)(smem + 1024 * 16);                          // 1024 * 4
+  unsigned long long* mask = (unsigned long long*)(smem + 1024 * 20); // 1024 * 16 * 8
+  unsigned long long* sremoved = (unsigned long long*)(smem + 1024 * 20 + 1024 * 128);   // 16 * 8
+  const int s = blockIdx.x, tid = threadIdx.x;
+  int n = p.count[s];
+  if (n > 1024) n = 1024;
+  const float* boxes = p.boxes + (long long)s * p.cap * 4;
+  const uint8_t* valid = p.valid ? p.valid + (long long)s * p.cap : nullptr;
+  uint8_t* keep = p.keep + (long long)s * p.cap;
+  for (int i = tid; i < p.cap; i += 1024) keep[i] = 0;
+  if (tid < 16) sremoved[tid] = 0ull;
+  __syncthreads();
+  if (tid < n) {
+    const float4 b = *(const float4*)(boxes + tid * 4);
+    sbox[tid] = b;
+    sarea[tid] = (b.z - b.x) * (b.w - b.y);
+    if (valid && !valid[tid]) atomicOr(&sremoved[tid >> 6], 1ull << (tid & 63));
+  }
+  __syncthreads();
+  const int nw = (n + 63) >> 6;
+  for (int idx = tid; idx < nw * n; idx += 1024) {
+    const int w = idx / n, i = idx - w * n;
+    unsigned long long bits = 0ull;
+    const int j0 = w * 64;
+    if (j0 + 63 > i) {
+      const float4 a = sbox[i];
+      const float sa = sarea[i];
+      const int jend = (n - j0) < 64 ? (n - j0) : 64;
+      for (int b = 0; b < jend; ++b) {
+        const int j = j0 + b;
+        if (j <= i) continue;
+        const float4 q = sbox[j];
+        const float iw = fmaxf(fminf(a.z, q.z) - fmaxf(a.x, q.x), 0.f);
+        const float ih = fmaxf(fminf(a.w, q.w) - fmaxf(a.y, q.y), 0.f);
+        const float inter = iw * ih;
+        const float iou = inter / (sa + sarea[j] - inter);
+        if (iou > p.thresh) bits |= 1ull << b;
+      }
+    }
+    mask[(long long)i * 16 + w] = bits;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int lane = tid;
+    unsigned long long removed = lane < 16 ? sremoved[lane] : 0ull;
+    for (int i = 0; i < n; ++i) {
+      const unsigned long long rw = __shfl(removed, i >> 6);
+      if (!((rw >> (i & 63)) & 1ull)) {
+        if (lane == 0) keep[i] = 1;
+        if (lane < nw) removed |= mask[(long long)i * 16 + lane];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RPN: merge levels (score desc, ties: lower (level, rank) first), keep post_topk
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rpn_merge_kernel(const RpnMergeParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* list = (unsigned long long*)smem;   // 8192
+  __shared__ unsigned int cnt;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) cnt = 0;
+  for (int i = tid; i < 8192; i += 1024) list[i] = 0ull;
+  __syncthreads();
+  for (int l = 0; l < p.L; ++l) {
+    const int c = p.cand_count[n * p.L + l];
+    const long long ob = ((long long)n * p.L + l) * 1024;
+    for (int i = tid; i < c; i += 1024) {
+      if (p.keep[ob + i]) {
+        const unsigned pos = atomicAdd(&cnt, 1u);
+        list[pos] = ((unsigned long long)fkey(p.cand_scores[ob + i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(l * 1024 + i));
+      }
+    }
+  }
+  __syncthreads();
+  bitonic_sort_desc<1024>(list, 8192, tid);
+  const int total = (int)cnt < p.post_topk ? (int)cnt : p.post_topk;
+  if (tid == 0) p.prop_count[n] = total;
+  for (int i = tid; i < p.cap; i += 1024) {
+    float* o = p.prop_boxes + ((long long)n * p.cap + i) * 4;
+    if (i < total) {
+      const uint32_t pos = 0xFFFFFFFFu - (uint32_t)(list[i] & 0xFFFFFFFFull);
+      const long long src = (long long)n * p.L * 1024 + pos;
+      const float* b = p.cand_boxes + src * 4;
+      o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
+      p.prop_scores[(long long)n * p.cap + i] = p.cand_scores[src];
+      if (p.prop_level) p.prop_level[(long long)n * p.cap + i] = (int)(pos >> 10);
+    } else {
+      o[0] = o[1] = o[2] = o[3] = 0.f;
+      p.prop_scores[(long long)n * p.cap + i] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ROIAlign (aligned = true, adaptive sampling), C == 256, one workgroup (4 waves) per RoI
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) {
+  const int entry = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int n_entries = p.S;
+  if (p.n_entries) { const int c = *p.n_entries; n_entries = c < n_entries ? c : n_entries; }
+  if (entry >= n_entries) return;
+  const int slot = p.slot_list ? p.slot_list[entry] : entry;
+  const int n = slot / p.slots_per_image;
+  const int P = p.P, PP = P + 2 * p.out_pad;
+  half_t* out = p.out + (long long)entry * PP * PP * 256;
+  bool valid = true;
+  if (p.per_image_count) valid = (slot - n * p.slots_per_image) < p.per_image_count[n];
+  if (!valid) {
+    for (int b = wave; b < P * P; b += 4) {
+      const int ph = b / P, pw = b - ph * P;
+      half4 z; z[0] = z[1] = z[2] = z[3] = (half_t)0.f;
+      *(half4*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + lane * 4) = z;
+    }
+    return;
+  }
+  const float* r = p.rois + (long long)slot * 4;
+  const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+  // assign_boxes_to_levels: floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [2,5]; evaluated with
+  // exact power-of-two thresholds instead of log2 (identical wherever log2 is exact at 2^k).
+  const float area = (x2 - x1) * (y2 - y1);
+  const float v = sqrtf(area) / 224.0f + 1e-8f;
+  int lvl = v >= 2.0f ? 3 : (v >= 1.0f ? 2 : (v >= 0.5f ? 1 : 0));
+  if (lvl > p.nlevels - 1) lvl = p.nlevels - 1;
+  if (p.out_level) { if (tid == 0) p.out_level[entry] = lvl; }
+  const int H = p.H[lvl], W = p.W[lvl];
+  const float sc = p.scale[lvl];
+  const half_t* feat = p.feat[lvl] + (long long)n * (H + 2) * (W + 2) * 256 + lane * 4;
+  const float roi_start_w = x1 * sc - 0.5f;
+  const float roi_start_h = y1 * sc - 0.5f;
+  const float roi_end_w = x2 * sc - 0.5f;
+  const float roi_end_h = y2 * sc - 0.5f;
+  const float roi_w = roi_end_w - roi_start_w;
+  const float roi_h = roi_end_h - roi_start_h;
+  const float bin_h = roi_h / (float)P;
+  const float bin_w = roi_w / (float)P;
+  const int gh = (int)ceilf(roi_h / (float)P);
+  const int gw = (int)ceilf(roi_w / (float)P);
+  const float count = (float)((gh * gw) > 1 ? (gh * gw) : 1);
+  for (int b = wave; b < P * P; b += 4) {
+    const int ph = b / P, pw = b - ph * P;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+      const bool oob_y = (y < -1.0f || y > (float)H);
+      if (y <= 0.f) y = 0.f;
+      int y_low = (int)y, y_high;
+      if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+      const float ly = y - (float)y_low, hy = 1.f - ly;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+        if (oob_y || x < -1.0f || x > (float)W) continue;
+        if (x <= 0.f) x = 0.f;
+        int x_low = (int)x, x_high;
+        if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+        const float lx = x - (float)x_low, hx = 1.f - lx;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const half4 v1 = *(const half4*)(feat + ((long long)(y_low + 1) * (W + 2) + x_low + 1) * 256);
+        const half4 v2 = *(const half4*)(feat + ((long long)(y_low + 1) * (W + 2) + x_high + 1) * 256);
+        const half4 v3 = *(const half4*)(feat + ((long long)(y_high + 1) * (W + 2) + x_low + 1) * 256);
+        const half4 v4 = *(const half4*)(feat + ((long long)(y_high + 1) * (W + 2) + x_high + 1) * 256);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float val = w1 * (float)v1[c] + w2 * (float)v2[c] + w3 * (float)v3[c] + w4 * (float)v4[c];
+          acc[c] += val;
+        }
+      }
+    }
+    half4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (half_t)(acc[c] / count);
+    *(half4*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + lane * 4) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Box head: softmax + per-class decode + threshold + per-(image,class) sort
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void box_candidates_kernel(const BoxCandParams p) {
+  __shared__ unsigned long long list[1024];
+  __shared__ unsigned int cnt;
+  const int k = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int K = p.K;
+  const int np = p.prop_count[n];
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  unsigned long long comp = 0ull;
+  float box[4] = {0.f, 0.f, 0.f, 0.f};
+  float score = 0.f;
+  if (tid < np && tid < p.cap) {
+    const float* pr = p.pred + ((long long)n * p.cap + tid) * p.cs;
+    float mx = pr[0];
+    for (int c = 1; c <= K; ++c) mx = fmaxf(mx, pr[c]);
+    float sum = 0.f;
+    for (int c = 0; c <= K; ++c) sum += expf(pr[c] - mx);
+    score = expf(pr[k] - mx) / sum;
+    const float* pb = p.prop_boxes + ((long long)n * p.cap + tid) * 4;
+    float b[4] = {pb[0], pb[1], pb[2], pb[3]};
+    const float* dp = pr + (K + 1) + k * 4;
+    float d[4] = {dp[0], dp[1], dp[2], dp[3]};
+    apply_deltas(b, d, p.wx, p.wy, p.ww, p.wh, p.scale_clamp, box);
+    box[0] = clampf(box[0], 0.f, p.img_w);
+    box[1] = clampf(box[1], 0.f, p.img_h);
+    box[2] = clampf(box[2], 0.f, p.img_w);
+    box[3] = clampf(box[3], 0.f, p.img_h);
+    float* db = p.dec_boxes + (((long long)n * p.cap + tid) * K + k) * 4;
+    db[0] = box[0]; db[1] = box[1]; db[2] = box[2]; db[3] = box[3];
+    p.dec_scores[((long long)n * p.cap + tid) * K + k] = score;
+    if (score > p.score_thresh) {
+      comp = ((unsigned long long)fkey(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)tid);
+      atomicAdd(&cnt, 1u);
+    }
+  }
+  list[tid] = comp;
+  __syncthreads();
+  bitonic_sort_desc<1024>(list, 1024, tid);
+  const int c = (int)cnt;
+  const long long sb = ((long long)n * K + k) * 1024;
+  if (tid == 0) p.seg_count[n * K + k] = c;
+  if (tid < c) {
+    const int r = (int)(0xFFFFFFFFu - (uint32_t)(list[tid] & 0xFFFFFFFFull));
+    const float* db = p.dec_boxes + (((long long)n * p.cap + r) * K + k) * 4;
+    float* o = p.seg_boxes + (sb + tid) * 4;
+    o[0] = db[0]; o[1] = db[1]; o[2] = db[2]; o[3] = db[3];
+    p.seg_roi[sb + tid] = r;
+  }
+}
+
+// Gather NMS survivors of all classes, order by score (ties: lower roi*K+class first), keep the
+// first dets_per_image, then detector_postprocess's box part (scale to tile, clip, drop empty).
+__global__ __launch_bounds__(1024) void det_merge_kernel(const DetMergeParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* list = (unsigned long long*)smem;   // 8192
+  __shared__ unsigned int cnt;
+  __shared__ unsigned char flag[1024];
+  __shared__ int dst[1024];
+  const int n = blockIdx.x, tid = threadIdx.x, K = p.K;
+  if (tid == 0) cnt = 0;
+  for (int i = tid; i < 8192; i += 1024) list[i] = 0ull;
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    const int c = p.seg_count[n * K + k];
+    const long long sb = ((long long)n * K + k) * 1024;
+    for (int i = tid; i < c; i += 1024) {
+      if (p.keep[sb + i]) {
+        const int r = p.seg_roi[sb + i];
+        const float sc = p.dec_scores[((long long)n * p.cap + r) * K + k];
+        const unsigned pos = atomicAdd(&cnt, 1u);
+        list[pos] = ((unsigned long long)fkey(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(r * K + k));
+      }
+    }
+  }
+  __syncthreads();
+  bitonic_sort_desc<1024>(list, 8192, tid);
+  const int D = p.dets_per_image;
+  const int nd = (int)cnt < D ? (int)cnt : D;
+  float bn[4] = {0, 0, 0, 0}, bo[4] = {0, 0, 0, 0};
+  float sc = 0.f;
+  int cls = 0, roi = 0;
+  bool ok = false;
+  if (tid < nd) {
+    const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(list[tid] & 0xFFFFFFFFull);
+    roi = (int)(flat / (uint32_t)K);
+    cls = (int)(flat - (uint32_t)roi * (uint32_t)K);
+    const float* db = p.dec_boxes + (((long long)n * p.cap + roi) * K + cls) * 4;
+    bn[0] = db[0]; bn[1] = db[1]; bn[2] = db[2]; bn[3] = db[3];
+    sc = fkey_inv((uint32_t)(list[tid] >> 32));
+    bo[0] = clampf(bn[0] * p.scale_x, 0.f, p.out_w);
+    bo[1] = clampf(bn[1] * p.scale_y, 0.f, p.out_h);
+    bo[2] = clampf(bn[2] * p.scale_x, 0.f, p.out_w);
+    bo[3] = clampf(bn[3] * p.scale_y, 0.f, p.out_h);
+    ok = ((bo[2] - bo[0]) > 0.f) && ((bo[3] - bo[1]) > 0.f);
+  }
+  flag[tid] = ok ? 1 : 0;
+  __syncthreads();
+  if (tid == 0) {
+    int c = 0;
+    for (int i = 0; i < nd; ++i) { dst[i] = c; c += flag[i]; }
+    p.det_count[n] = c;
+  }
+  __syncthreads();
+  if (ok) {
+    const long long s = (long long)n * D + dst[tid];
+    float* o1 = p.det_boxes_net + s * 4;
+    float* o2 = p.det_boxes + s * 4;
+    o1[0] = bn[0]; o1[1] = bn[1]; o1[2] = bn[2]; o1[3] = bn[3];
+    o2[0] = bo[0]; o2[1] = bo[1]; o2[2] = bo[2]; o2[3] = bo[3];
+    p.det_scores[s] = sc;
+    p.det_classes[s] = cls;
+    if (p.det_roi) p.det_roi[s] = roi;
+  }
+}
+
+// exclusive scan of per-image detection counts -> compact entry list for the mask head
+__global__ __launch_bounds__(1024) void det_compact_kernel(const int* det_count, int N, int D, int* slot_list, int* total) {
+  __shared__ int off[1025];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int c = 0;
+    for (int i = 0; i < N; ++i) { off[i] = c; c += det_count[i]; }
+    off[N] = c;
+    *total = c;
+  }
+  __syncthreads();
+  for (int n = 0; n < N; ++n) {
+    const int c = det_count[n];
+    for (int i = tid; i < c; i += 1024) slot_list[off[n] + i] = n * D + i;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mask predictor (1x1 conv, predicted class only) + sigmoid.  in: [R][S][S][256] fp16
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_predict_kernel(const MaskPredictParams p) {
+  const int total = *p.n_entries;
+  const int SS = p.S * p.S;
+  const int tid = threadIdx.x;
+  const int sub = tid & 15;         // 16 lanes per pixel, 16 channels each
+  const long long pix = (long long)blockIdx.x * 16 + (tid >> 4);
+  const long long npix = (long long)total * SS;
+  if (pix >= npix) return;          // whole 16-lane group exits together
+  const int entry = (int)(pix / SS);
+  const int slot = p.slot_list[entry];
+  const int cls = p.det_classes[slot];
+  const half_t* x = p.in + pix * 256 + sub * 16;
+  const float* w = p.w + (long long)cls * 256 + sub * 16;
+  const half8 a = *(const half8*)x, b = *(const half8*)(x + 8);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (float)a[i] * w[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (float)b[i] * w[8 + i];
+  s += __shfl_xor(s, 8, 16);
+  s += __shfl_xor(s, 4, 16);
+  s += __shfl_xor(s, 2, 16);
+  s += __shfl_xor(s, 1, 16);
+  if (sub == 0) {
+    const float logit = s + p.b[cls];
+    const float prob = 1.f / (1.f + expf(-logit));
+    p.out[(long long)slot * SS + (pix - (long long)entry * SS)] = prob;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// paste_masks_in_image: one thread = 8 horizontally adjacent output pixels = one output byte
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
+  const int total = *p.n_entries;
+  const int Wb = (p.out_w + 7) >> 3;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = (long long)p.out_h * Wb;
+  if (gid >= (long long)total * per) return;
+  const int entry = (int)(gid / per);
+  const int rem = (int)(gid - (long long)entry * per);
+  const int y = rem / Wb, xb = rem - y * Wb;
+  const int slot = p.slot_list[entry];
+  const float* bx = p.det_boxes + (long long)slot * 4;
+  const float x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
+  const float* m = p.probs + (long long)slot * p.S * p.S;
+  const int S = p.S;
+  unsigned int byte = 0;
+  // img_y = (y + 0.5 - y0) / (y1 - y0) * 2 - 1 ; iy = ((img_y + 1) * S - 1) / 2
+  const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.f - 1.f;
+  const float iy = ((gy + 1.f) * (float)S - 1.f) / 2.f;
+  const float fy = floorf(iy);
+  const int iy0 = (int)fy, iy1 = iy0 + 1;
+  const float wy1 = iy - fy, wy0 = 1.f - wy1;
+  if (iy1 >= 0 && iy0 < S) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int x = xb * 8 + b;
+      if (x >= p.out_w) break;
+      const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
+      const float ix = ((gx + 1.f) * (float)S - 1.f) / 2.f;
+      const float fx = floorf(ix);
+      const int ix0 = (int)fx, ix1 = ix0 + 1;
+      if (ix1 < 0 || ix0 >= S) continue;
+      const float wx1 = ix - fx, wx0 = 1.f - wx1;
+      float v = 0.f;
+      if (iy0 >= 0 && ix0 >= 0) v += m[iy0 * S + ix0] * (wx0 * wy0);
+      if (iy0 >= 0 && ix1 < S) v += m[iy0 * S + ix1] * (wx1 * wy0);
+      if (iy1 < S && ix0 >= 0) v += m[iy1 * S + ix0] * (wx0 * wy1);
+      if (iy1 < S && ix1 < S) v += m[iy1 * S + ix1] * (wx1 * wy1);
+      if (v >= p.threshold) byte |= 1u << b;
+    }
+  }
+  p.out[(long long)slot * per + rem] = (uint8_t)byte;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------- launchers
+int launch_rpn_select(const RpnParams& p, hipStream_t s) {
+  RS_CHECK(p.topk <= 1024 && p.A <= RS_MAX_ANCHORS && p.L <= RS_MAX_LEVELS, RS_ERR_UNSUPPORTED, "rpn: topk %d / A %d / L %d out of range", p.topk, p.A, p.L);
+  hipLaunchKernelGGL(rpn_select_kernel, dim3(p.L, p.N), dim3(1024), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_nms(const NmsParams& p, int segments, hipStream_t s) {
+  const int lds = 1024 * 20 + 1024 * 128 + 128;
+  static bool done = false;
+  if (!done) {
+    RS_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done = true;
+  }
+  RS_CHECK(p.cap >= 1024 || p.cap > 0, RS_ERR_ARG, "nms: cap");
+  hipLaunchKernelGGL(nms_kernel, dim3(segments), dim3(1024), lds, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_rpn_merge(const RpnMergeParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.L * 1024 <= 8192, RS_ERR_UNSUPPORTED, "rpn merge: too many levels");
+  static bool done = false;
+  if (!done) {
+    RS_HIP(hipFuncSetAttribute((const void*)rpn_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    done = true;
+  }
+  hipLaunchKernelGGL(rpn_merge_kernel, dim3(N), dim3(1024), 65536, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_roi_align(const RoiAlignParams& p, hipStream_t s) {
+  RS_CHECK(p.C == 256, RS_ERR_UNSUPPORTED, "roi_align: C must be 256 (got %d)", p.C);
+  RS_CHECK(p.S > 0, RS_ERR_ARG, "roi_align: S");
+  hipLaunchKernelGGL(roi_align_kernel, dim3(p.S), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_box_candidates(const BoxCandParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.cap <= 1024, RS_ERR_UNSUPPORTED, "box head: more than 1024 proposals per image");
+  hipLaunchKernelGGL(box_candidates_kernel, dim3(p.K, N), dim3(1024), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_det_merge(const DetMergeParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.K * 1024 <= 8192, RS_ERR_UNSUPPORTED, "det merge: NUM_CLASSES %d > 8 not supported yet", p.K);
+  RS_CHECK(p.dets_per_image <= 1024, RS_ERR_UNSUPPORTED, "det merge: DETECTIONS_PER_IMAGE > 1024");
+  static bool done = false;
+  if (!done) {
+    RS_HIP(hipFuncSetAttribute((const void*)det_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    done = true;
+  }
+  hipLaunchKernelGGL(det_merge_kernel, dim3(N), dim3(1024), 65536, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_det_compact(const int* det_count, int N, int D, int* slot_list, int* total, hipStream_t s) {
+  RS_CHECK(N <= 1024, RS_ERR_UNSUPPORTED, "batch > 1024");
+  hipLaunchKernelGGL(det_compact_kernel, dim3(1), dim3(1024), 0, s, det_count, N, D, slot_list, total);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_mask_predict(const MaskPredictParams& p, int capacity_entries, hipStream_t s) {
+  const long long npix = (long long)capacity_entries * p.S * p.S;
+  hipLaunchKernelGGL(mask_predict_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_paste_masks(const PasteParams& p, int capacity_entries, hipStream_t s) {
+  const long long total = (long long)capacity_entries * p.out_h * ((p.out_w + 7) >> 3);
+  hipLaunchKernelGGL(paste_masks_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}

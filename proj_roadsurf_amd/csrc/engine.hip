@@ -1,0 +1,935 @@
+// librs_engine.so host side: C ABI (include/rs_engine.h), weight blob, workspace and the op list
+// of one GeneralizedRCNN.inference pass ([EXT d2: modeling/meta_arch/rcnn.py]; topology fixed by
+// R:config/detectron2_config_3bands.yaml).  All device work is enqueued on one HIP stream with
+// fixed-capacity buffers and device-side counts: no host synchronisation inside a forward.
+#include <stdarg.h>
+#include <string.h>
+
+#include <cmath>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rs_engine.h"
+#include "detect.h"
+
+// ------------------------------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+void rs_set_error(const char* fmt, ...) {
+  va_list a;
+  va_start(a, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, a);
+  va_end(a);
+}
+
+namespace {
+
+enum { DT_F16 = 1, DT_F32 = 2, DT_I32 = 3, DT_U8 = 4 };
+static size_t dt_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_U8 ? 1 : 4); }
+
+struct TensorInfo {
+  std::string name;
+  void* p = nullptr;
+  int dtype = 0, ndim = 0, halo = 0;
+  int64_t dims[5] = {1, 1, 1, 1, 1};
+  size_t bytes = 0;
+};
+
+struct Act {   // NHWC fp16 activation with halo
+  half_t* p = nullptr;
+  int N = 0, H = 0, W = 0, C = 0, pad = 0;
+  int Hp() const { return H + 2 * pad; }
+  int Wp() const { return W + 2 * pad; }
+};
+
+struct Stage {
+  std::string name;
+  std::function<int(int, hipStream_t)> fn;
+  double flops_per_image = 0, bytes_per_image = 0;   // algorithmic, per tile (0 = n/a)
+  double ms_total = 0;
+  int calls = 0;
+  double last_flops = 0, last_bytes = 0;
+};
+
+struct BlobEntry { const void* host; void* dev; int dtype; int ndim; int64_t dims[4]; size_t nbytes; };
+
+}  // namespace
+
+// host-only helpers -------------------------------------------------------------------------
+extern "C" void rs_resize_shape(int h, int w, int short_edge, int max_size, int* new_h, int* new_w) {
+  // [EXT d2: data/transforms/augmentation_impl.py ResizeShortestEdge.get_output_shape]
+  double scale = (double)short_edge * 1.0 / (double)(h < w ? h : w);
+  double newh, neww;
+  if (h < w) { newh = short_edge; neww = scale * w; } else { newh = scale * h; neww = short_edge; }
+  const double mx = newh > neww ? newh : neww;
+  if (mx > max_size) {
+    scale = (double)max_size * 1.0 / mx;
+    newh = newh * scale;
+    neww = neww * scale;
+  }
+  *new_w = (int)(neww + 0.5);
+  *new_h = (int)(newh + 0.5);
+}
+
+extern "C" int rs_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs) {
+  // Pillow src/libImaging/Resample.c precompute_coeffs (bilinear, support 1) + normalize_coeffs_8bpc
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const int ksize = (int)ceil(support) * 2 + 1;
+  if (!bounds || !coeffs) return ksize;
+  const double ss = 1.0 / filterscale;
+  std::vector<double> w(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < ksize; ++x) w[x] = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      double a = (x + xmin - center + 0.5) * ss;
+      if (a < 0) a = -a;
+      const double v = a < 1.0 ? 1.0 - a : 0.0;
+      w[x] = v;
+      ww += v;
+    }
+    for (int x = 0; x < xmax; ++x)
+      if (ww != 0.0) w[x] /= ww;
+    for (int x = 0; x < ksize; ++x) {
+      const double v = w[x] * (double)(1 << 22);
+      coeffs[xx * ksize + x] = v < 0 ? (int)(v - 0.5) : (int)(v + 0.5);
+    }
+    bounds[xx * 2] = xmin;
+    bounds[xx * 2 + 1] = xmax;
+  }
+  return ksize;
+}
+
+// =================================================================================== engine
+struct rs_engine {
+  rs_spec spec;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int max_batch = 0, tile_h = 0, tile_w = 0, tile_c = 0;
+  int net_h = 0, net_w = 0, pad_h = 0, pad_w = 0;
+  int use_glds = 1;
+  bool profiling = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  void* blob_dev = nullptr;
+  std::map<std::string, BlobEntry> blob;
+  std::vector<void*> allocs;
+  std::vector<TensorInfo> tensors;
+  std::vector<Stage> stages;
+
+  uint8_t* tiles_dev = nullptr;
+  // results (device)
+  int* det_count = nullptr;
+  float* det_boxes = nullptr;
+  float* det_boxes_net = nullptr;
+  float* det_scores = nullptr;
+  int* det_classes = nullptr;
+  uint8_t* masks = nullptr;
+  float* mask_probs = nullptr;
+  int D = 0;
+
+  int alloc(void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    RS_HIP(hipMalloc(p, bytes));
+    allocs.push_back(*p);
+    RS_HIP(hipMemsetAsync(*p, 0, bytes, stream));
+    return RS_OK;
+  }
+  void reg(const std::string& name, void* p, int dtype, std::vector<int64_t> dims, int halo) {
+    TensorInfo t;
+    t.name = name; t.p = p; t.dtype = dtype; t.ndim = (int)dims.size(); t.halo = halo;
+    size_t nb = dt_size(dtype);
+    for (size_t i = 0; i < dims.size(); ++i) { t.dims[i] = dims[i]; nb *= (size_t)dims[i]; }
+    t.bytes = nb;
+    tensors.push_back(t);
+  }
+  int new_act(Act* a, const std::string& name, int N, int H, int W, int C, int pad) {
+    a->N = N; a->H = H; a->W = W; a->C = C; a->pad = pad;
+    const size_t bytes = (size_t)N * a->Hp() * a->Wp() * C * 2;
+    int rc = alloc((void**)&a->p, bytes);
+    if (rc) return rc;
+    reg(name, a->p, DT_F16, {N, a->Hp(), a->Wp(), C}, pad);
+    return RS_OK;
+  }
+  const BlobEntry* find(const std::string& n) {
+    auto it = blob.find(n);
+    return it == blob.end() ? nullptr : &it->second;
+  }
+  int parse_blob(const void* data, size_t nbytes);
+  int build();
+  int add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k, int stride,
+               int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile = 1,
+               const int* m_count = nullptr);
+  int run(const uint8_t* tiles, int n);
+};
+
+int rs_engine::parse_blob(const void* data, size_t nbytes) {
+  const uint8_t* b = (const uint8_t*)data;
+  RS_CHECK(nbytes >= 16, RS_ERR_BLOB, "weight blob too small");
+  uint32_t hdr[4];
+  memcpy(hdr, b, 16);
+  RS_CHECK(hdr[0] == 0x52534557u && hdr[1] == 1u, RS_ERR_BLOB, "bad weight blob magic/version %08x/%u", hdr[0], hdr[1]);
+  const size_t ent = 96 + 4 + 4 + 32 + 8 + 8;
+  RS_CHECK(16 + ent * hdr[2] <= nbytes, RS_ERR_BLOB, "weight blob truncated");
+  RS_HIP(hipMalloc(&blob_dev, nbytes));
+  RS_HIP(hipMemcpy(blob_dev, data, nbytes, hipMemcpyHostToDevice));
+  for (uint32_t i = 0; i < hdr[2]; ++i) {
+    const uint8_t* e = b + 16 + ent * i;
+    char name[97];
+    memcpy(name, e, 96);
+    name[96] = 0;
+    BlobEntry be;
+    uint32_t dt, nd;
+    uint64_t dims[4], off, nb;
+    memcpy(&dt, e + 96, 4);
+    memcpy(&nd, e + 100, 4);
+    memcpy(dims, e + 104, 32);
+    memcpy(&off, e + 136, 8);
+    memcpy(&nb, e + 144, 8);
+    RS_CHECK(off + nb <= nbytes, RS_ERR_BLOB, "weight blob entry %s out of range", name);
+    be.host = b + off;
+    be.dev = (char*)blob_dev + off;
+    be.dtype = (int)dt;
+    be.ndim = (int)nd;
+    for (int d = 0; d < 4; ++d) be.dims[d] = (int64_t)dims[d];
+    be.nbytes = nb;
+    blob[name] = be;
+  }
+  return RS_OK;
+}
+
+// One conv / linear stage.  `cin_real` only feeds the FLOP count (stem: 3 of 8 padded channels).
+// `units_per_tile` = images of the conv per input tile (1 for feature maps, D for per-RoI maps);
+// `m_count` = optional device-side count of units actually present.
+int rs_engine::add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k,
+                        int stride, int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile,
+                        const int* m_count) {
+  const BlobEntry* w = find(wname + ".w");
+  const BlobEntry* b = find(wname + ".b");
+  RS_CHECK(w && b, RS_ERR_BLOB, "weights for %s missing from blob", wname.c_str());
+  RS_CHECK(w->dtype == DT_F16 && b->dtype == DT_F32, RS_ERR_BLOB, "weights for %s have wrong dtype", wname.c_str());
+  ConvParams p;
+  memset(&p, 0, sizeof p);
+  p.in = in.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev; p.out = out.p;
+  p.res = res ? res->p : nullptr;
+  p.up = up ? up->p : nullptr;
+  p.Ho = out.H; p.Wo = out.W;
+  p.in_Hp = in.Hp(); p.in_Wp = in.Wp(); p.in_Cs = in.C; p.in_off = in.pad - pad;
+  p.stride = stride; p.KH = k; p.KW = k; p.Cin = in.C;
+  p.Kpad = (int)w->dims[1];
+  p.Cout = out.C;
+  p.out_Hp = out.Hp(); p.out_Wp = out.Wp(); p.out_Cs = out.C; p.out_pad = out.pad;
+  if (up) { p.up_Hp = up->Hp(); p.up_Wp = up->Wp(); p.up_Cs = up->C; p.up_pad = up->pad; }
+  p.relu = relu ? 1 : 0;
+  RS_CHECK(in.pad >= pad, RS_ERR_ARG, "%s: input halo %d < conv pad %d", name.c_str(), in.pad, pad);
+  RS_CHECK((int)w->dims[0] >= out.C, RS_ERR_BLOB, "%s: weight rows %lld < Cout %d", name.c_str(), (long long)w->dims[0], out.C);
+  RS_CHECK((out.H - 1) * stride + k - 2 * pad <= in.H + (stride - 1), RS_ERR_ARG, "%s: geometry", name.c_str());
+  if (res) RS_CHECK(res->H == out.H && res->W == out.W && res->C == out.C && res->pad == out.pad, RS_ERR_ARG, "%s: residual geometry", name.c_str());
+  if (in.C < 64) {
+    // small-Cin (stem) path: per-16-byte-chunk element offsets, one tap per chunk
+    RS_CHECK(in.C == 8, RS_ERR_UNSUPPORTED, "%s: Cin %d", name.c_str(), in.C);
+    std::vector<int> koff(p.Kpad / 8, 0);
+    for (int t = 0; t < k * k && t < (int)koff.size(); ++t) koff[t] = ((t / k) * p.in_Wp + (t % k)) * in.C;
+    int* d = nullptr;
+    int rc = alloc((void**)&d, koff.size() * 4);
+    if (rc) return rc;
+    RS_HIP(hipMemcpyAsync(d, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, stream));
+    RS_HIP(hipStreamSynchronize(stream));
+    p.koff = d;
+  }
+  const int m_per_image = out.H * out.W * units_per_tile;
+  p.m_count = m_count;
+  p.m_mul = out.H * out.W;
+  Stage st;
+  st.name = name;
+  st.flops_per_image = 2.0 * m_per_image * (double)k * k * cin_real * out.C;
+  st.bytes_per_image = 2.0 * ((double)in.H * in.W * in.C * units_per_tile + (double)m_per_image * out.C * (1 + (res ? 1 : 0)));
+  const int glds = use_glds;
+  st.fn = [p, m_per_image, glds](int n, hipStream_t s) mutable {
+    p.M = n * m_per_image;
+    return launch_conv(p, s, -1, glds);
+  };
+  stages.push_back(st);
+  return RS_OK;
+}
+
+int rs_engine::build() {
+  const rs_spec& S = spec;
+  const int NB = max_batch;
+  rs_resize_shape(tile_h, tile_w, S.min_size_test, S.max_size_test, &net_h, &net_w);
+  const int dv = S.size_divisibility;
+  pad_h = (net_h + dv - 1) / dv * dv;
+  pad_w = (net_w + dv - 1) / dv * dv;
+  RS_CHECK(S.fpn_out_channels == 256 && S.mask_conv_dim == 256, RS_ERR_UNSUPPORTED, "FPN/mask width must be 256");
+  RS_CHECK(S.num_levels == 5, RS_ERR_UNSUPPORTED, "RPN must use p2..p6");
+  RS_CHECK(S.rpn_pre_nms_topk <= 1024 && S.rpn_post_nms_topk <= 1024, RS_ERR_UNSUPPORTED, "RPN top-k > 1024");
+  RS_CHECK(S.num_classes >= 1 && S.num_classes <= 8, RS_ERR_UNSUPPORTED, "NUM_CLASSES %d outside [1,8]", S.num_classes);
+  RS_CHECK(S.in_channels >= 1 && S.in_channels <= 4 && S.in_channels == tile_c, RS_ERR_ARG, "tile channels %d vs PIXEL_MEAN %d", tile_c, S.in_channels);
+  RS_CHECK(!S.mask_on || S.mask_pooler_resolution * 2 == RS_MASK_SIDE, RS_ERR_UNSUPPORTED, "mask side must be 28");
+  int rc;
+
+  // ---- resize tables + input staging
+  RS_CHECK(alloc((void**)&tiles_dev, (size_t)NB * tile_h * tile_w * tile_c) == RS_OK, RS_ERR_HIP, "alloc tiles");
+  reg("tiles", tiles_dev, DT_U8, {NB, tile_h, tile_w, tile_c}, 0);
+  PreprocParams pp;
+  memset(&pp, 0, sizeof pp);
+  pp.need_h = net_w != tile_w;
+  pp.need_v = net_h != tile_h;
+  {
+    const int ksh = rs_resize_coeffs(tile_w, net_w, nullptr, nullptr);
+    const int ksv = rs_resize_coeffs(tile_h, net_h, nullptr, nullptr);
+    std::vector<int32_t> hb(net_w * 2), hk((size_t)net_w * ksh), vb(net_h * 2), vk((size_t)net_h * ksv);
+    rs_resize_coeffs(tile_w, net_w, hb.data(), hk.data());
+    rs_resize_coeffs(tile_h, net_h, vb.data(), vk.data());
+    int *dhb, *dhk, *dvb, *dvk;
+    if ((rc = alloc((void**)&dhb, hb.size() * 4))) return rc;
+    if ((rc = alloc((void**)&dhk, hk.size() * 4))) return rc;
+    if ((rc = alloc((void**)&dvb, vb.size() * 4))) return rc;
+    if ((rc = alloc((void**)&dvk, vk.size() * 4))) return rc;
+    RS_HIP(hipMemcpyAsync(dhb, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, stream));
+    RS_HIP(hipMemcpyAsync(dhk, hk.data(), hk.size() * 4, hipMemcpyHostToDevice, stream));
+    RS_HIP(hipMemcpyAsync(dvb, vb.data(), vb.size() * 4, hipMemcpyHostToDevice, stream));
+    RS_HIP(hipMemcpyAsync(dvk, vk.data(), vk.size() * 4, hipMemcpyHostToDevice, stream));
+    RS_HIP(hipStreamSynchronize(stream));
+    pp.hb = dhb; pp.hk = dhk; pp.vb = dvb; pp.vk = dvk; pp.ksh = ksh; pp.ksv = ksv;
+  }
+  Act x0;
+  if ((rc = new_act(&x0, "net_input", NB, pad_h, pad_w, 8, 3))) return rc;
+  pp.out = x0.p; pp.H = tile_h; pp.W = tile_w; pp.C = tile_c; pp.new_h = net_h; pp.new_w = net_w;
+  pp.out_Hp = x0.Hp(); pp.out_Wp = x0.Wp(); pp.flip = S.flip_channels;
+  for (int c = 0; c < 4; ++c) { pp.mean[c] = S.pixel_mean[c]; pp.stdv[c] = S.pixel_std[c] == 0.f ? 1.f : S.pixel_std[c]; }
+  {
+    Stage st;
+    st.name = "preprocess";
+    st.bytes_per_image = (double)tile_h * tile_w * tile_c + (double)net_h * net_w * 16;
+    pp.tiles = tiles_dev;
+    st.fn = [pp](int n, hipStream_t s) mutable {
+      pp.N = n;
+      return launch_preprocess(pp, s);
+    };
+    stages.push_back(st);
+  }
+
+  // ---- stem
+  const std::string bu = "backbone.bottom_up.";
+  const int h2 = pad_h / 2, w2 = pad_w / 2, h4 = pad_h / 4, w4 = pad_w / 4;
+  Act stem, c1;
+  if ((rc = new_act(&stem, "stem_conv", NB, h2, w2, S.stem_out_channels, 1))) return rc;
+  if ((rc = new_act(&c1, "stem", NB, h4, w4, S.stem_out_channels, 1))) return rc;
+  if ((rc = add_conv("stem.conv1", bu + "stem.conv1", x0, stem, 7, 2, 3, true, nullptr, nullptr, S.in_channels))) return rc;
+  {
+    Stage st;
+    st.name = "stem.maxpool";
+    st.bytes_per_image = 2.0 * ((double)h2 * w2 + (double)h4 * w4) * S.stem_out_channels;
+    st.fn = [stem, c1](int n, hipStream_t s) { return launch_maxpool(stem.p, c1.p, n, stem.H, stem.W, c1.H, c1.W, c1.C, s); };
+    stages.push_back(st);
+  }
+
+  // ---- res2..res5
+  Act cur = c1;
+  Act res_out[4];
+  int bott = 64, cout = S.res2_out_channels;
+  int ch = h4, cw = w4;
+  for (int si = 0; si < 4; ++si) {
+    for (int bi = 0; bi < S.res_blocks[si]; ++bi) {
+      const std::string nm = "res" + std::to_string(si + 2) + "." + std::to_string(bi);
+      const std::string wn = bu + nm;
+      const int stride = (bi == 0 && si > 0) ? 2 : 1;
+      const int s1 = S.stride_in_1x1 ? stride : 1, s3 = S.stride_in_1x1 ? 1 : stride;
+      const int oh = ch / stride, ow = cw / stride;
+      Act t1, t2, sc, out;
+      if ((rc = new_act(&t1, nm + ".conv1", NB, ch / s1, cw / s1, bott, 1))) return rc;
+      if ((rc = new_act(&t2, nm + ".conv2", NB, oh, ow, bott, 1))) return rc;
+      if ((rc = new_act(&out, bi == S.res_blocks[si] - 1 ? "res" + std::to_string(si + 2) : nm + ".out", NB, oh, ow, cout, 1))) return rc;
+      const Act* resid = &cur;
+      if (cur.C != cout) {
+        if ((rc = new_act(&sc, nm + ".shortcut", NB, oh, ow, cout, 1))) return rc;
+        if ((rc = add_conv(nm + ".shortcut", wn + ".shortcut", cur, sc, 1, stride, 0, false, nullptr, nullptr, cur.C))) return rc;
+        resid = &sc;
+      }
+      if ((rc = add_conv(nm + ".conv1", wn + ".conv1", cur, t1, 1, s1, 0, true, nullptr, nullptr, cur.C))) return rc;
+      if ((rc = add_conv(nm + ".conv2", wn + ".conv2", t1, t2, 3, s3, 1, true, nullptr, nullptr, bott))) return rc;
+      if ((rc = add_conv(nm + ".conv3", wn + ".conv3", t2, out, 1, 1, 0, true, resid, nullptr, bott))) return rc;
+      cur = out;
+      ch = oh; cw = ow;
+    }
+    res_out[si] = cur;
+    bott *= 2;
+    cout *= 2;
+  }
+
+  // ---- FPN
+  Act inner[4], P[5];
+  for (int l = 3; l >= 0; --l) {
+    const std::string ln = std::to_string(l + 2);
+    if ((rc = new_act(&inner[l], "inner" + ln, NB, res_out[l].H, res_out[l].W, 256, 1))) return rc;
+    if ((rc = new_act(&P[l], "p" + ln, NB, res_out[l].H, res_out[l].W, 256, 1))) return rc;
+    if ((rc = add_conv("fpn_lateral" + ln, "backbone.fpn_lateral" + ln, res_out[l], inner[l], 1, 1, 0, false, nullptr,
+                       l < 3 ? &inner[l + 1] : nullptr, res_out[l].C))) return rc;
+    if ((rc = add_conv("fpn_output" + ln, "backbone.fpn_output" + ln, inner[l], P[l], 3, 1, 1, false, nullptr, nullptr, 256))) return rc;
+  }
+  {
+    const int h6 = (P[3].H - 1) / 2 + 1, w6 = (P[3].W - 1) / 2 + 1;
+    if ((rc = new_act(&P[4], "p6", NB, h6, w6, 256, 1))) return rc;
+    Stage st;
+    st.name = "fpn.p6";
+    Act a = P[3], b = P[4];
+    st.fn = [a, b](int n, hipStream_t s) { return launch_subsample2(a.p, b.p, n, a.H, a.W, b.H, b.W, 256, s); };
+    stages.push_back(st);
+  }
+
+  // ---- RPN head
+  const int A = S.num_anchors, L = S.num_levels;
+  const int head_cs = (5 * A + 15) / 16 * 16;
+  RpnParams rp;
+  memset(&rp, 0, sizeof rp);
+  for (int l = 0; l < L; ++l) {
+    const std::string ln = std::to_string(l + 2);
+    Act t;
+    if ((rc = new_act(&t, "rpn_conv" + ln, NB, P[l].H, P[l].W, 256, 0))) return rc;
+    if ((rc = add_conv("rpn.conv" + ln, "proposal_generator.rpn_head.conv", P[l], t, 3, 1, 1, true, nullptr, nullptr, 256))) return rc;
+    float* ho = nullptr;
+    if ((rc = alloc((void**)&ho, (size_t)NB * P[l].H * P[l].W * head_cs * 4))) return rc;
+    reg("rpn_head" + ln, ho, DT_F32, {NB, P[l].H, P[l].W, head_cs}, 0);
+    // 1x1 heads (objectness + deltas fused), fp32 out
+    {
+      const BlobEntry* w = find("proposal_generator.rpn_head.heads.w");
+      const BlobEntry* b = find("proposal_generator.rpn_head.heads.b");
+      RS_CHECK(w && b, RS_ERR_BLOB, "rpn head weights missing");
+      RS_CHECK((int)w->dims[0] == head_cs, RS_ERR_BLOB, "rpn head rows %lld != %d", (long long)w->dims[0], head_cs);
+      ConvParams p;
+      memset(&p, 0, sizeof p);
+      p.in = t.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev; p.out = ho;
+      p.Ho = t.H; p.Wo = t.W; p.in_Hp = t.Hp(); p.in_Wp = t.Wp(); p.in_Cs = 256; p.in_off = 0; p.stride = 1;
+      p.KH = p.KW = 1; p.Cin = 256; p.Kpad = (int)w->dims[1]; p.Cout = head_cs;
+      p.out_Hp = t.H; p.out_Wp = t.W; p.out_Cs = head_cs; p.out_pad = 0; p.out_f32 = 1;
+      const int mpi = t.H * t.W;
+      const int glds = use_glds;
+      Stage st;
+      st.name = "rpn.heads" + ln;
+      st.flops_per_image = 2.0 * mpi * 256 * 5 * A;
+      st.bytes_per_image = (double)mpi * (256 * 2 + head_cs * 4);
+      st.fn = [p, mpi, glds](int n, hipStream_t s) mutable { p.M = n * mpi; return launch_conv(p, s, 2, glds); };
+      stages.push_back(st);
+    }
+    rp.head[l] = ho;
+    rp.H[l] = P[l].H; rp.W[l] = P[l].W; rp.stride[l] = 4 << l;
+    uint32_t* keys = nullptr;
+    if ((rc = alloc((void**)&keys, (size_t)NB * P[l].H * P[l].W * A * 4))) return rc;
+    rp.keys[l] = keys;
+    for (int a = 0; a < A; ++a)
+      for (int d = 0; d < 4; ++d) rp.base[l][a][d] = S.cell_anchors[l][a][d];
+    RS_CHECK((long long)P[l].H * P[l].W * A < (1 << 24), RS_ERR_UNSUPPORTED, "feature map too large for the RPN index select");
+  }
+  rp.offset = S.anchor_offset; rp.L = L; rp.A = A; rp.cs = head_cs; rp.topk = S.rpn_pre_nms_topk;
+  rp.img_h = (float)net_h; rp.img_w = (float)net_w;
+  rp.wx = S.rpn_bbox_reg_weights[0]; rp.wy = S.rpn_bbox_reg_weights[1]; rp.ww = S.rpn_bbox_reg_weights[2]; rp.wh = S.rpn_bbox_reg_weights[3];
+  rp.scale_clamp = S.scale_clamp; rp.min_size = S.rpn_min_size;
+  uint8_t* cand_keep = nullptr;
+  if ((rc = alloc((void**)&rp.cand_boxes, (size_t)NB * L * 1024 * 16))) return rc;
+  if ((rc = alloc((void**)&rp.cand_scores, (size_t)NB * L * 1024 * 4))) return rc;
+  if ((rc = alloc((void**)&rp.cand_valid, (size_t)NB * L * 1024))) return rc;
+  if ((rc = alloc((void**)&rp.cand_count, (size_t)NB * L * 4))) return rc;
+  if ((rc = alloc((void**)&rp.cand_index, (size_t)NB * L * 1024 * 4))) return rc;
+  if ((rc = alloc((void**)&cand_keep, (size_t)NB * L * 1024))) return rc;
+  reg("rpn_cand_boxes", rp.cand_boxes, DT_F32, {NB, L, 1024, 4}, 0);
+  reg("rpn_cand_scores", rp.cand_scores, DT_F32, {NB, L, 1024}, 0);
+  reg("rpn_cand_valid", rp.cand_valid, DT_U8, {NB, L, 1024}, 0);
+  reg("rpn_cand_count", rp.cand_count, DT_I32, {NB, L}, 0);
+  reg("rpn_cand_index", rp.cand_index, DT_I32, {NB, L, 1024}, 0);
+  reg("rpn_cand_keep", cand_keep, DT_U8, {NB, L, 1024}, 0);
+  {
+    Stage st;
+    st.name = "rpn.select_decode";
+    st.fn = [rp](int n, hipStream_t s) mutable { rp.N = n; return launch_rpn_select(rp, s); };
+    stages.push_back(st);
+  }
+  {
+    NmsParams np;
+    np.boxes = rp.cand_boxes; np.count = rp.cand_count; np.valid = rp.cand_valid; np.keep = cand_keep; np.cap = 1024;
+    np.thresh = S.rpn_nms_thresh;
+    Stage st;
+    st.name = "rpn.nms";
+    st.fn = [np, L](int n, hipStream_t s) { return launch_nms(np, n * L, s); };
+    stages.push_back(st);
+  }
+  const int PC = 1024;   // proposal slots per image
+  float *prop_boxes, *prop_scores;
+  int *prop_count, *prop_level;
+  if ((rc = alloc((void**)&prop_boxes, (size_t)NB * PC * 16))) return rc;
+  if ((rc = alloc((void**)&prop_scores, (size_t)NB * PC * 4))) return rc;
+  if ((rc = alloc((void**)&prop_level, (size_t)NB * PC * 4))) return rc;
+  if ((rc = alloc((void**)&prop_count, (size_t)NB * 4))) return rc;
+  reg("proposal_boxes", prop_boxes, DT_F32, {NB, PC, 4}, 0);
+  reg("proposal_logits", prop_scores, DT_F32, {NB, PC}, 0);
+  reg("proposal_level", prop_level, DT_I32, {NB, PC}, 0);
+  reg("proposal_count", prop_count, DT_I32, {NB}, 0);
+  {
+    RpnMergeParams mp;
+    mp.cand_boxes = rp.cand_boxes; mp.cand_scores = rp.cand_scores; mp.keep = cand_keep; mp.cand_count = rp.cand_count;
+    mp.L = L; mp.post_topk = S.rpn_post_nms_topk; mp.cap = PC;
+    mp.prop_boxes = prop_boxes; mp.prop_scores = prop_scores; mp.prop_level = prop_level; mp.prop_count = prop_count;
+    Stage st;
+    st.name = "rpn.merge";
+    st.fn = [mp](int n, hipStream_t s) { return launch_rpn_merge(mp, n, s); };
+    stages.push_back(st);
+  }
+
+  // ---- box head
+  const int PR = S.box_pooler_resolution;
+  RoiAlignParams ra;
+  memset(&ra, 0, sizeof ra);
+  for (int l = 0; l < 4; ++l) { ra.feat[l] = P[l].p; ra.H[l] = P[l].H; ra.W[l] = P[l].W; ra.scale[l] = 1.0f / (float)(4 << l); }
+  ra.nlevels = 4; ra.C = 256;
+  Act boxfeat;   // [NB*PC] "images" of PR x PR x 256
+  if ((rc = new_act(&boxfeat, "box_pooled", NB * PC, PR, PR, 256, 0))) return rc;
+  int* box_level = nullptr;
+  if ((rc = alloc((void**)&box_level, (size_t)NB * PC * 4))) return rc;
+  reg("box_roi_level", box_level, DT_I32, {NB, PC}, 0);
+  {
+    RoiAlignParams q = ra;
+    q.rois = prop_boxes; q.per_image_count = prop_count; q.slots_per_image = PC; q.out = boxfeat.p; q.P = PR; q.out_pad = 0;
+    q.out_level = box_level;
+    Stage st;
+    st.name = "box.roi_align";
+    st.bytes_per_image = (double)PC * PR * PR * 256 * 2 * 2;
+    st.fn = [q, PC](int n, hipStream_t s) mutable { q.S = n * PC; return launch_roi_align(q, s); };
+    stages.push_back(st);
+  }
+  // FC layers as 1x1 "convs" over a (M x 1) image
+  const int FC = S.box_fc_dim;
+  Act fin, f1, f2;
+  fin.p = boxfeat.p; fin.N = 1; fin.H = NB * PC; fin.W = 1; fin.C = PR * PR * 256; fin.pad = 0;
+  if ((rc = new_act(&f1, "box_fc1", 1, NB * PC, 1, FC, 0))) return rc;
+  if ((rc = new_act(&f2, "box_fc2", 1, NB * PC, 1, FC, 0))) return rc;
+  auto add_fc = [&](const std::string& name, const std::string& wn, const Act& in, const Act& out, bool relu, float* out32, int rows32) -> int {
+    const BlobEntry* w = find(wn + ".w");
+    const BlobEntry* b = find(wn + ".b");
+    RS_CHECK(w && b, RS_ERR_BLOB, "weights for %s missing", wn.c_str());
+    ConvParams p;
+    memset(&p, 0, sizeof p);
+    p.in = in.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev;
+    p.Ho = NB * PC; p.Wo = 1; p.in_Hp = NB * PC; p.in_Wp = 1; p.in_Cs = in.C; p.stride = 1; p.KH = p.KW = 1; p.Cin = in.C;
+    p.Kpad = (int)w->dims[1];
+    p.out_Hp = NB * PC; p.out_Wp = 1; p.relu = relu;
+    if (out32) { p.out = out32; p.Cout = rows32; p.out_Cs = rows32; p.out_f32 = 1; }
+    else { p.out = out.p; p.Cout = out.C; p.out_Cs = out.C; }
+    RS_CHECK((int)w->dims[0] >= p.Cout && p.Kpad >= in.C, RS_ERR_BLOB, "%s: weight shape", wn.c_str());
+    const int glds = use_glds;
+    const int variant = out32 ? 2 : -1;
+    Stage st;
+    st.name = name;
+    st.flops_per_image = 2.0 * PC * (double)in.C * p.Cout;
+    st.bytes_per_image = (double)PC * (in.C * 2 + p.Cout * (out32 ? 4 : 2));
+    st.fn = [p, PC, glds, variant](int n, hipStream_t s) mutable { p.M = n * PC; return launch_conv(p, s, variant, glds); };
+    stages.push_back(st);
+    return RS_OK;
+  };
+  if ((rc = add_fc("box.fc1", "roi_heads.box_head.fc1", fin, f1, true, nullptr, 0))) return rc;
+  if ((rc = add_fc("box.fc2", "roi_heads.box_head.fc2", f1, f2, true, nullptr, 0))) return rc;
+  const int K = S.num_classes;
+  const int pred_cs = (5 * K + 1 + 15) / 16 * 16;
+  float* pred = nullptr;
+  if ((rc = alloc((void**)&pred, (size_t)NB * PC * pred_cs * 4))) return rc;
+  reg("box_pred", pred, DT_F32, {NB, PC, pred_cs}, 0);
+  if ((rc = add_fc("box.predictor", "roi_heads.box_predictor", f2, f2, false, pred, pred_cs))) return rc;
+
+  D = S.detections_per_image;
+  BoxCandParams bc;
+  memset(&bc, 0, sizeof bc);
+  bc.pred = pred; bc.prop_boxes = prop_boxes; bc.prop_count = prop_count; bc.K = K; bc.cap = PC; bc.cs = pred_cs;
+  bc.wx = S.box_reg_weights[0]; bc.wy = S.box_reg_weights[1]; bc.ww = S.box_reg_weights[2]; bc.wh = S.box_reg_weights[3];
+  bc.scale_clamp = S.scale_clamp; bc.img_h = (float)net_h; bc.img_w = (float)net_w; bc.score_thresh = S.score_thresh_test;
+  uint8_t* seg_keep = nullptr;
+  if ((rc = alloc((void**)&bc.dec_boxes, (size_t)NB * PC * K * 16))) return rc;
+  if ((rc = alloc((void**)&bc.dec_scores, (size_t)NB * PC * K * 4))) return rc;
+  if ((rc = alloc((void**)&bc.seg_boxes, (size_t)NB * K * 1024 * 16))) return rc;
+  if ((rc = alloc((void**)&bc.seg_roi, (size_t)NB * K * 1024 * 4))) return rc;
+  if ((rc = alloc((void**)&bc.seg_count, (size_t)NB * K * 4))) return rc;
+  if ((rc = alloc((void**)&seg_keep, (size_t)NB * K * 1024))) return rc;
+  reg("box_dec_boxes", bc.dec_boxes, DT_F32, {NB, PC, K, 4}, 0);
+  reg("box_dec_scores", bc.dec_scores, DT_F32, {NB, PC, K}, 0);
+  reg("box_seg_boxes", bc.seg_boxes, DT_F32, {NB, K, 1024, 4}, 0);
+  reg("box_seg_roi", bc.seg_roi, DT_I32, {NB, K, 1024}, 0);
+  reg("box_seg_count", bc.seg_count, DT_I32, {NB, K}, 0);
+  reg("box_seg_keep", seg_keep, DT_U8, {NB, K, 1024}, 0);
+  {
+    Stage st;
+    st.name = "box.candidates";
+    st.fn = [bc](int n, hipStream_t s) { return launch_box_candidates(bc, n, s); };
+    stages.push_back(st);
+  }
+  {
+    NmsParams np;
+    np.boxes = bc.seg_boxes; np.count = bc.seg_count; np.valid = nullptr; np.keep = seg_keep; np.cap = 1024; np.thresh = S.nms_thresh_test;
+    Stage st;
+    st.name = "box.nms";
+    st.fn = [np, K](int n, hipStream_t s) { return launch_nms(np, n * K, s); };
+    stages.push_back(st);
+  }
+  int* det_roi = nullptr;
+  if ((rc = alloc((void**)&det_boxes_net, (size_t)NB * D * 16))) return rc;
+  if ((rc = alloc((void**)&det_boxes, (size_t)NB * D * 16))) return rc;
+  if ((rc = alloc((void**)&det_scores, (size_t)NB * D * 4))) return rc;
+  if ((rc = alloc((void**)&det_classes, (size_t)NB * D * 4))) return rc;
+  if ((rc = alloc((void**)&det_roi, (size_t)NB * D * 4))) return rc;
+  if ((rc = alloc((void**)&det_count, (size_t)NB * 4))) return rc;
+  reg("det_boxes_net", det_boxes_net, DT_F32, {NB, D, 4}, 0);
+  reg("det_boxes", det_boxes, DT_F32, {NB, D, 4}, 0);
+  reg("det_scores", det_scores, DT_F32, {NB, D}, 0);
+  reg("det_classes", det_classes, DT_I32, {NB, D}, 0);
+  reg("det_roi", det_roi, DT_I32, {NB, D}, 0);
+  reg("det_count", det_count, DT_I32, {NB}, 0);
+  {
+    DetMergeParams dm;
+    memset(&dm, 0, sizeof dm);
+    dm.dec_boxes = bc.dec_boxes; dm.dec_scores = bc.dec_scores; dm.seg_roi = bc.seg_roi; dm.seg_count = bc.seg_count; dm.keep = seg_keep;
+    dm.K = K; dm.cap = PC; dm.dets_per_image = D;
+    dm.scale_x = (float)((double)tile_w / (double)net_w);
+    dm.scale_y = (float)((double)tile_h / (double)net_h);
+    dm.out_w = (float)tile_w; dm.out_h = (float)tile_h;
+    dm.det_boxes_net = det_boxes_net; dm.det_boxes = det_boxes; dm.det_scores = det_scores; dm.det_classes = det_classes;
+    dm.det_roi = det_roi; dm.det_count = det_count;
+    Stage st;
+    st.name = "box.merge_postprocess";
+    st.fn = [dm](int n, hipStream_t s) { return launch_det_merge(dm, n, s); };
+    stages.push_back(st);
+  }
+
+  // ---- mask head
+  if (S.mask_on) {
+    const int MR = S.mask_pooler_resolution, R = NB * D;
+    int *slot_list, *det_total;
+    if ((rc = alloc((void**)&slot_list, (size_t)R * 4))) return rc;
+    if ((rc = alloc((void**)&det_total, 16))) return rc;
+    reg("det_slot_list", slot_list, DT_I32, {R}, 0);
+    reg("det_total", det_total, DT_I32, {1}, 0);
+    {
+      Stage st;
+      st.name = "mask.compact";
+      int* dc = det_count;
+      const int Dc = D;
+      st.fn = [dc, Dc, slot_list, det_total](int n, hipStream_t s) { return launch_det_compact(dc, n, Dc, slot_list, det_total, s); };
+      stages.push_back(st);
+    }
+    Act mx;
+    if ((rc = new_act(&mx, "mask_pooled", R, MR, MR, 256, 1))) return rc;
+    {
+      RoiAlignParams q = ra;
+      q.rois = det_boxes_net; q.slot_list = slot_list; q.n_entries = det_total; q.slots_per_image = D;
+      q.out = mx.p; q.P = MR; q.out_pad = 1;
+      Stage st;
+      st.name = "mask.roi_align";
+      st.bytes_per_image = (double)D * MR * MR * 256 * 2 * 2;
+      const int Dc = D;
+      st.fn = [q, Dc](int n, hipStream_t s) mutable { q.S = n * Dc; return launch_roi_align(q, s); };
+      stages.push_back(st);
+    }
+    Act curm = mx;
+    for (int i = 0; i < S.mask_num_conv; ++i) {
+      Act o;
+      const std::string nm = "mask_fcn" + std::to_string(i + 1);
+      if ((rc = new_act(&o, nm, R, MR, MR, 256, 1))) return rc;
+      if ((rc = add_conv("mask.fcn" + std::to_string(i + 1), "roi_heads.mask_head." + nm, curm, o, 3, 1, 1, true, nullptr, nullptr, 256, D, det_total))) return rc;
+      curm = o;
+    }
+    Act dec;
+    if ((rc = new_act(&dec, "mask_deconv", R, 2 * MR, 2 * MR, 256, 0))) return rc;
+    {
+      const BlobEntry* w = find("roi_heads.mask_head.deconv.w");
+      const BlobEntry* b = find("roi_heads.mask_head.deconv.b");
+      RS_CHECK(w && b && w->dims[0] == 1024, RS_ERR_BLOB, "deconv weights missing / wrong rows");
+      ConvParams p;
+      memset(&p, 0, sizeof p);
+      p.in = curm.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev; p.out = dec.p;
+      p.Ho = MR; p.Wo = MR; p.in_Hp = curm.Hp(); p.in_Wp = curm.Wp(); p.in_Cs = 256; p.in_off = 1; p.stride = 1; p.KH = p.KW = 1;
+      p.Cin = 256; p.Kpad = (int)w->dims[1]; p.Cout = 256; p.out_Hp = 2 * MR; p.out_Wp = 2 * MR; p.out_Cs = 256; p.out_pad = 0; p.relu = 1;
+      p.mode = 1; p.m_count = det_total; p.m_mul = MR * MR;
+      const int glds = use_glds, Dc = D, per_roi = MR * MR;
+      Stage st;
+      st.name = "mask.deconv";
+      st.flops_per_image = 2.0 * D * per_roi * 256 * 1024;
+      st.bytes_per_image = (double)D * per_roi * 256 * 2 * 5;
+      st.fn = [p, per_roi, Dc, glds](int n, hipStream_t s) mutable { p.M = n * Dc * per_roi; return launch_conv(p, s, -1, glds); };
+      stages.push_back(st);
+    }
+    if ((rc = alloc((void**)&mask_probs, (size_t)R * RS_MASK_SIDE * RS_MASK_SIDE * 4))) return rc;
+    reg("mask_probs", mask_probs, DT_F32, {NB, D, RS_MASK_SIDE, RS_MASK_SIDE}, 0);
+    {
+      const BlobEntry* w = find("roi_heads.mask_head.predictor.w");
+      const BlobEntry* b = find("roi_heads.mask_head.predictor.b");
+      RS_CHECK(w && b && w->dtype == DT_F32, RS_ERR_BLOB, "mask predictor weights missing");
+      MaskPredictParams mp;
+      mp.in = dec.p; mp.w = (const float*)w->dev; mp.b = (const float*)b->dev; mp.slot_list = slot_list; mp.det_classes = det_classes;
+      mp.n_entries = det_total; mp.out = mask_probs; mp.S = RS_MASK_SIDE;
+      Stage st;
+      st.name = "mask.predict_sigmoid";
+      st.bytes_per_image = (double)D * RS_MASK_SIDE * RS_MASK_SIDE * (256 * 2 + 4);
+      const int Dc = D;
+      st.fn = [mp, Dc](int n, hipStream_t s) { return launch_mask_predict(mp, n * Dc, s); };
+      stages.push_back(st);
+    }
+    const int Wb = (tile_w + 7) / 8;
+    if ((rc = alloc((void**)&masks, (size_t)R * tile_h * Wb))) return rc;
+    reg("masks", masks, DT_U8, {NB, D, tile_h, Wb}, 0);
+    {
+      PasteParams pm;
+      pm.probs = mask_probs; pm.det_boxes = det_boxes; pm.slot_list = slot_list; pm.n_entries = det_total; pm.out = masks;
+      pm.S = RS_MASK_SIDE; pm.out_h = tile_h; pm.out_w = tile_w; pm.threshold = S.mask_threshold;
+      Stage st;
+      st.name = "mask.paste";
+      st.bytes_per_image = (double)D * tile_h * Wb;
+      const int Dc = D;
+      st.fn = [pm, Dc](int n, hipStream_t s) { return launch_paste_masks(pm, n * Dc, s); };
+      stages.push_back(st);
+    }
+  }
+  RS_HIP(hipStreamSynchronize(stream));
+  return RS_OK;
+}
+
+int rs_engine::run(const uint8_t* tiles, int n) {
+  RS_CHECK(n >= 1 && n <= max_batch, RS_ERR_ARG, "batch %d outside [1, %d]", n, max_batch);
+  if (tiles != tiles_dev) {
+    // tiles already resident elsewhere on the device: stage them into the engine's input buffer
+    RS_HIP(hipMemcpyAsync(tiles_dev, tiles, (size_t)n * tile_h * tile_w * tile_c, hipMemcpyDeviceToDevice, stream));
+  }
+  for (Stage& st : stages) {
+    if (profiling) RS_HIP(hipEventRecord(ev0, stream));
+    int rc = st.fn(n, stream);
+    if (rc) return rc;
+    if (profiling) {
+      RS_HIP(hipEventRecord(ev1, stream));
+      RS_HIP(hipEventSynchronize(ev1));
+      float ms = 0.f;
+      RS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+      st.ms_total += ms;
+      st.calls += 1;
+      st.last_flops = st.flops_per_image * n;
+      st.last_bytes = st.bytes_per_image * n;
+    }
+  }
+  return RS_OK;
+}
+
+// ===================================================================================== C ABI
+extern "C" {
+
+const char* rs_last_error(void) { return g_err; }
+int rs_abi_version(void) { return RS_ABI_VERSION; }
+
+int rs_memcpy_d2h(void* dst, const void* src, size_t n) {
+  RS_HIP(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+int rs_memcpy_h2d(void* dst, const void* src, size_t n) {
+  RS_HIP(hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+  return RS_OK;
+}
+
+int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, int device_ordinal, int max_batch,
+                     int tile_h, int tile_w, int tile_c, void* stream, rs_engine** out) {
+  RS_CHECK(spec && weights && out, RS_ERR_ARG, "null argument");
+  RS_CHECK(spec->struct_size == (int32_t)sizeof(rs_spec), RS_ERR_ARG, "rs_spec size mismatch: caller %d, library %d", spec->struct_size, (int)sizeof(rs_spec));
+  RS_CHECK(max_batch >= 1 && tile_h >= 32 && tile_w >= 32, RS_ERR_ARG, "bad batch/tile shape");
+  int ndev = 0;
+  RS_HIP(hipGetDeviceCount(&ndev));
+  RS_CHECK(ndev > 0, RS_ERR_HIP, "no HIP device visible: the engine has no CPU fallback");
+  RS_CHECK(device_ordinal >= 0 && device_ordinal < ndev, RS_ERR_ARG, "device %d of %d", device_ordinal, ndev);
+  RS_HIP(hipSetDevice(device_ordinal));
+  rs_engine* e = new rs_engine();
+  e->spec = *spec;
+  e->device = device_ordinal;
+  e->max_batch = max_batch; e->tile_h = tile_h; e->tile_w = tile_w; e->tile_c = tile_c;
+  const char* g = getenv("RS_USE_GLDS");
+  e->use_glds = g ? atoi(g) : 1;
+  if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
+  else {
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { rs_set_error("hipStreamCreate: %s", hipGetErrorString(he)); delete e; return RS_ERR_HIP; }
+    e->own_stream = true;
+  }
+  int rc = RS_OK;
+  if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { rs_set_error("hipEventCreate failed"); rc = RS_ERR_HIP; }
+  if (!rc) rc = e->parse_blob(weights, nbytes);
+  if (!rc) rc = e->build();
+  if (rc) { rs_engine_destroy(e); return rc; }
+  *out = e;
+  return RS_OK;
+}
+
+void rs_engine_destroy(rs_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  for (void* p : e->allocs) hipFree(p);
+  if (e->blob_dev) hipFree(e->blob_dev);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int rs_engine_infer_device(rs_engine* e, const uint8_t* tiles_dev, int n) {
+  RS_CHECK(e && tiles_dev, RS_ERR_ARG, "null argument");
+  RS_HIP(hipSetDevice(e->device));
+  return e->run(tiles_dev, n);
+}
+
+int rs_engine_sync(rs_engine* e) {
+  RS_CHECK(e, RS_ERR_ARG, "null engine");
+  RS_HIP(hipStreamSynchronize(e->stream));
+  return RS_OK;
+}
+
+int rs_engine_fetch(rs_engine* e, int n, rs_dets* o) {
+  RS_CHECK(e && o && o->count, RS_ERR_ARG, "null argument");
+  RS_CHECK(n >= 1 && n <= e->max_batch, RS_ERR_ARG, "batch %d", n);
+  const int D = e->D;
+  hipStream_t s = e->stream;
+  RS_HIP(hipMemcpyAsync(o->count, e->det_count, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  if (o->boxes) RS_HIP(hipMemcpyAsync(o->boxes, e->det_boxes, (size_t)n * D * 16, hipMemcpyDeviceToHost, s));
+  if (o->scores) RS_HIP(hipMemcpyAsync(o->scores, e->det_scores, (size_t)n * D * 4, hipMemcpyDeviceToHost, s));
+  if (o->classes) RS_HIP(hipMemcpyAsync(o->classes, e->det_classes, (size_t)n * D * 4, hipMemcpyDeviceToHost, s));
+  if (o->masks) {
+    RS_CHECK(e->masks, RS_ERR_ARG, "masks requested but MASK_ON is false");
+    RS_HIP(hipMemcpyAsync(o->masks, e->masks, (size_t)n * D * e->tile_h * ((e->tile_w + 7) / 8), hipMemcpyDeviceToHost, s));
+  }
+  if (o->mask_probs) {
+    RS_CHECK(e->mask_probs, RS_ERR_ARG, "mask_probs requested but MASK_ON is false");
+    RS_HIP(hipMemcpyAsync(o->mask_probs, e->mask_probs, (size_t)n * D * RS_MASK_SIDE * RS_MASK_SIDE * 4, hipMemcpyDeviceToHost, s));
+  }
+  RS_HIP(hipStreamSynchronize(s));
+  return RS_OK;
+}
+
+int rs_engine_infer(rs_engine* e, const uint8_t* tiles_host, int n, rs_dets* out_host) {
+  RS_CHECK(e && tiles_host && out_host, RS_ERR_ARG, "null argument");
+  RS_CHECK(n >= 1 && n <= e->max_batch, RS_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
+  RS_HIP(hipSetDevice(e->device));
+  RS_HIP(hipMemcpyAsync(e->tiles_dev, tiles_host, (size_t)n * e->tile_h * e->tile_w * e->tile_c, hipMemcpyHostToDevice, e->stream));
+  int rc = e->run(e->tiles_dev, n);
+  if (rc) return rc;
+  return rs_engine_fetch(e, n, out_host);
+}
+
+void* rs_engine_stream(rs_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int rs_engine_set_profiling(rs_engine* e, int enabled) {
+  RS_CHECK(e, RS_ERR_ARG, "null engine");
+  e->profiling = enabled != 0;
+  for (Stage& s : e->stages) { s.ms_total = 0; s.calls = 0; }
+  return RS_OK;
+}
+int rs_engine_stage_count(rs_engine* e) { return e ? (int)e->stages.size() : 0; }
+int rs_engine_stage_info(rs_engine* e, int i, char* name_out, double* ms_total, int* calls, double* flops, double* bytes) {
+  RS_CHECK(e && i >= 0 && i < (int)e->stages.size(), RS_ERR_ARG, "stage index");
+  const Stage& s = e->stages[i];
+  if (name_out) { strncpy(name_out, s.name.c_str(), 95); name_out[95] = 0; }
+  if (ms_total) *ms_total = s.ms_total;
+  if (calls) *calls = s.calls;
+  if (flops) *flops = s.last_flops;
+  if (bytes) *bytes = s.last_bytes;
+  return RS_OK;
+}
+
+int rs_engine_tensor(rs_engine* e, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo) {
+  RS_CHECK(e && name, RS_ERR_ARG, "null argument");
+  for (const TensorInfo& t : e->tensors) {
+    if (t.name == name) {
+      if (dev_ptr) *dev_ptr = t.p;
+      if (dtype) *dtype = t.dtype;
+      if (ndim) *ndim = t.ndim;
+      if (dims) for (int i = 0; i < 5; ++i) dims[i] = t.dims[i];
+      if (halo) *halo = t.halo;
+      return RS_OK;
+    }
+  }
+  rs_set_error("no tensor named %s", name);
+  return RS_ERR_ARG;
+}
+int rs_engine_tensor_count(rs_engine* e) { return e ? (int)e->tensors.size() : 0; }
+int rs_engine_tensor_name(rs_engine* e, int i, char* name_out) {
+  RS_CHECK(e && i >= 0 && i < (int)e->tensors.size() && name_out, RS_ERR_ARG, "tensor index");
+  strncpy(name_out, e->tensors[i].name.c_str(), 95);
+  name_out[95] = 0;
+  return RS_OK;
+}
+
+int rs_engine_net_shape(rs_engine* e, int* rh, int* rw, int* ph, int* pw) {
+  RS_CHECK(e, RS_ERR_ARG, "null engine");
+  if (rh) *rh = e->net_h;
+  if (rw) *rw = e->net_w;
+  if (ph) *ph = e->pad_h;
+  if (pw) *pw = e->pad_w;
+  return RS_OK;
+}
+
+// ------------------------------------------------------------------------- stand-alone operators
+int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual, const void* upsample_add,
+                 int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
+                 int out_halo, int relu, int out_f32, int deconv2x, int variant, int use_glds, void* stream) {
+  RS_CHECK(in && w && bias && out, RS_ERR_ARG, "null argument");
+  RS_CHECK(in_halo >= pad, RS_ERR_ARG, "input halo %d < pad %d", in_halo, pad);
+  const int ho = (hi + 2 * pad - kh) / stride + 1, wo = (wi + 2 * pad - kw) / stride + 1;
+  ConvParams p;
+  memset(&p, 0, sizeof p);
+  p.in = (const half_t*)in; p.w = (const half_t*)w; p.bias = bias; p.out = out;
+  p.res = (const half_t*)residual; p.up = (const half_t*)upsample_add;
+  p.M = n * ho * wo; p.Ho = ho; p.Wo = wo;
+  p.in_Hp = hi + 2 * in_halo; p.in_Wp = wi + 2 * in_halo; p.in_Cs = cin; p.in_off = in_halo - pad;
+  p.stride = stride; p.KH = kh; p.KW = kw; p.Cin = cin; p.Kpad = kpad; p.Cout = cout;
+  const int oh = deconv2x ? 2 * ho : ho, ow = deconv2x ? 2 * wo : wo;
+  p.out_Hp = oh + 2 * out_halo; p.out_Wp = ow + 2 * out_halo; p.out_Cs = cout; p.out_pad = out_halo;
+  if (upsample_add) { p.up_Hp = ho / 2 + 2 * out_halo; p.up_Wp = wo / 2 + 2 * out_halo; p.up_Cs = cout; p.up_pad = out_halo; }
+  p.relu = relu; p.mode = deconv2x ? 1 : 0; p.out_f32 = out_f32;
+  int* koff_dev = nullptr;
+  if (cin < 64) {
+    RS_CHECK(cin == 8, RS_ERR_UNSUPPORTED, "small-Cin path needs cin == 8");
+    std::vector<int> koff(kpad / 8, 0);
+    for (int t = 0; t < kh * kw && t < (int)koff.size(); ++t) koff[t] = ((t / kw) * p.in_Wp + (t % kw)) * cin;
+    RS_HIP(hipMalloc((void**)&koff_dev, koff.size() * 4));
+    RS_HIP(hipMemcpy(koff_dev, koff.data(), koff.size() * 4, hipMemcpyHostToDevice));
+    p.koff = koff_dev;
+  }
+  int rc = launch_conv(p, (hipStream_t)stream, variant, use_glds);
+  if (koff_dev) {
+    hipStreamSynchronize((hipStream_t)stream);
+    hipFree(koff_dev);
+  }
+  return rc;
+}
+
+int rs_op_nms(const float* boxes, const int32_t* counts, const uint8_t* valid, uint8_t* keep, int segments, int cap,
+              float thresh, void* stream) {
+  RS_CHECK(boxes && counts && keep && segments > 0, RS_ERR_ARG, "bad argument");
+  RS_CHECK(cap >= 1 && cap <= 1024, RS_ERR_ARG, "cap %d outside [1,1024]", cap);
+  NmsParams p;
+  p.boxes = boxes; p.count = counts; p.valid = valid; p.keep = keep; p.cap = cap; p.thresh = thresh;
+  return launch_nms(p, segments, (hipStream_t)stream);
+}
+
+int rs_op_roi_align(const void* const feats[4], const int32_t heights[4], const int32_t widths[4], const float scales[4],
+                    int nlevels, const float* rois, int n_rois, int rois_per_image, int P, int out_halo, void* out,
+                    int32_t* levels_out, void* stream) {
+  RS_CHECK(feats && rois && out && nlevels >= 1 && nlevels <= 4 && n_rois > 0 && rois_per_image > 0, RS_ERR_ARG, "bad argument");
+  RoiAlignParams p;
+  memset(&p, 0, sizeof p);
+  for (int l = 0; l < nlevels; ++l) { p.feat[l] = (const half_t*)feats[l]; p.H[l] = heights[l]; p.W[l] = widths[l]; p.scale[l] = scales[l]; }
+  p.nlevels = nlevels; p.C = 256; p.rois = rois; p.S = n_rois; p.slots_per_image = rois_per_image;
+  p.out = (half_t*)out; p.P = P; p.out_pad = out_halo; p.out_level = levels_out;
+  return launch_roi_align(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// Tile ingest and the two pooling ops of the backbone (HBM-bound byte/half kernels).
+//
+//  * preprocess_kernel: DefaultPredictor.__call__ + GeneralizedRCNN.preprocess_image fused
+//    ([EXT d2: engine/defaults.py, data/transforms/transform.py ResizeTransform,
+//      modeling/meta_arch/rcnn.py]; R:config/detectron2_config_3bands.yaml:26-30,81-88):
+//    BGR->RGB flip, Pillow's 2-pass fixed-point bilinear resize (uint8 rounding between the
+//    passes, antialiased when shrinking -- coefficient tables come from the host, bit-exact with
+//    Pillow's precompute_coeffs/normalize_coeffs_8bpc), (x-mean)/std, fp16 NHWC with the channel
+//    dim padded to 8 and a 3-pixel zero halo for the 7x7 stem.
+//  * maxpool3x3s2_kernel: stem max_pool2d(3, 2, 1) [EXT d2: modeling/backbone/resnet.py BasicStem].
+//    The input is post-ReLU (>= 0), so the zero halo is equivalent to -inf padding.
+//  * subsample2_kernel: LastLevelMaxPool = max_pool2d(k=1, s=2) [EXT d2: modeling/backbone/fpn.py].
+#include "common.h"
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)p.N * p.new_h * p.new_w;
+  if (gid >= total) return;
+  const int X = (int)(gid % p.new_w);
+  const long long t = gid / p.new_w;
+  const int Y = (int)(t % p.new_h);
+  const int n = (int)(t / p.new_h);
+  int ymin = Y, ny = 1, xmin = X, nx = 1;
+  if (p.need_v) { ymin = p.vb[Y * 2]; ny = p.vb[Y * 2 + 1]; }
+  if (p.need_h) { xmin = p.hb[X * 2]; nx = p.hb[X * 2 + 1]; }
+  const uint8_t* img = p.tiles + (long long)n * p.H * p.W * p.C;
+  half8 o;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = (half_t)0.f;
+  for (int c = 0; c < p.C; ++c) {
+    const int cs = p.flip ? (p.C - 1 - c) : c;
+    int vacc = 1 << 21;
+    int val = 0;
+    for (int ty = 0; ty < ny; ++ty) {
+      const uint8_t* row = img + ((long long)(ymin + ty) * p.W) * p.C + cs;
+      int h;
+      if (p.need_h) {
+        int ss = 1 << 21;
+        for (int tx = 0; tx < nx; ++tx) ss += (int)row[(xmin + tx) * p.C] * p.hk[X * p.ksh + tx];
+        h = ss >> 22;
+        h = h < 0 ? 0 : (h > 255 ? 255 : h);
+      } else {
+        h = row[X * p.C];
+      }
+      if (p.need_v) vacc += h * p.vk[Y * p.ksv + ty];
+      else val = h;
+    }
+    if (p.need_v) {
+      val = vacc >> 22;
+      val = val < 0 ? 0 : (val > 255 ? 255 : val);
+    }
+    const float f = ((float)val - p.mean[c]) / p.stdv[c];
+    o[c] = (half_t)f;
+  }
+  half_t* dst = p.out + (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 8;
+  *(half8*)dst = o;
+}
+
+int launch_preprocess(const PreprocParams& p, hipStream_t s) {
+  const long long total = (long long)p.N * p.new_h * p.new_w;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+// in: [N][Hi+2][Wi+2][C] (halo 1), out: [N][Ho+2][Wo+2][C] (halo 1); window 3x3 stride 2 pad 1.
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C) {
+  const int cv = C >> 3;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Ho * Wo * cv;
+  if (gid >= total) return;
+  const int c8 = (int)(gid % cv);
+  long long t = gid / cv;
+  const int x = (int)(t % Wo); t /= Wo;
+  const int y = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  const int Hip = Hi + 2, Wip = Wi + 2;
+  // output (y,x) covers input rows 2y-1..2y+1 -> halo-buffer rows 2y..2y+2
+  half8 m;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m[i] = (half_t)0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const half8 v = *(const half8*)(in + (((long long)n * Hip + 2 * y + dy) * Wip + 2 * x + dx) * C + c8 * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m[i] = v[i] > m[i] ? v[i] : m[i];
+    }
+  *(half8*)(out + (((long long)n * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * C + c8 * 8) = m;
+}
+
+int launch_maxpool(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s) {
+  const long long total = (long long)N * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, N, Hi, Wi, Ho, Wo, C);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+// out[n][y][x][:] = in[n][2y][2x][:]; both with halo 1.
+__global__ __launch_bounds__(256) void subsample2_kernel(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C) {
+  const int cv = C >> 3;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Ho * Wo * cv;
+  if (gid >= total) return;
+  const int c8 = (int)(gid % cv);
+  long long t = gid / cv;
+  const int x = (int)(t % Wo); t /= Wo;
+  const int y = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  const half8 v = *(const half8*)(in + (((long long)n * (Hi + 2) + 2 * y + 1) * (Wi + 2) + 2 * x + 1) * C + c8 * 8);
+  *(half8*)(out + (((long long)n * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * C + c8 * 8) = v;
+}
+
+int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s) {
+  const long long total = (long long)N * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(subsample2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, N, Hi, Wi, Ho, Wo, C);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}

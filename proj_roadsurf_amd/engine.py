@@ -1,0 +1,368 @@
+"""ctypes binding of ``librs_engine.so`` (C ABI: ``include/rs_engine.h``).
+
+This is the host-side mirror of the call the reference's detector makes per tile,
+``DefaultPredictor(cfg)(im)`` ([EXT d2: engine/defaults.py], invoked by the object-detector's
+``make_detections.py``, R:README.md:78).  There is no CPU fallback: if the shared library or a HIP
+device is missing the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .spec import EngineSpec
+from .weights import pack_weights
+
+_LIB: Optional[C.CDLL] = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librs_engine.so")
+MAX_LEVELS, MAX_ANCHORS, MASK_SIDE = 5, 8, 28
+DT_NP = {1: np.float16, 2: np.float32, 3: np.int32, 4: np.uint8}
+
+
+class RsError(RuntimeError):
+    pass
+
+
+class RsSpec(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("in_channels", C.c_int32), ("flip_channels", C.c_int32),
+        ("pixel_mean", C.c_float * 4), ("pixel_std", C.c_float * 4),
+        ("min_size_test", C.c_int32), ("max_size_test", C.c_int32), ("size_divisibility", C.c_int32),
+        ("res_blocks", C.c_int32 * 4), ("stem_out_channels", C.c_int32), ("res2_out_channels", C.c_int32),
+        ("stride_in_1x1", C.c_int32), ("fpn_out_channels", C.c_int32),
+        ("num_levels", C.c_int32), ("num_anchors", C.c_int32),
+        ("cell_anchors", ((C.c_float * 4) * MAX_ANCHORS) * MAX_LEVELS), ("anchor_offset", C.c_float),
+        ("rpn_bbox_reg_weights", C.c_float * 4), ("rpn_pre_nms_topk", C.c_int32), ("rpn_post_nms_topk", C.c_int32),
+        ("rpn_nms_thresh", C.c_float), ("rpn_min_size", C.c_float),
+        ("num_classes", C.c_int32), ("box_reg_weights", C.c_float * 4),
+        ("score_thresh_test", C.c_float), ("nms_thresh_test", C.c_float), ("detections_per_image", C.c_int32),
+        ("box_fc_dim", C.c_int32), ("box_pooler_resolution", C.c_int32),
+        ("mask_on", C.c_int32), ("mask_pooler_resolution", C.c_int32), ("mask_num_conv", C.c_int32),
+        ("mask_conv_dim", C.c_int32), ("mask_threshold", C.c_float), ("scale_clamp", C.c_float),
+    ]
+
+
+class RsDets(C.Structure):
+    _fields_ = [("count", C.POINTER(C.c_int32)), ("boxes", C.POINTER(C.c_float)), ("scores", C.POINTER(C.c_float)),
+                ("classes", C.POINTER(C.c_int32)), ("masks", C.POINTER(C.c_uint8)), ("mask_probs", C.POINTER(C.c_float))]
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load librs_engine.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RsError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc, gfx950). There is no CPU fallback for the detection path.")
+    lib = C.CDLL(p)
+    vp, i32, f32p, i32p, u8p = C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    lib.rs_last_error.restype = C.c_char_p
+    lib.rs_abi_version.restype = i32
+    lib.rs_engine_create.argtypes = [C.POINTER(RsSpec), vp, C.c_size_t, i32, i32, i32, i32, i32, vp, C.POINTER(vp)]
+    lib.rs_engine_destroy.argtypes = [vp]
+    lib.rs_engine_destroy.restype = None
+    lib.rs_engine_infer.argtypes = [vp, vp, i32, C.POINTER(RsDets)]
+    lib.rs_engine_infer_device.argtypes = [vp, vp, i32]
+    lib.rs_engine_sync.argtypes = [vp]
+    lib.rs_engine_fetch.argtypes = [vp, i32, C.POINTER(RsDets)]
+    lib.rs_engine_stream.argtypes = [vp]
+    lib.rs_engine_stream.restype = vp
+    lib.rs_engine_set_profiling.argtypes = [vp, i32]
+    lib.rs_engine_stage_count.argtypes = [vp]
+    lib.rs_engine_stage_info.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_double), i32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.rs_engine_tensor.argtypes = [vp, C.c_char_p, C.POINTER(vp), i32p, i32p, C.POINTER(C.c_int64), i32p]
+    lib.rs_engine_tensor_count.argtypes = [vp]
+    lib.rs_engine_tensor_name.argtypes = [vp, i32, C.c_char_p]
+    lib.rs_engine_net_shape.argtypes = [vp, i32p, i32p, i32p, i32p]
+    lib.rs_op_conv2d.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 17 + [vp]
+    lib.rs_op_nms.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp]
+    lib.rs_op_roi_align.argtypes = [C.POINTER(vp), i32p, i32p, f32p, i32, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.rs_resize_shape.argtypes = [i32, i32, i32, i32, i32p, i32p]
+    lib.rs_resize_shape.restype = None
+    lib.rs_resize_coeffs.argtypes = [i32, i32, i32p, i32p]
+    lib.rs_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    lib.rs_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _check(lib: C.CDLL, rc: int, what: str) -> None:
+    if rc != 0:
+        raise RsError(f"{what} failed ({rc}): {lib.rs_last_error().decode(errors='replace')}")
+
+
+def cell_anchor_table(spec: EngineSpec) -> np.ndarray:
+    """``DefaultAnchorGenerator.generate_cell_anchors`` [EXT d2: modeling/anchor_generator.py]
+    (R:45-56): float64 arithmetic, stored as fp32.  Shape (levels, anchors, 4)."""
+    out = np.zeros((len(spec.anchor_sizes), spec.num_anchors, 4), np.float32)
+    for l, sizes in enumerate(spec.anchor_sizes):
+        a = 0
+        for size in sizes:
+            area = float(size) ** 2.0
+            for ar in spec.anchor_aspect_ratios:
+                w = math.sqrt(area / ar)
+                h = ar * w
+                out[l, a] = (-w / 2.0, -h / 2.0, w / 2.0, h / 2.0)
+                a += 1
+    return out
+
+
+def make_rs_spec(spec: EngineSpec) -> RsSpec:
+    spec.check_supported()
+    s = RsSpec()
+    s.struct_size = C.sizeof(RsSpec)
+    s.in_channels = spec.in_channels
+    s.flip_channels = 1 if spec.input_format == "RGB" else 0
+    for i in range(spec.in_channels):
+        s.pixel_mean[i] = spec.pixel_mean[i]
+        s.pixel_std[i] = spec.pixel_std[i]
+    s.min_size_test, s.max_size_test, s.size_divisibility = spec.min_size_test, spec.max_size_test, spec.size_divisibility
+    for i, b in enumerate(spec.res_blocks):
+        s.res_blocks[i] = b
+    s.stem_out_channels, s.res2_out_channels = spec.stem_out_channels, spec.res2_out_channels
+    s.stride_in_1x1 = int(spec.stride_in_1x1)
+    s.fpn_out_channels = spec.fpn_out_channels
+    s.num_levels, s.num_anchors = len(spec.rpn_in_features), spec.num_anchors
+    if s.num_levels > MAX_LEVELS or s.num_anchors > MAX_ANCHORS:
+        raise RsError("too many RPN levels / anchors")
+    ca = cell_anchor_table(spec)
+    for l in range(ca.shape[0]):
+        for a in range(ca.shape[1]):
+            for d in range(4):
+                s.cell_anchors[l][a][d] = float(ca[l, a, d])
+    s.anchor_offset = spec.anchor_offset
+    for i in range(4):
+        s.rpn_bbox_reg_weights[i] = spec.rpn_bbox_reg_weights[i]
+        s.box_reg_weights[i] = spec.box_reg_weights[i]
+    s.rpn_pre_nms_topk, s.rpn_post_nms_topk = spec.rpn_pre_nms_topk_test, spec.rpn_post_nms_topk_test
+    s.rpn_nms_thresh, s.rpn_min_size = spec.rpn_nms_thresh, spec.rpn_min_size
+    s.num_classes = spec.num_classes
+    s.score_thresh_test, s.nms_thresh_test = spec.score_thresh_test, spec.nms_thresh_test
+    s.detections_per_image = spec.detections_per_image
+    s.box_fc_dim, s.box_pooler_resolution = spec.box_fc_dim, spec.box_pooler_resolution
+    s.mask_on, s.mask_pooler_resolution = int(spec.mask_on), spec.mask_pooler_resolution
+    s.mask_num_conv, s.mask_conv_dim = spec.mask_num_conv, spec.mask_conv_dim
+    s.mask_threshold, s.scale_clamp = spec.mask_threshold, spec.scale_clamp
+    return s
+
+
+class Instances:
+    """Numpy-backed stand-in for detectron2 ``Instances`` ([EXT d2: structures/instances.py]) with the
+    four fields the object-detector reads: ``pred_boxes`` (n,4 XYXY abs, tile pixels), ``scores``,
+    ``pred_classes``, ``pred_masks`` (n,H,W bool).  Sorted by score, descending."""
+
+    def __init__(self, image_size: Tuple[int, int], pred_boxes: np.ndarray, scores: np.ndarray, pred_classes: np.ndarray,
+                 packed_masks: Optional[np.ndarray], mask_probs: Optional[np.ndarray]):
+        self.image_size = image_size
+        self.pred_boxes = pred_boxes
+        self.scores = scores
+        self.pred_classes = pred_classes
+        self._packed = packed_masks
+        self.mask_probs = mask_probs
+
+    def __len__(self) -> int:
+        return int(self.scores.shape[0])
+
+    def has(self, name: str) -> bool:
+        return name in ("pred_boxes", "scores", "pred_classes") or (name == "pred_masks" and self._packed is not None)
+
+    @property
+    def pred_masks(self) -> np.ndarray:
+        if self._packed is None:
+            raise AttributeError("pred_masks not computed (MASK_ON false)")
+        h, w = self.image_size
+        if len(self) == 0:
+            return np.zeros((0, h, w), bool)
+        bits = np.unpackbits(self._packed, axis=-1, bitorder="little")[:, :, :w]
+        return bits.astype(bool)
+
+    def to(self, *_a: Any, **_k: Any) -> "Instances":   # ``instances.to("cpu")`` in caller code
+        return self
+
+    def get_fields(self) -> Dict[str, Any]:
+        d = {"pred_boxes": self.pred_boxes, "scores": self.scores, "pred_classes": self.pred_classes}
+        if self._packed is not None:
+            d["pred_masks"] = self.pred_masks
+        return d
+
+
+class Engine:
+    """One engine = one process, one GPU, one tile shape, batches up to ``max_batch``."""
+
+    def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], max_batch: int = 16,
+                 device: int = 0, stream: Optional[int] = None, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        if self.lib.rs_abi_version() != 1:
+            raise RsError("librs_engine.so ABI version mismatch")
+        self.spec = spec
+        self.tile_h, self.tile_w, self.tile_c = (int(x) for x in tile_shape)
+        self.max_batch = int(max_batch)
+        self.D = spec.detections_per_image
+        blob = pack_weights(spec, weights)
+        rs = make_rs_spec(spec)
+        h = C.c_void_p()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        rc = self.lib.rs_engine_create(C.byref(rs), buf, len(blob), device, self.max_batch, self.tile_h, self.tile_w, self.tile_c,
+                                       C.c_void_p(stream) if stream else None, C.byref(h))
+        _check(self.lib, rc, "rs_engine_create")
+        self._h = h
+        self._alloc_out(self.max_batch)
+
+    # ------------------------------------------------------------------ plumbing
+    def _alloc_out(self, n: int) -> None:
+        D, h, wb = self.D, self.tile_h, (self.tile_w + 7) // 8
+        self._count = np.zeros(n, np.int32)
+        self._boxes = np.zeros((n, D, 4), np.float32)
+        self._scores = np.zeros((n, D), np.float32)
+        self._classes = np.zeros((n, D), np.int32)
+        self._masks = np.zeros((n, D, h, wb), np.uint8) if self.spec.mask_on else None
+        self._probs = np.zeros((n, D, MASK_SIDE, MASK_SIDE), np.float32) if self.spec.mask_on else None
+
+    def _dets_struct(self, want_probs: bool) -> RsDets:
+        d = RsDets()
+        d.count = self._count.ctypes.data_as(C.POINTER(C.c_int32))
+        d.boxes = self._boxes.ctypes.data_as(C.POINTER(C.c_float))
+        d.scores = self._scores.ctypes.data_as(C.POINTER(C.c_float))
+        d.classes = self._classes.ctypes.data_as(C.POINTER(C.c_int32))
+        if self._masks is not None:
+            d.masks = self._masks.ctypes.data_as(C.POINTER(C.c_uint8))
+            if want_probs:
+                d.mask_probs = self._probs.ctypes.data_as(C.POINTER(C.c_float))
+        return d
+
+    def _collect(self, n: int, want_probs: bool) -> List[Instances]:
+        out = []
+        for i in range(n):
+            c = int(self._count[i])
+            out.append(Instances((self.tile_h, self.tile_w), self._boxes[i, :c].copy(), self._scores[i, :c].copy(),
+                                 self._classes[i, :c].astype(np.int64),
+                                 self._masks[i, :c].copy() if self._masks is not None else None,
+                                 self._probs[i, :c].copy() if (self._probs is not None and want_probs) else None))
+        return out
+
+    # ------------------------------------------------------------------ inference
+    def infer(self, tiles: np.ndarray, want_probs: bool = False) -> List[Instances]:
+        """tiles: (n, h, w, c) uint8, BGR as ``cv2.imread`` returns them.  Returns one ``Instances`` per tile."""
+        tiles = np.ascontiguousarray(tiles)
+        if tiles.dtype != np.uint8 or tiles.ndim != 4 or tiles.shape[1:] != (self.tile_h, self.tile_w, self.tile_c):
+            raise ValueError(f"tiles must be uint8 (n,{self.tile_h},{self.tile_w},{self.tile_c}), got {tiles.dtype} {tiles.shape}")
+        n = tiles.shape[0]
+        if not 1 <= n <= self.max_batch:
+            raise ValueError(f"batch {n} outside [1, {self.max_batch}]")
+        d = self._dets_struct(want_probs)
+        rc = self.lib.rs_engine_infer(self._h, tiles.ctypes.data_as(C.c_void_p), n, C.byref(d))
+        _check(self.lib, rc, "rs_engine_infer")
+        return self._collect(n, want_probs)
+
+    def infer_device(self, tiles_dev_ptr: int, n: int) -> None:
+        """Enqueue a forward on tiles already in device memory (no wait)."""
+        _check(self.lib, self.lib.rs_engine_infer_device(self._h, C.c_void_p(tiles_dev_ptr), n), "rs_engine_infer_device")
+
+    def sync(self) -> None:
+        _check(self.lib, self.lib.rs_engine_sync(self._h), "rs_engine_sync")
+
+    def fetch(self, n: int, want_probs: bool = False) -> List[Instances]:
+        d = self._dets_struct(want_probs)
+        _check(self.lib, self.lib.rs_engine_fetch(self._h, n, C.byref(d)), "rs_engine_fetch")
+        return self._collect(n, want_probs)
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.rs_engine_stream(self._h) or 0)
+
+    def net_shape(self) -> Tuple[int, int, int, int]:
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _check(self.lib, self.lib.rs_engine_net_shape(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "net_shape")
+        return a.value, b.value, c.value, d.value
+
+    # ------------------------------------------------------------------ introspection
+    def tensor_names(self) -> List[str]:
+        buf = C.create_string_buffer(96)
+        names = []
+        for i in range(self.lib.rs_engine_tensor_count(self._h)):
+            self.lib.rs_engine_tensor_name(self._h, i, buf)
+            names.append(buf.value.decode())
+        return names
+
+    def tensor_ptr(self, name: str) -> Tuple[int, np.dtype, Tuple[int, ...], int]:
+        p, dt, nd, halo = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        dims = (C.c_int64 * 5)()
+        _check(self.lib, self.lib.rs_engine_tensor(self._h, name.encode(), C.byref(p), C.byref(dt), C.byref(nd), dims, C.byref(halo)),
+               f"rs_engine_tensor({name})")
+        return int(p.value), np.dtype(DT_NP[dt.value]), tuple(int(dims[i]) for i in range(nd.value)), halo.value
+
+    def tensor(self, name: str, n: Optional[int] = None, strip_halo: bool = True) -> np.ndarray:
+        """Copy an intermediate tensor to the host.  NHWC activations lose their halo; ``n`` limits the
+        leading (batch) dimension."""
+        ptr, dt, shape, halo = self.tensor_ptr(name)
+        if n is not None:
+            shape = (min(n, shape[0]),) + shape[1:]
+        a = np.empty(shape, dt)
+        _check(self.lib, self.lib.rs_memcpy_d2h(a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), a.nbytes), "rs_memcpy_d2h")
+        if strip_halo and halo:
+            a = a[:, halo:-halo, halo:-halo]
+        return a
+
+    def set_profiling(self, on: bool) -> None:
+        _check(self.lib, self.lib.rs_engine_set_profiling(self._h, int(on)), "rs_engine_set_profiling")
+
+    def stage_times(self) -> List[Dict[str, Any]]:
+        out = []
+        name = C.create_string_buffer(96)
+        ms, fl, by, calls = C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        for i in range(self.lib.rs_engine_stage_count(self._h)):
+            self.lib.rs_engine_stage_info(self._h, i, name, C.byref(ms), C.byref(calls), C.byref(fl), C.byref(by))
+            out.append({"name": name.value.decode(), "ms_total": ms.value, "calls": calls.value, "flops": fl.value, "bytes": by.value})
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.rs_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Predictor:
+    """Drop-in for ``detectron2.engine.DefaultPredictor``: ``predictor(im_bgr) -> {"instances": Instances}``.
+    One engine is built per tile shape on first use (tilesets are single-shape: 256^2/512^2 z18 tiles,
+    R:config/config_obj_detec.yaml:45).  ``predict_batch`` is the batched form the CLI shim uses."""
+
+    def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], max_batch: int = 16, device: int = 0):
+        self.spec, self.weights, self.max_batch, self.device = spec, weights, max_batch, device
+        self._engines: Dict[Tuple[int, int, int], Engine] = {}
+
+    def _engine(self, shape: Tuple[int, int, int]) -> Engine:
+        if shape not in self._engines:
+            self._engines[shape] = Engine(self.spec, self.weights, shape, self.max_batch, self.device)
+        return self._engines[shape]
+
+    def __call__(self, original_image: np.ndarray) -> Dict[str, Instances]:
+        if original_image.ndim != 3:
+            raise ValueError("expected an HWC image")
+        eng = self._engine(tuple(original_image.shape))
+        return {"instances": eng.infer(original_image[None])[0]}
+
+    def predict_batch(self, images: Sequence[np.ndarray]) -> List[Dict[str, Instances]]:
+        out: List[Dict[str, Instances]] = []
+        i = 0
+        while i < len(images):
+            shape = tuple(images[i].shape)
+            j = i
+            while j < len(images) and j - i < self.max_batch and tuple(images[j].shape) == shape:
+                j += 1
+            res = self._engine(shape).infer(np.stack(images[i:j]))
+            out.extend({"instances": r} for r in res)
+            i = j
+        return out

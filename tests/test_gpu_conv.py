@@ -1,0 +1,193 @@
+"""GPU parity of the implicit-GEMM conv kernel (through the C ABI ``rs_op_conv2d``) against
+``torch.nn.functional`` fp32 on the same fp16-representable operands.  Tolerance: the kernel
+accumulates fp16 products in fp32 (MFMA) and rounds the result to fp16 once, so
+|err| <= 2^-10 * |ref| + accumulation noise; we assert max|err| <= 2e-3 * max(1, max|ref|)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from proj_roadsurf_amd.engine import load_library, _check
+from proj_roadsurf_amd.weights import _ohwi
+
+pytestmark = pytest.mark.gpu
+
+
+def _halo(x_nhwc: torch.Tensor, pad: int) -> torch.Tensor:
+    n, h, w, c = x_nhwc.shape
+    out = torch.zeros((n, h + 2 * pad, w + 2 * pad, c), dtype=x_nhwc.dtype)
+    out[:, pad:pad + h, pad:pad + w] = x_nhwc
+    return out
+
+
+def run_conv(x, w, b, *, stride=1, pad=0, relu=False, res=None, up=None, in_halo=None, out_halo=1, out_f32=False,
+             deconv=False, variant=-1, glds=1, cin_pad=None):
+    """x (N,C,H,W) fp32 (fp16-representable), w (Cout,Cin,kh,kw) fp32 -> (N,Cout,Ho,Wo) fp32 from the GPU."""
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    n, cin, hi, wi = x.shape
+    cout, _, kh, kw = w.shape
+    cin_p = cin_pad or cin
+    in_halo = pad if in_halo is None else in_halo
+    xn = torch.zeros((n, hi, wi, cin_p), dtype=torch.float16)
+    xn[..., :cin] = x.permute(0, 2, 3, 1).half()
+    xd = _halo(xn, in_halo).to(dev)
+    if deconv:
+        # w is ConvTranspose2d weight (Cin, Cout, 2, 2) -> rows (dy,dx,co) x ci
+        g = w.permute(2, 3, 1, 0).reshape(4 * w.shape[1], w.shape[0]).numpy()
+        wp = _ohwi(g[:, :, None, None], g.shape[1])
+        bias = np.tile(b.numpy().astype(np.float32), 4)
+        cout = w.shape[1]
+        kh = kw = 1
+    else:
+        wp = _ohwi(w.numpy().astype(np.float32), cin_p)
+        bias = b.numpy().astype(np.float32)
+    rows = wp.shape[0]
+    rows_pad = (rows + 15) // 16 * 16
+    if rows_pad != rows:
+        wp = np.concatenate([wp, np.zeros((rows_pad - rows, wp.shape[1]), np.float16)])
+        bias = np.concatenate([bias, np.zeros(rows_pad - rows, np.float32)])
+    cout_store = rows_pad if out_f32 else cout
+    wd = torch.from_numpy(wp).to(dev)
+    bd = torch.from_numpy(bias).to(dev)
+    ho = (hi + 2 * pad - kh) // stride + 1
+    wo = (wi + 2 * pad - kw) // stride + 1
+    oh, ow = (2 * ho, 2 * wo) if deconv else (ho, wo)
+    od = torch.zeros((n, oh + 2 * out_halo, ow + 2 * out_halo, cout_store), dtype=torch.float32 if out_f32 else torch.float16, device=dev)
+    rd = ud = None
+    if res is not None:
+        rd = _halo(res.permute(0, 2, 3, 1).half().contiguous(), out_halo).to(dev)
+    if up is not None:
+        ud = _halo(up.permute(0, 2, 3, 1).half().contiguous(), out_halo).to(dev)
+    torch.cuda.synchronize()
+    rc = lib.rs_op_conv2d(C.c_void_p(xd.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(od.data_ptr()),
+                          C.c_void_p(rd.data_ptr()) if rd is not None else None, C.c_void_p(ud.data_ptr()) if ud is not None else None,
+                          n, hi, wi, cin_p, in_halo, kh, kw, stride, pad, cout_store, wp.shape[1], out_halo, int(relu), int(out_f32),
+                          int(deconv), variant, glds, None)
+    _check(lib, rc, "rs_op_conv2d")
+    torch.cuda.synchronize()
+    o = od.cpu().float()
+    if out_halo:
+        # the halo must stay untouched (zero)
+        inner = o[:, out_halo:-out_halo, out_halo:-out_halo]
+        assert float(o.abs().sum()) == pytest.approx(float(inner.abs().sum()), rel=1e-6), "kernel wrote into the halo"
+        o = inner
+    return o[..., :cout].permute(0, 3, 1, 2).contiguous()
+
+
+def _r16(t):
+    return t.half().float()
+
+
+def _check_close(got, ref, tol=2e-3):
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"max err {err} > {tol * scale}"
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_conv3x3_256(gpu_required, glds, variant):
+    g = torch.Generator().manual_seed(0)
+    x = _r16(torch.randn(2, 256, 37, 41, generator=g))
+    w = _r16(torch.randn(256, 256, 3, 3, generator=g) * 0.03)
+    b = torch.randn(256, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, padding=1))
+    got = run_conv(x, w, b, pad=1, relu=True, variant=variant, glds=glds)
+    _check_close(got, ref)
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+def test_conv1x1_residual_relu(gpu_required, glds):
+    g = torch.Generator().manual_seed(1)
+    x = _r16(torch.randn(3, 64, 29, 31, generator=g))
+    w = _r16(torch.randn(256, 64, 1, 1, generator=g) * 0.1)
+    b = torch.randn(256, generator=g)
+    res = _r16(torch.randn(3, 256, 29, 31, generator=g))
+    ref = F.relu(F.conv2d(x, w, b) + res)
+    got = run_conv(x, w, b, res=res, relu=True, in_halo=1, glds=glds)
+    _check_close(got, ref)
+
+
+def test_conv1x1_to64_variant1(gpu_required):
+    g = torch.Generator().manual_seed(2)
+    x = _r16(torch.randn(2, 256, 50, 50, generator=g))
+    w = _r16(torch.randn(64, 256, 1, 1, generator=g) * 0.06)
+    b = torch.randn(64, generator=g)
+    ref = F.relu(F.conv2d(x, w, b))
+    got = run_conv(x, w, b, relu=True, in_halo=1)
+    _check_close(got, ref)
+
+
+def test_conv1x1_stride2(gpu_required):
+    g = torch.Generator().manual_seed(3)
+    x = _r16(torch.randn(2, 256, 40, 36, generator=g))
+    w = _r16(torch.randn(512, 256, 1, 1, generator=g) * 0.06)
+    b = torch.randn(512, generator=g)
+    ref = F.conv2d(x, w, b, stride=2)
+    got = run_conv(x, w, b, stride=2, in_halo=1)
+    _check_close(got, ref)
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+def test_stem_7x7_s2_cin3(gpu_required, glds):
+    g = torch.Generator().manual_seed(4)
+    x = _r16(torch.randn(2, 3, 64, 96, generator=g) * 50)
+    w = _r16(torch.randn(64, 3, 7, 7, generator=g) * 0.01)
+    b = torch.randn(64, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, stride=2, padding=3))
+    got = run_conv(x, w, b, stride=2, pad=3, relu=True, cin_pad=8, variant=1, glds=glds)
+    _check_close(got, ref)
+
+
+def test_fpn_lateral_upsample_add(gpu_required):
+    g = torch.Generator().manual_seed(5)
+    x = _r16(torch.randn(2, 512, 26, 30, generator=g))
+    w = _r16(torch.randn(256, 512, 1, 1, generator=g) * 0.04)
+    b = torch.randn(256, generator=g)
+    top = _r16(torch.randn(2, 256, 13, 15, generator=g))
+    ref = F.conv2d(x, w, b) + F.interpolate(top, scale_factor=2.0, mode="nearest")
+    got = run_conv(x, w, b, up=top, in_halo=1)
+    _check_close(got, ref)
+
+
+def test_small_head_fp32_out(gpu_required):
+    g = torch.Generator().manual_seed(6)
+    x = _r16(torch.randn(2, 256, 25, 27, generator=g))
+    w = _r16(torch.randn(15, 256, 1, 1, generator=g) * 0.06)
+    b = torch.randn(15, generator=g)
+    ref = F.conv2d(x, w, b)
+    got = run_conv(x, w, b, out_f32=True, out_halo=0, variant=2)
+    assert float((got - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_deconv2x2_pixel_shuffle(gpu_required):
+    g = torch.Generator().manual_seed(7)
+    x = _r16(torch.randn(5, 256, 14, 14, generator=g))
+    w = _r16(torch.randn(256, 256, 2, 2, generator=g) * 0.06)    # (Cin, Cout, 2, 2)
+    b = torch.randn(256, generator=g)
+    ref = F.relu(F.conv_transpose2d(x, w, b, stride=2))
+    got = run_conv(x, w, b, relu=True, deconv=True, in_halo=1, out_halo=0)
+    _check_close(got, ref)
+
+
+def test_fc_gemm(gpu_required):
+    g = torch.Generator().manual_seed(8)
+    m, k, nout = 333, 12544, 1024
+    a = _r16(torch.randn(m, k, generator=g))
+    w = _r16(torch.randn(nout, k, generator=g) * 0.01)
+    b = torch.randn(nout, generator=g)
+    ref = F.relu(F.linear(a, w, b))
+    x = a.t().reshape(1, k, 1, m).permute(0, 1, 3, 2).contiguous()     # (1, K, M, 1): "image" of M x 1 pixels
+    got = run_conv(x, w.view(nout, k, 1, 1), b, relu=True, out_halo=0)
+    got = got[0, :, :, 0].t()
+    _check_close(got, ref, tol=3e-3)
+
+
+def test_rejects_bad_shapes(gpu_required):
+    lib = load_library()
+    rc = lib.rs_op_conv2d(C.c_void_p(1), C.c_void_p(1), C.c_void_p(1), C.c_void_p(1), None, None,
+                          1, 8, 8, 48, 1, 3, 3, 1, 1, 64, 448, 1, 0, 0, 0, -1, 1, None)
+    assert rc != 0 and b"Cin" in lib.rs_last_error()

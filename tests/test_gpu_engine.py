@@ -1,0 +1,260 @@
+"""GPU parity of the whole engine, through the C ABI, against the CPU oracle.
+
+Two kinds of checks:
+
+* stage-wise: every stage of the forward is re-computed by the oracle FROM THE ENGINE'S OWN
+  INPUT to that stage (read back through ``rs_engine_tensor``), so discrete stages (top-k, NMS,
+  level assignment, thresholds) must agree exactly and float stages within the tolerance written
+  next to each assert;
+* end-to-end: oracle fp32 forward vs engine (fp16 operands / fp32 accumulate) on the same tiles
+  and weights, detections matched greedily by class + IoU.  Tolerance: >= 98 % of
+  reference detections with score >= 0.1 matched at box IoU >= 0.95 (both directions),
+  |dscore| <= 0.02, mask IoU >= 0.95 on the pasted masks.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from proj_roadsurf_amd.engine import Engine
+from proj_roadsurf_amd.spec import EngineSpec
+from proj_roadsurf_amd.weights import synthetic_weights
+from tests.util import match_detections, synthetic_tiles
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import maskrcnn_oracle as O
+    return O
+
+
+def _r16w(W):
+    """weights as the engine sees them (fp16-rounded), for stage tests of GEMM stages"""
+    return {k: torch.from_numpy(np.asarray(v)).half().float() for k, v in W.items()}
+
+
+@pytest.fixture(scope="module")
+def small(gpu_required):
+    """256x256 tiles resized to 320x320 (p2 80x80 ... p6 3x3), 300 proposals, batch 3."""
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(3, 256, 256, 3, seed=77)
+    eng = Engine(spec, W, (256, 256, 3), max_batch=4)
+    dets = eng.infer(tiles, want_probs=True)
+    yield spec, W, tiles, eng, dets
+    eng.close()
+
+
+def test_preprocess_bit_exact(small):
+    spec, W, tiles, eng, _ = small
+    O = _oracle()
+    x = eng.tensor("net_input", n=3)           # (3, 320, 320, 8) fp16
+    for i in range(3):
+        t, _ = O.predictor_preprocess(spec, tiles[i])
+        ref, _ = O.normalize_and_pad(spec, [t])
+        ref16 = ref[0].permute(1, 2, 0).half().numpy()
+        assert np.array_equal(x[i, :, :, :3], ref16), "resize + normalisation must be bit-exact with PIL + fp32 math"
+        assert not x[i, :, :, 3:].any()
+
+
+def test_backbone_features(small):
+    spec, W, tiles, eng, _ = small
+    O = _oracle()
+    m = O.OracleModel(spec, W)
+    x = torch.from_numpy(eng.tensor("net_input", n=3)[..., :3].astype(np.float32)).permute(0, 3, 1, 2)
+    feats = m.backbone(x)
+    # fp16 storage of every activation + fp16 weights: relative L2 error per map <= 1.5 %
+    for name in ["stem", "res2", "res3", "res4", "res5", "p2", "p3", "p4", "p5", "p6"]:
+        got = torch.from_numpy(eng.tensor(name, n=3).astype(np.float32)).permute(0, 3, 1, 2)
+        ref = feats[name]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        rel = float((got - ref).norm() / ref.norm())
+        assert rel <= 1.5e-2, f"{name}: rel L2 err {rel}"
+
+
+def test_rpn_stage_exact(small):
+    spec, W, tiles, eng, _ = small
+    O = _oracle()
+    A = spec.num_anchors
+    logits, deltas = [], []
+    for l in range(5):
+        h = torch.from_numpy(eng.tensor(f"rpn_head{l + 2}", n=3))          # (3,H,W,16) fp32
+        logits.append(h[..., :A].permute(0, 3, 1, 2).contiguous())
+        deltas.append(h[..., A:5 * A].permute(0, 3, 1, 2).contiguous())
+    nh, nw, _, _ = eng.net_shape()
+    ref = O.rpn_proposals(spec, logits, deltas, [(nh, nw)] * 3, nms_trick=False)
+    pb = eng.tensor("proposal_boxes", n=3)
+    pl = eng.tensor("proposal_logits", n=3)
+    pc = eng.tensor("proposal_count", n=3)
+    cidx = eng.tensor("rpn_cand_index", n=3)
+    ccount = eng.tensor("rpn_cand_count", n=3)
+    for i in range(3):
+        # top-k selection (index work): exact
+        off = 0
+        for l in range(5):
+            k = int(ccount[i, l])
+            want = ref[i]["pre_nms"]["anchor_idx"][off:off + k].numpy()
+            assert np.array_equal(cidx[i, l, :k], want), f"image {i} level {l}: top-k anchor set/order differs"
+            off += k
+        n = int(pc[i])
+        assert n == ref[i]["boxes"].shape[0], f"image {i}: {n} proposals vs {ref[i]['boxes'].shape[0]}"
+        # logits are copied, not computed: exact.  Boxes go through expf: 1e-3 px.
+        assert np.array_equal(pl[i, :n], ref[i]["logits"].numpy())
+        assert np.abs(pb[i, :n] - ref[i]["boxes"].numpy()).max() <= 1e-3
+
+
+def test_roi_align_box_stage(small):
+    spec, W, tiles, eng, _ = small
+    O = _oracle()
+    feats = [torch.from_numpy(eng.tensor(f"p{l}", n=3).astype(np.float32)).permute(0, 3, 1, 2) for l in (2, 3, 4, 5)]
+    pb = eng.tensor("proposal_boxes", n=3)
+    pc = eng.tensor("proposal_count", n=3)
+    lv = eng.tensor("box_roi_level", n=3)
+    pooled = eng.tensor("box_pooled", strip_halo=False)        # (4*1024, 7, 7, 256)
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    rng = np.random.default_rng(0)
+    for i in range(3):
+        n = int(pc[i])
+        boxes = torch.from_numpy(pb[i, :n])
+        ref_lv = O.assign_levels(boxes, 2, 5).numpy()
+        assert np.array_equal(lv[i, :n], ref_lv), "FPN level assignment must be exact"
+        for r in rng.choice(n, size=min(n, 40), replace=False):
+            ref = O.roi_align_one(feats[ref_lv[r]][i], boxes[r], 7, scales[ref_lv[r]])
+            got = torch.from_numpy(pooled[i * 1024 + r].astype(np.float32)).permute(2, 0, 1)
+            # fp32 math on identical fp16 features, one fp16 rounding of the result
+            assert float((got - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_box_head_stage(small):
+    spec, W, tiles, eng, _ = small
+    O = _oracle()
+    W16 = _r16w(W)
+    pc = eng.tensor("proposal_count", n=3)
+    pooled = eng.tensor("box_pooled", strip_halo=False)
+    pred = eng.tensor("box_pred", n=3)
+    K = spec.num_classes
+    for i in range(3):
+        n = int(pc[i])
+        x = torch.from_numpy(pooled[i * 1024:i * 1024 + n].astype(np.float32)).permute(0, 3, 1, 2)   # (n,256,7,7)
+        _, cls, reg = O.box_head(W16, x)
+        got = torch.from_numpy(pred[i, :n])
+        # two fp16-rounded hidden layers (1024 wide) in between: 1e-2 absolute on O(1) logits
+        assert float((got[:, :K + 1] - cls).abs().max()) <= 1e-2 * max(1.0, float(cls.abs().max()))
+        assert float((got[:, K + 1:5 * K + 1] - reg).abs().max()) <= 1e-2 * max(1.0, float(reg.abs().max()))
+
+
+def test_box_postprocess_stage_exact(small):
+    spec, W, tiles, eng, dets = small
+    O = _oracle()
+    K = spec.num_classes
+    nh, nw, _, _ = eng.net_shape()
+    pred = torch.from_numpy(eng.tensor("box_pred", n=3))
+    pb = torch.from_numpy(eng.tensor("proposal_boxes", n=3))
+    pc = eng.tensor("proposal_count", n=3)
+    dn = eng.tensor("det_boxes_net", n=3)
+    for i in range(3):
+        n = int(pc[i])
+        probs = F.softmax(pred[i, :n, :K + 1], dim=-1)
+        dec = O.apply_deltas(pred[i, :n, K + 1:5 * K + 1], pb[i, :n], spec.box_reg_weights, spec.scale_clamp)
+        ref = O.fast_rcnn_inference_single_image(spec, dec, probs, (nh, nw), nms_trick=False)
+        fin = O.detector_postprocess(ref, (nh, nw), 256, 256)
+        d = dets[i]
+        assert len(d) == fin["boxes"].shape[0], f"image {i}: {len(d)} detections vs {fin['boxes'].shape[0]}"
+        assert np.array_equal(d.pred_classes, fin["classes"].numpy())
+        assert np.abs(d.scores - fin["scores"].numpy()).max() <= 2e-6
+        assert np.abs(d.pred_boxes - fin["boxes"].numpy()).max() <= 1e-3
+        assert np.abs(dn[i, :len(d)] - ref["boxes"].numpy()[: len(d)]).max() <= 2e-3
+
+
+def test_mask_stage(small):
+    spec, W, tiles, eng, dets = small
+    O = _oracle()
+    W16 = _r16w(W)
+    total = int(eng.tensor("det_total")[0])
+    assert total == sum(len(d) for d in dets)
+    mp = eng.tensor("mask_pooled", strip_halo=True)[:total]                  # compact entries
+    x = torch.from_numpy(mp.astype(np.float32)).permute(0, 3, 1, 2)
+    classes = torch.from_numpy(np.concatenate([d.pred_classes for d in dets]))
+    _, probs = O.mask_head(spec, W16, x, classes)
+    got = np.concatenate([d.mask_probs for d in dets])
+    # 6 fp16-rounded layers before the sigmoid: 2e-2 absolute on probabilities
+    assert np.abs(got - probs[:, 0].numpy()).max() <= 2e-2
+    # paste: oracle grid_sample on the engine's own probabilities and boxes
+    for d in dets:
+        if len(d) == 0:
+            continue
+        ref = O.paste_masks(torch.from_numpy(d.mask_probs)[:, None], torch.from_numpy(d.pred_boxes), 256, 256, spec.mask_threshold).numpy()
+        gm = d.pred_masks
+        assert gm.shape == ref.shape
+        mism = np.logical_xor(gm, ref).sum()
+        assert mism <= 1e-4 * ref.size + 2, f"{mism} pasted-mask pixels differ"
+
+
+def test_mask_roi_align_stage(small):
+    spec, W, tiles, eng, dets = small
+    O = _oracle()
+    feats = [torch.from_numpy(eng.tensor(f"p{l}", n=3).astype(np.float32)).permute(0, 3, 1, 2) for l in (2, 3, 4, 5)]
+    dn = eng.tensor("det_boxes_net", n=3)
+    mp = eng.tensor("mask_pooled", strip_halo=True)
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    e = 0
+    for i, d in enumerate(dets):
+        boxes = torch.from_numpy(dn[i, :len(d)])
+        lv = O.assign_levels(boxes, 2, 5).numpy() if len(d) else []
+        for r in range(len(d)):
+            if r % 7 == 0:
+                ref = O.roi_align_one(feats[lv[r]][i], boxes[r], 14, scales[lv[r]])
+                got = torch.from_numpy(mp[e].astype(np.float32)).permute(2, 0, 1)
+                assert float((got - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
+            e += 1
+
+
+def test_end_to_end_small(small):
+    spec, W, tiles, eng, dets = small
+    O = _oracle()
+    m = O.OracleModel(spec, W)
+    ref = m([tiles[i] for i in range(3)])
+    for i in range(3):
+        r = {"boxes": ref[i]["boxes"].numpy(), "scores": ref[i]["scores"].numpy(), "classes": ref[i]["classes"].numpy(), "masks": ref[i]["masks"].numpy()}
+        g = {"boxes": dets[i].pred_boxes, "scores": dets[i].scores, "classes": dets[i].pred_classes, "masks": dets[i].pred_masks}
+        fw = match_detections(r, g)
+        bw = match_detections(g, r)
+        assert fw["frac_matched"] >= 0.98 and bw["frac_matched"] >= 0.98, (fw, bw)
+        assert fw["max_dscore"] <= 0.02 and fw["min_mask_iou"] >= 0.95, fw
+
+
+def test_batch_independence_and_determinism(small):
+    """Tiles are independent units: tile i alone == tile i inside a batch, and two runs agree bit for bit."""
+    spec, W, tiles, eng, dets = small
+    again = eng.infer(tiles, want_probs=True)
+    single = eng.infer(tiles[1:2], want_probs=True)[0]
+    for a, b in zip(dets, again):
+        assert np.array_equal(a.pred_boxes, b.pred_boxes) and np.array_equal(a.scores, b.scores)
+        assert np.array_equal(a._packed, b._packed)
+    assert np.array_equal(single.pred_boxes, dets[1].pred_boxes)
+    assert np.array_equal(single.scores, dets[1].scores)
+    assert np.array_equal(single._packed, dets[1]._packed)
+
+
+def test_full_size_512_tile(gpu_required):
+    """BASELINE config 1/2 geometry: 512x512x3 tile -> 800x800 network input, 1000 proposals, 100 detections."""
+    O = _oracle()
+    spec = EngineSpec(num_classes=2)
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 512, 512, 3, seed=1234)
+    eng = Engine(spec, W, (512, 512, 3), max_batch=2)
+    try:
+        assert eng.net_shape() == (800, 800, 800, 800)
+        dets = eng.infer(tiles)
+        m = O.OracleModel(spec, W)
+        ref = m([tiles[0]])
+        r = {"boxes": ref[0]["boxes"].numpy(), "scores": ref[0]["scores"].numpy(), "classes": ref[0]["classes"].numpy(), "masks": ref[0]["masks"].numpy()}
+        g = {"boxes": dets[0].pred_boxes, "scores": dets[0].scores, "classes": dets[0].pred_classes, "masks": dets[0].pred_masks}
+        fw = match_detections(r, g)
+        bw = match_detections(g, r)
+        assert fw["n_ref"] > 0
+        assert fw["frac_matched"] >= 0.98 and bw["frac_matched"] >= 0.98, (fw, bw)
+        assert fw["max_dscore"] <= 0.02 and fw["min_mask_iou"] >= 0.95, fw
+    finally:
+        eng.close()
