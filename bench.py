@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): tiles/sec of the Mask R-CNN R50-FPN forward on synthetic
+512x512 3-band tiles, batch 16 per GPU (BASELINE configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; tiles shard across ranks with no data-path collective (each rank runs its
+own batch -> "weak" scaling); torch.distributed (RCCL) is used only for the barrier and the
+max-over-ranks of the timed region.  A step = one pass of the whole hot path (resize+normalise,
+backbone, FPN, RPN, box head, NMS, mask head, mask paste) over one batch of 16 tiles that is
+already resident in HBM; results stay in HBM (PCIe-inclusive rate: DESIGN.md).
+
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the 128x128-tile implicit-GEMM
+conv, HIP-event timed on the engine's stream during the timed steps) and `cpu_baseline` (the
+oracle = CPU restatement of detectron2's path, on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(spec, W, tiles, max_seconds=30.0):
+    """Oracle (kind "port": our CPU restatement of detectron2 0.6's path) on the host cores."""
+    import torch
+    from oracle.maskrcnn_oracle import OracleModel
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("RS_CPU_BASELINE_THREADS", "16"))))   # a 1-GPU box's CPU share is 16
+    torch.set_num_threads(cores)
+    m = OracleModel(spec, W)
+    print(f"[bench] cpu_baseline: oracle on {cores} threads ...", file=sys.stderr, flush=True)
+    t0 = time.time()
+    n = 0
+    while n < len(tiles) and (n < 1 or (time.time() - t0) < max_seconds):
+        t1 = time.time()
+        m([tiles[n]])
+        n += 1
+        print(f"[bench] cpu_baseline: tile {n} took {time.time() - t1:.1f} s", file=sys.stderr, flush=True)
+        if time.time() - t0 > max_seconds * 0.7:
+            break
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 512x512x3 tile(s), batch 1 as DefaultPredictor does, torch CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--tile", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="print the per-stage table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from proj_roadsurf_amd.engine import Engine
+    from proj_roadsurf_amd.spec import EngineSpec
+    from proj_roadsurf_amd.weights import synthetic_weights
+    from tests.util import synthetic_tiles
+
+    spec = EngineSpec(num_classes=2)      # R:config/detectron2_config_3bands.yaml defaults, 2 classes (artificial/natural)
+    W = synthetic_weights(spec, seed=0)
+    B, T = args.batch, args.tile
+    # rank r owns tiles r*B .. r*B+B-1 of the synthetic tileset (seed = 1234 + tile id)
+    tiles = synthetic_tiles(B, T, T, 3, seed=1234 + rank * B)
+    eng = Engine(spec, W, (T, T, 3), max_batch=B, device=local_rank)
+    ptr = eng.upload_tiles(tiles)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.infer_device(ptr, B)
+    eng.sync()
+    eng.set_profiling(2)                 # HIP events around every launch, on the engine's stream, no host wait
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.infer_device(ptr, B)
+    eng.sync()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stages = eng.stage_times()
+    eng.set_profiling(0)
+    dets = eng.fetch(B)
+    nprop = eng.tensor("proposal_count", n=B)
+    ndet = [len(d) for d in dets]
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        # dominant kernel: conv_igemm 128x128 variant = every conv stage with Cout % 128 == 0
+        conv = [s for s in stages if s["flops"] > 0 and s["calls"] > 0]
+        by_time = sorted(stages, key=lambda s: -s["ms_total"])
+        tot_ms = sum(s["ms_total"] for s in stages)
+        # (res2 conv1/conv2 and the stem have Cout 64 -> 256x64 variant, the small heads the 256x16 one;
+        #  every other GEMM stage runs the 128x128 variant)
+        big = [s for s in conv if not (s["name"].startswith("res2.") and s["name"].endswith((".conv1", ".conv2")))
+               and not s["name"].startswith(("rpn.heads", "box.predictor", "stem.conv1"))]
+        fl = sum(s["flops"] * s["calls"] for s in big)
+        ms = sum(s["ms_total"] for s in big)
+        nlaunch = sum(s["calls"] for s in big)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        total_flops_step = sum(s["flops"] for s in conv)
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<2,2,4,4> (128x128 tile, fp16 MFMA 16x16x32)",
+                    "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                    "traffic": None, "launches": nlaunch, "avg_launch_ms": ms / max(nlaunch, 1),
+                    "flops_per_launch_avg": fl / max(nlaunch, 1), "share_of_step_time": ms / tot_ms if tot_ms else None,
+                    "whole_path_tflops": total_flops_step * args.steps * world / dt / 1e12}
+        if args.stages:
+            print(f"{'stage':28s} {'ms/call':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}", file=sys.stderr)
+            for s in stages:
+                if s["calls"]:
+                    mc = s["ms_total"] / s["calls"]
+                    print(f"{s['name']:28s} {mc:9.4f} {s['flops'] / mc / 1e9 if mc else 0:9.1f} {s['bytes'] / mc / 1e6 if mc else 0:9.1f}", file=sys.stderr)
+            print(f"sum of stage times {tot_ms / max(stages[0]['calls'], 1):.3f} ms/step; wall {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr)
+        out = {
+            "metric": "tiles_per_sec_512x512x3", "value": value, "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"Mask R-CNN R50-FPN inference, batch {B} of {T}x{T} 3-band tiles per GPU (BASELINE configs[1]), 800x800 network input",
+                       "batch_per_gpu": B, "tile": [T, T, 3], "num_classes": 2,
+                       "proposals_per_tile": float(np.mean(nprop)), "detections_per_tile": float(np.mean(ndet)),
+                       "sharding": "tiles across ranks, no data-path collective"},
+            "roofline": roofline,
+            "top_stages": [{"name": s["name"], "ms_per_step": s["ms_total"] / max(s["calls"], 1)} for s in by_time[:6]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, W, tiles)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

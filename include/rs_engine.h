@@ -104,8 +104,10 @@ int rs_engine_fetch(rs_engine* e, int n, rs_dets* out_host);
 /* Stream the engine launches on (hipStream_t), for event timing by the caller. */
 void* rs_engine_stream(rs_engine* e);
 
-/* Per-stage timing with HIP events on the engine's stream (serialises the host per stage). */
-int rs_engine_set_profiling(rs_engine* e, int enabled);
+/* Per-stage timing with HIP events on the engine's stream.  mode 0 = off; 1 = record + wait per
+ * stage (serialises the host, debugging); 2 = record only, events are read back when
+ * rs_engine_stage_info() is next called (up to 32 forwards' worth; extra forwards are not timed). */
+int rs_engine_set_profiling(rs_engine* e, int mode);
 int rs_engine_stage_count(rs_engine* e);
 /* name_out: >= 96 bytes.  ms_total / calls accumulate since the last rs_engine_set_profiling().
  * flops = algorithmic FLOPs of one call at the last batch size (0 for non-GEMM stages),

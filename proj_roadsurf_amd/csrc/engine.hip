@@ -118,8 +118,13 @@ struct rs_engine {
   int max_batch = 0, tile_h = 0, tile_w = 0, tile_c = 0;
   int net_h = 0, net_w = 0, pad_h = 0, pad_w = 0;
   int use_glds = 1;
-  bool profiling = false;
+  int profiling = 0;   // 0 off, 1 = events + host sync per stage, 2 = events only (resolved later)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // mode 2
+  std::vector<int> ev_stage;
+  std::vector<int> ev_batch;
+  size_t ev_used = 0;
+  int resolve_profile();
 
   void* blob_dev = nullptr;
   std::map<std::string, BlobEntry> blob;
@@ -705,11 +710,20 @@ int rs_engine::run(const uint8_t* tiles, int n) {
     // tiles already resident elsewhere on the device: stage them into the engine's input buffer
     RS_HIP(hipMemcpyAsync(tiles_dev, tiles, (size_t)n * tile_h * tile_w * tile_c, hipMemcpyDeviceToDevice, stream));
   }
-  for (Stage& st : stages) {
-    if (profiling) RS_HIP(hipEventRecord(ev0, stream));
+  for (size_t si = 0; si < stages.size(); ++si) {
+    Stage& st = stages[si];
+    const bool pooled = profiling == 2 && ev_used < ev_pool.size();
+    if (profiling == 1) RS_HIP(hipEventRecord(ev0, stream));
+    if (pooled) RS_HIP(hipEventRecord(ev_pool[ev_used].first, stream));
     int rc = st.fn(n, stream);
     if (rc) return rc;
-    if (profiling) {
+    if (pooled) {
+      RS_HIP(hipEventRecord(ev_pool[ev_used].second, stream));
+      ev_stage[ev_used] = (int)si;
+      ev_batch[ev_used] = n;
+      ++ev_used;
+    }
+    if (profiling == 1) {
       RS_HIP(hipEventRecord(ev1, stream));
       RS_HIP(hipEventSynchronize(ev1));
       float ms = 0.f;
@@ -720,6 +734,22 @@ int rs_engine::run(const uint8_t* tiles, int n) {
       st.last_bytes = st.bytes_per_image * n;
     }
   }
+  return RS_OK;
+}
+
+int rs_engine::resolve_profile() {
+  if (ev_used == 0) return RS_OK;
+  RS_HIP(hipStreamSynchronize(stream));
+  for (size_t i = 0; i < ev_used; ++i) {
+    float ms = 0.f;
+    RS_HIP(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
+    Stage& st = stages[ev_stage[i]];
+    st.ms_total += ms;
+    st.calls += 1;
+    st.last_flops = st.flops_per_image * ev_batch[i];
+    st.last_bytes = st.bytes_per_image * ev_batch[i];
+  }
+  ev_used = 0;
   return RS_OK;
 }
 
@@ -775,6 +805,7 @@ void rs_engine_destroy(rs_engine* e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   for (void* p : e->allocs) hipFree(p);
   if (e->blob_dev) hipFree(e->blob_dev);
+  for (auto& pr : e->ev_pool) { if (pr.first) hipEventDestroy(pr.first); if (pr.second) hipEventDestroy(pr.second); }
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -828,13 +859,26 @@ void* rs_engine_stream(rs_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int rs_engine_set_profiling(rs_engine* e, int enabled) {
   RS_CHECK(e, RS_ERR_ARG, "null engine");
-  e->profiling = enabled != 0;
+  RS_CHECK(enabled >= 0 && enabled <= 2, RS_ERR_ARG, "profiling mode %d", enabled);
+  e->ev_used = 0;
+  e->profiling = enabled;
   for (Stage& s : e->stages) { s.ms_total = 0; s.calls = 0; }
+  if (enabled == 2 && e->ev_pool.empty()) {
+    const size_t want = e->stages.size() * 32;   // 32 forwards' worth of event pairs
+    e->ev_pool.resize(want);
+    e->ev_stage.resize(want);
+    e->ev_batch.resize(want);
+    for (auto& pr : e->ev_pool) {
+      RS_HIP(hipEventCreate(&pr.first));
+      RS_HIP(hipEventCreate(&pr.second));
+    }
+  }
   return RS_OK;
 }
 int rs_engine_stage_count(rs_engine* e) { return e ? (int)e->stages.size() : 0; }
 int rs_engine_stage_info(rs_engine* e, int i, char* name_out, double* ms_total, int* calls, double* flops, double* bytes) {
   RS_CHECK(e && i >= 0 && i < (int)e->stages.size(), RS_ERR_ARG, "stage index");
+  if (e->ev_used) { int rc = e->resolve_profile(); if (rc) return rc; }
   const Stage& s = e->stages[i];
   if (name_out) { strncpy(name_out, s.name.c_str(), 95); name_out[95] = 0; }
   if (ms_total) *ms_total = s.ms_total;

@@ -310,8 +310,18 @@ class Engine:
             a = a[:, halo:-halo, halo:-halo]
         return a
 
-    def set_profiling(self, on: bool) -> None:
-        _check(self.lib, self.lib.rs_engine_set_profiling(self._h, int(on)), "rs_engine_set_profiling")
+    def set_profiling(self, mode: int) -> None:
+        """0 off, 1 per-stage events + host wait, 2 events only (read back by ``stage_times``)."""
+        _check(self.lib, self.lib.rs_engine_set_profiling(self._h, int(mode)), "rs_engine_set_profiling")
+
+    def upload_tiles(self, tiles: np.ndarray) -> int:
+        """Copy tiles into the engine's own device input buffer; returns its device pointer so that
+        ``infer_device`` can run on tiles already resident in HBM (no staging copy)."""
+        tiles = np.ascontiguousarray(tiles)
+        assert tiles.dtype == np.uint8 and tiles.shape[1:] == (self.tile_h, self.tile_w, self.tile_c) and tiles.shape[0] <= self.max_batch
+        ptr, _, _, _ = self.tensor_ptr("tiles")
+        _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(ptr), tiles.ctypes.data_as(C.c_void_p), tiles.nbytes), "rs_memcpy_h2d")
+        return ptr
 
     def stage_times(self) -> List[Dict[str, Any]]:
         out = []

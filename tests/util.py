@@ -47,13 +47,14 @@ def box_iou(a, b):
 def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
     """Greedy one-to-one matching (same class, box IoU >= thr) of reference detections with score >= min_score.
     ref/got: dicts with boxes (n,4), scores (n,), classes (n,), optional masks (n,H,W) bool.
-    Returns dict(frac_matched, max_dscore, min_mask_iou, n_ref)."""
+    Returns dict(frac_matched, max_dscore, min_mask_iou (masks >= 100 px), agg_mask_iou (sum inter / sum union), n_ref)."""
     rb, rs, rc = np.asarray(ref["boxes"]), np.asarray(ref["scores"]), np.asarray(ref["classes"])
     gb, gs, gc = np.asarray(got["boxes"]), np.asarray(got["scores"]), np.asarray(got["classes"])
     sel = np.where(rs >= min_score)[0]
     iou = box_iou(rb, gb)
     used = set()
     matched, dscore, miou = 0, 0.0, 1.0
+    inter_sum, union_sum = 0, 0
     for i in sel:
         cand = [(iou[i, j], j) for j in range(len(gb)) if j not in used and gc[j] == rc[i] and iou[i, j] >= iou_thr]
         if not cand:
@@ -65,7 +66,11 @@ def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
         if "masks" in ref and "masks" in got:
             a, b = np.asarray(ref["masks"][i], bool), np.asarray(got["masks"][j], bool)
             u = np.logical_or(a, b).sum()
-            if u > 0:
-                miou = min(miou, np.logical_and(a, b).sum() / u)
+            it = np.logical_and(a, b).sum()
+            inter_sum += it
+            union_sum += u
+            if u >= 100:     # a 1-pixel flip on a 3-pixel mask is not a meaningful IoU
+                miou = min(miou, it / u)
     n = len(sel)
-    return {"frac_matched": matched / n if n else 1.0, "max_dscore": dscore, "min_mask_iou": miou, "n_ref": n}
+    return {"frac_matched": matched / n if n else 1.0, "max_dscore": dscore, "min_mask_iou": miou, "n_ref": n,
+            "agg_mask_iou": (inter_sum / union_sum) if union_sum else 1.0}
