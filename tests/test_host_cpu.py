@@ -1,0 +1,147 @@
+"""CPU-side checks of the product's host code and of the C ABI surface (no GPU compute)."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import maskrcnn_oracle as O
+from proj_roadsurf_amd import weights as Wt
+from proj_roadsurf_amd.engine import LIB_PATH, RsSpec, cell_anchor_table, load_library, make_rs_spec
+from proj_roadsurf_amd.spec import EngineSpec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "rs_engine.h")).read()
+    names = set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 20
+    for n in sorted(names):
+        assert hasattr(lib, n), f"librs_engine.so does not export {n}"
+    assert lib.rs_abi_version() == 1
+
+
+def test_rs_spec_layout_matches_header(lib):
+    # the C side rejects a struct_size mismatch; here we at least pin the Python mirror's size
+    s = make_rs_spec(EngineSpec(num_classes=2))
+    assert s.struct_size == C.sizeof(RsSpec)
+    assert s.num_anchors == 3 and s.num_levels == 5 and s.flip_channels == 1
+    assert abs(s.pixel_mean[0] - 103.53) < 1e-5 and abs(s.scale_clamp - 4.1351666) < 1e-6
+
+
+def test_cell_anchor_table_equals_oracle():
+    spec = EngineSpec()
+    t = cell_anchor_table(spec)
+    for l in range(5):
+        assert np.array_equal(t[l], O.cell_anchors(spec.anchor_sizes[l], spec.anchor_aspect_ratios).numpy())
+
+
+def test_resize_shape_c_equals_python(lib):
+    from proj_roadsurf_amd.spec import resize_shortest_edge_shape
+    for h, w in [(512, 512), (1024, 1024), (256, 256), (600, 900), (480, 1000), (333, 777), (1000, 480)]:
+        a, b = C.c_int32(), C.c_int32()
+        lib.rs_resize_shape(h, w, 800, 1333, C.byref(a), C.byref(b))
+        assert (a.value, b.value) == resize_shortest_edge_shape(h, w, 800, 1333)
+
+
+@pytest.mark.parametrize("insz,outsz", [(512, 800), (256, 800), (1024, 800), (96, 128), (600, 800), (37, 91)])
+def test_resize_coeffs_c_equals_oracle(lib, insz, outsz):
+    ks = lib.rs_resize_coeffs(insz, outsz, None, None)
+    b = np.zeros((outsz, 2), np.int32)
+    k = np.zeros((outsz, ks), np.int32)
+    assert lib.rs_resize_coeffs(insz, outsz, b.ctypes.data_as(C.POINTER(C.c_int32)), k.ctypes.data_as(C.POINTER(C.c_int32))) == ks
+    ob, ok, oks = O._pil_bilinear_coeffs(insz, outsz)
+    assert oks == ks and np.array_equal(b, ob) and np.array_equal(k, ok)
+
+
+@pytest.mark.parametrize("shape,new", [((64, 48), (100, 75)), ((128, 128), (200, 200)), ((160, 200), (128, 160)), ((50, 50), (50, 80))])
+def test_restated_pil_resize_is_bit_exact(shape, new):
+    """The fixed-point 2-pass algorithm (what the HIP preprocess kernel runs) == Pillow, bit for bit,
+    for up-scaling and (antialiased) down-scaling."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    ref = O.pil_resize(img, new[0], new[1])
+    got = O.pil_resize_restated(img, new[0], new[1])
+    assert np.array_equal(ref, got)
+
+
+def test_conv_layer_list_and_param_count():
+    spec = EngineSpec(num_classes=2)
+    W = Wt.synthetic_weights(spec, 0)
+    layers = Wt.conv_layers(spec)
+    assert len([l for l in layers if "bottom_up" in l[0]]) == 53          # 53 backbone convs
+    n_params = sum(v.size for k, v in W.items() if "running" not in k and ".norm." not in k)
+    assert abs(n_params - 43.9e6) < 0.2e6                                  # SURVEY §8a parameter count (K=2)
+    # detectron2 key layout
+    for k in ["backbone.bottom_up.stem.conv1.weight", "backbone.bottom_up.res2.0.shortcut.norm.running_var", "backbone.fpn_lateral5.bias",
+              "proposal_generator.rpn_head.anchor_deltas.weight", "roi_heads.box_head.fc1.weight", "roi_heads.box_predictor.bbox_pred.bias",
+              "roi_heads.mask_head.deconv.weight", "roi_heads.mask_head.predictor.weight"]:
+        assert k in W
+
+
+def test_pack_weights_blob_roundtrip_and_bn_fold():
+    spec = EngineSpec(num_classes=2)
+    W = Wt.synthetic_weights(spec, 0)
+    T = Wt.engine_tensors(spec, W)
+    blob = Wt.serialize(T)
+    magic, ver, n, off = struct.unpack("<IIII", blob[:16])
+    assert magic == Wt.BLOB_MAGIC and ver == 1 and n == len(T) and off % 256 == 0
+    # parse back one entry
+    ent = 96 + 4 + 4 + 32 + 8 + 8
+    names = sorted(T)
+    i = names.index("backbone.bottom_up.res2.0.conv2.w")
+    e = blob[16 + ent * i: 16 + ent * (i + 1)]
+    name = e[:96].rstrip(b"\0").decode()
+    dt, nd, d0, d1, d2, d3, o, nb = struct.unpack("<II4QQQ", e[96:])
+    assert name == names[i] and dt == Wt.DT_F16 and (d0, d1) == (64, 576) and nb == 64 * 576 * 2 and o % 256 == 0
+    back = np.frombuffer(blob[o:o + nb], np.float16).reshape(64, 576)
+    # BN fold: w' = w * gamma / sqrt(var + eps), layout (Cout, kh, kw, cin)
+    p = "backbone.bottom_up.res2.0.conv2"
+    scale = W[p + ".norm.weight"] / np.sqrt(W[p + ".norm.running_var"] + np.float32(1e-5))
+    want = (W[p + ".weight"] * scale[:, None, None, None]).transpose(0, 2, 3, 1).reshape(64, 576).astype(np.float16)
+    assert np.array_equal(back, want)
+    bias = T[p + ".b"]
+    assert np.allclose(bias, W[p + ".norm.bias"] - W[p + ".norm.running_mean"] * scale)
+    # stem: Cin padded 3 -> 8, K padded to a multiple of 64
+    assert T["backbone.bottom_up.stem.conv1.w"].shape == (64, 448)
+    # fc1 K-axis permuted to (h, w, c)
+    fc1 = T["roi_heads.box_head.fc1.w"].astype(np.float32)
+    src = W["roi_heads.box_head.fc1.weight"].reshape(1024, 256, 7, 7)
+    assert np.allclose(fc1[5, (3 * 7 + 2) * 256 + 17], src[5, 17, 3, 2], atol=1e-3)
+    # fused heads padded to 16 rows
+    assert T["proposal_generator.rpn_head.heads.w"].shape == (16, 256)
+    assert T["roi_heads.box_predictor.w"].shape == (16, 1024)
+    assert T["roi_heads.mask_head.deconv.w"].shape == (1024, 256)
+
+
+def test_checkpoint_loader_refuses_pickle(tmp_path):
+    with pytest.raises(ValueError):
+        Wt.load_checkpoint(str(tmp_path / "model_final.pkl"))
+    import torch
+    W = {"roi_heads.box_predictor.cls_score.weight": torch.zeros(3, 1024)}
+    p = tmp_path / "m.pth"
+    torch.save({"model": W, "iteration": 5}, str(p))
+    back = Wt.load_checkpoint(str(p))
+    assert Wt.infer_num_classes(back) == 2
+
+
+def test_engine_fails_loudly_without_gpu(lib):
+    """No CPU fallback: on a box without a HIP device engine creation must error, not degrade."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from proj_roadsurf_amd.engine import Engine, RsError
+    spec = EngineSpec(num_classes=2)
+    with pytest.raises(RsError):
+        Engine(spec, Wt.synthetic_weights(spec, 0), (64, 64, 3), max_batch=1)
