@@ -118,6 +118,13 @@ def main():
         dt = float(tmax.item())
     stages = eng.stage_times()
     eng.set_profiling(0)
+    # PCIe-inclusive rate of the host-buffer entry point (H2D tiles + forward + D2H boxes/scores/masks);
+    # reported beside the headline, never as `value`
+    eng.infer(tiles)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        eng.infer(tiles)
+    pcie_tiles_per_s = 3 * B / (time.perf_counter() - t1)
     dets = eng.fetch(B)
     nprop = eng.tensor("proposal_count", n=B)
     ndet = [len(d) for d in dets]
@@ -137,9 +144,16 @@ def main():
         nlaunch = sum(s["calls"] for s in big)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         total_flops_step = sum(s["flops"] for s in conv)
+        alg_bytes = sum(s["bytes"] * s["calls"] for s in big) / max(nlaunch, 1)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")     # written by tools/pmc_summary.py from two --pmc passes
+        if os.path.exists(pmc) and B == 16 and T == 512:
+            for k in json.load(open(pmc)):
+                if "conv_igemm_kernel<2, 2, 4, 4, false, true>" in k["kernel"]:
+                    traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; (2*FETCH+WRITE)*1024)"
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<2,2,4,4> (128x128 tile, fp16 MFMA 16x16x32)",
                     "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                    "traffic": None, "launches": nlaunch, "avg_launch_ms": ms / max(nlaunch, 1),
+                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch_avg": alg_bytes, "launches": nlaunch, "avg_launch_ms": ms / max(nlaunch, 1),
                     "flops_per_launch_avg": fl / max(nlaunch, 1), "share_of_step_time": ms / tot_ms if tot_ms else None,
                     "whole_path_tflops": total_flops_step * args.steps * world / dt / 1e12}
         if args.stages:
@@ -158,6 +172,7 @@ def main():
                        "proposals_per_tile": float(np.mean(nprop)), "detections_per_tile": float(np.mean(ndet)),
                        "sharding": "tiles across ranks, no data-path collective"},
             "roofline": roofline,
+            "pcie_inclusive_tiles_per_s": pcie_tiles_per_s,
             "top_stages": [{"name": s["name"], "ms_per_step": s["ms_total"] / max(s["calls"], 1)} for s in by_time[:6]],
         }
         if world == 1 and not args.no_cpu_baseline:
