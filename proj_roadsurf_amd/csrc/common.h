@@ -63,6 +63,7 @@ struct ConvParams {
   int relu;
   int mode;             // 0 = conv, 1 = 2x2 stride-2 transposed conv as 4 GEMMs + pixel shuffle
   int out_f32;
+  int stages;           // LDS K-step buffers: 0/2 = double buffered, 1 = single (set by launch_conv for shallow K)
 };
 
 int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant /* -1 auto */, int use_glds);

@@ -14,6 +14,8 @@
 //     128-byte LDS rows, XOR swizzle applied on the per-lane SOURCE address and on the ds_read
 //     (LDS destination stays lane-linear), double buffered, one barrier per 64-deep K step.
 //   * activations carry a zero halo (common.h), so the gather has no bounds checks.
+// (A channel permutation that makes every 16-byte epilogue store part of a 64-byte run was tried and
+//  measured 5-13 % SLOWER on the HBM-bound 1x1 layers than the present 32-bytes-per-lane layout.)
 // Tile variants (pixels x channels per workgroup): 128x128 (4 waves 2x2), 256x64 (4 waves 4x1),
 // 256x16 fp32-out (small heads).  Each wave owns NJ*16 pixels x MI*16 channels.
 #include "common.h"
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   }
 
   const int nk = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> 6));
-  int* koff_s = (int*)(smem + 2 * T::STAGE);
+  const int nst = p.stages == 1 ? 1 : 2;   // LDS K-step buffers: 1 = shallow-K layers (more workgroups per CU)
+  int* koff_s = (int*)(smem + nst * T::STAGE);
   if constexpr (SMALLC) {
     for (int i = tid; i < (p.Kpad >> 3); i += T::NT) koff_s[i] = p.koff[i];
     __syncthreads();
@@ -170,8 +173,8 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   for (int t = 0; t < nk; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < nk) stage((t + 1) & 1, t + 1, SMALLC ? 0 : next_off());
-    const char* sb = smem + (t & 1) * T::STAGE;
+    if (nst == 2 && t + 1 < nk) stage((t + 1) & 1, t + 1, SMALLC ? 0 : next_off());
+    const char* sb = smem + (nst == 2 ? (t & 1) : 0) * T::STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int co = kk ? c1_off : c0_off;
@@ -185,6 +188,10 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (nst == 1 && t + 1 < nk) {
+      __syncthreads();                               // everyone done reading the only buffer
+      stage(0, t + 1, SMALLC ? 0 : next_off());
     }
   }
 
@@ -277,7 +284,8 @@ int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
     RS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS));
     done = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS, stream, p);
+  const int lds = (p.stages == 1 ? 1 : 2) * T::STAGE + 1024;
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), lds, stream, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
@@ -285,7 +293,17 @@ int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
 }  // namespace
 
 // variant: 0 = 128x128, 1 = 256x64, 2 = 256x16 (small heads), -1 = choose
-int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant, int use_glds) {
+int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, int use_glds) {
+  ConvParams p = p_in;
+  {
+    // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second
+    // LDS buffer; a single buffer halves the LDS footprint so 4 workgroups fit per CU and their
+    // loads/epilogues overlap each other instead.
+    static int nk_single = -1;
+    if (nk_single < 0) { const char* e = getenv("RS_CONV_SINGLE_STAGE_NK"); nk_single = e ? atoi(e) : 4; }
+    const int nk = p.Cin < 64 ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6);
+    if (p.stages == 0) p.stages = nk <= nk_single ? 1 : 2;
+  }
   RS_CHECK(p.M > 0, RS_ERR_ARG, "conv: M=%d", p.M);
   RS_CHECK(p.Kpad % 64 == 0, RS_ERR_ARG, "conv: Kpad %d not a multiple of 64", p.Kpad);
   const bool smallc = p.Cin < 64;

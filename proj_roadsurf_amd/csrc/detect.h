@@ -7,7 +7,7 @@
 
 struct RpnParams {
   const float* head[RS_MAX_LEVELS];   // [N][H][W][cs] fp32: channels [0,A) logits, [A,5A) deltas (a*4+d)
-  uint32_t* keys[RS_MAX_LEVELS];      // scratch [N][H*W*A]
+  uint32_t* keys[RS_MAX_LEVELS];      // scratch [N][2][H*W*A]: ordered keys, candidate indices
   int H[RS_MAX_LEVELS], W[RS_MAX_LEVELS], stride[RS_MAX_LEVELS];
   float base[RS_MAX_LEVELS][RS_MAX_ANCHORS][4];   // cell anchors (fp32 of the float64 formula)
   float offset;
@@ -29,6 +29,7 @@ struct NmsParams {
   uint8_t* keep;            // [S][cap]
   int cap;                  // 1024
   float thresh;
+  int debug;                // timing experiments only: 1 = skip the scan, 2 = skip the mask build
 };
 
 struct RpnMergeParams {

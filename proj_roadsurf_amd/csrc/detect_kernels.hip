@@ -80,18 +80,22 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
   __shared__ unsigned long long list[1024];
   __shared__ int hist[256];
-  __shared__ unsigned int sh_prefix, sh_need, sh_cnt, sh_idx_thr;
+  __shared__ unsigned int sh_prefix, sh_need, sh_cnt, sh_idx_thr, sh_ccount, sh_tie;
   const int l = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int H = p.H[l], W = p.W[l], A = p.A;
   const int HW = H * W;
   const int n_el = HW * A;
   const int k = n_el < p.topk ? n_el : p.topk;
   const float* head = p.head[l] + (long long)n * HW * p.cs;
-  uint32_t* keys = p.keys[l] + (long long)n * n_el;
+  uint32_t* keys = p.keys[l] + (long long)n * 2 * n_el;     // [n_el] ordered keys, then [n_el] candidate indices
+  uint32_t* cidx = keys + n_el;
 
-  // pass 0: ordered keys to scratch + histogram of the top digit
+  // Scan A: ordered keys to scratch + histogram of the top 8 bits.
   if (tid < 256) hist[tid] = 0;
+  if (tid == 0) { sh_prefix = 0; sh_need = (unsigned)k; sh_cnt = 0; sh_ccount = 0; sh_idx_thr = 0xFFFFFFFFu; }
+  list[tid] = 0ull;
   __syncthreads();
+  // (wave-aggregated histogram atomics were measured slower here than plain LDS atomics: 0.29 vs 0.24 ms)
   for (int e = tid; e < n_el; e += 1024) {
     const int pix = e / A, a = e - pix * A;
     const uint32_t key = fkey(head[(long long)pix * p.cs + a]);
@@ -99,38 +103,54 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     atomicAdd(&hist[key >> 24], 1);
   }
   __syncthreads();
-  if (tid == 0) { sh_prefix = 0; sh_need = (unsigned)k; }
+  auto pick_desc = [&](int shift) {     // thread 0: bin holding the need-th largest, walking from the top
+    unsigned need = sh_need, acc = 0;
+    int b = 255;
+    for (; b > 0; --b) {
+      if (acc + (unsigned)hist[b] >= need) break;
+      acc += (unsigned)hist[b];
+    }
+    sh_need = need - acc;              // still to take from bin b
+    sh_prefix |= ((unsigned)b) << shift;
+    sh_tie = (unsigned)hist[b];        // elements in bin b under the current prefix
+  };
+  if (tid == 0) pick_desc(24);
   __syncthreads();
-  for (int d = 0; d < 4; ++d) {
+  // Scan B: everything above the selected top-digit bin is in; the bin itself (typically ~10 % of the
+  // anchors) is compacted to a candidate list, so the remaining digit passes touch only candidates.
+  {
+    const uint32_t b0 = sh_prefix >> 24;
+    for (int e = tid; e < n_el; e += 1024) {
+      const uint32_t key = keys[e];
+      const uint32_t top = key >> 24;
+      if (top > b0) {
+        const unsigned pos = atomicAdd(&sh_cnt, 1u);
+        if (pos < 1024u) list[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e);
+      } else if (top == b0) {
+        const unsigned c = atomicAdd(&sh_ccount, 1u);
+        cidx[c] = (uint32_t)e;
+      }
+    }
+  }
+  __syncthreads();
+  const int nc = (int)sh_ccount;
+  for (int d = 1; d < 4; ++d) {
     const int shift = 24 - 8 * d;
-    if (d > 0) {
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
-      const uint32_t prefix = sh_prefix;
-      for (int e = tid; e < n_el; e += 1024) {
-        const uint32_t key = keys[e];
-        if ((key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1);
-      }
-      __syncthreads();
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = sh_prefix;
+    for (int ci = tid; ci < nc; ci += 1024) {
+      const uint32_t key = keys[cidx[ci]];
+      if ((key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1);
     }
-    if (tid == 0) {
-      unsigned need = sh_need, acc = 0;
-      int b = 255;
-      for (; b > 0; --b) {
-        if (acc + (unsigned)hist[b] >= need) break;
-        acc += (unsigned)hist[b];
-      }
-      sh_need = need - acc;            // still to take from bin b
-      sh_prefix |= ((unsigned)b) << shift;
-      sh_cnt = (unsigned)hist[b];      // elements in bin b under the current prefix
-    }
+    __syncthreads();
+    if (tid == 0) pick_desc(shift);
     __syncthreads();
   }
   const uint32_t T = sh_prefix;       // k-th largest key
   // ties on the threshold key: take the lowest anchor indices (radix select on the index)
-  if (tid == 0) sh_idx_thr = 0xFFFFFFFFu;
-  __syncthreads();
-  if (sh_cnt > sh_need) {              // uniform
+  if (sh_tie > sh_need) {              // uniform
+    __syncthreads();
     if (tid == 0) sh_prefix = 0;
     __syncthreads();
     for (int d = 0; d < 3; ++d) {
@@ -138,9 +158,10 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
       const uint32_t prefix = sh_prefix;
-      for (int e = tid; e < n_el; e += 1024) {
-        if (keys[e] == T && (d == 0 || ((uint32_t)e >> (shift + 8)) == (prefix >> (shift + 8))))
-          atomicAdd(&hist[((uint32_t)e >> shift) & 255], 1);
+      for (int ci = tid; ci < nc; ci += 1024) {
+        const uint32_t e = cidx[ci];
+        if (keys[e] == T && (d == 0 || (e >> (shift + 8)) == (prefix >> (shift + 8))))
+          atomicAdd(&hist[(e >> shift) & 255], 1);
       }
       __syncthreads();
       if (tid == 0) {
@@ -159,14 +180,12 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     __syncthreads();
   }
   const uint32_t idx_thr = sh_idx_thr;
-  if (tid == 0) sh_cnt = 0;
-  list[tid] = 0ull;
-  __syncthreads();
-  for (int e = tid; e < n_el; e += 1024) {
+  for (int ci = tid; ci < nc; ci += 1024) {
+    const uint32_t e = cidx[ci];
     const uint32_t key = keys[e];
-    if (key > T || (key == T && (uint32_t)e <= idx_thr)) {
+    if (key > T || (key == T && e <= idx_thr)) {
       const unsigned pos = atomicAdd(&sh_cnt, 1u);
-      if (pos < 1024u) list[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e);
+      if (pos < 1024u) list[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - e);
     }
   }
   __syncthreads();
@@ -225,37 +244,93 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
   }
   __syncthreads();
   const int nw = (n + 63) >> 6;
-  for (int idx = tid; idx < nw * n; idx += 1024) {
-    const int w = idx / n, i = idx - w * n;
+  // Row i needs words (i>>6) .. nw-1 only, a triangular amount of work.  Rows are paired (i, n-1-i)
+  // so that every task slot (row pair, word slot) carries the same load and all 16 waves stay busy.
+  const int nh = (n + 1) >> 1;
+  const int nhp = (nh + 63) & ~63;
+  for (int idx = tid; idx < (nw + 2) * nhp && p.debug != 2; idx += 1024) {
+    const int wq = idx / nhp, ip = idx - wq * nhp;
+    if (ip >= nh) continue;
+    const int first = nw - (ip >> 6);
+    int i, w;
+    if (wq < first) { i = ip; w = (ip >> 6) + wq; }
+    else {
+      i = n - 1 - ip;
+      w = (i >> 6) + (wq - first);
+      if (i == ip || w >= nw) continue;
+    }
     unsigned long long bits = 0ull;
     const int j0 = w * 64;
     if (j0 + 63 > i) {
       const float4 a = sbox[i];
       const float sa = sarea[i];
-      const int jend = (n - j0) < 64 ? (n - j0) : 64;
-      for (int b = 0; b < jend; ++b) {
-        const int j = j0 + b;
-        if (j <= i) continue;
+      const float thr = p.thresh;
+      // torchvision: suppress when fl(inter / (sa + sb - inter)) > thr.  The division is only needed when
+      // inter is within 1e-5 (relative) of thr * union; outside that band the comparison of the products
+      // decides identically (fp32 rounding is 6e-8), so the result stays bit-exact with the reference.
+      auto test = [&](int j) -> bool {
         const float4 q = sbox[j];
         const float iw = fmaxf(fminf(a.z, q.z) - fmaxf(a.x, q.x), 0.f);
         const float ih = fmaxf(fminf(a.w, q.w) - fmaxf(a.y, q.y), 0.f);
         const float inter = iw * ih;
-        const float iou = inter / (sa + sarea[j] - inter);
-        if (iou > p.thresh) bits |= 1ull << b;
+        if (!(inter > 0.f)) return false;           // 0/x = 0, 0/0 = NaN: never > thr
+        const float uni = sa + sarea[j] - inter;
+        const float tu = thr * uni;
+        if (inter > tu * 1.00001f) return true;
+        if (!(inter > tu * 0.99999f)) return false;
+        return (inter / uni) > thr;
+      };
+      unsigned lo = 0u, hi = 0u;
+      if (j0 > i && j0 + 64 <= n) {                 // word entirely right of the diagonal and inside n
+#pragma unroll 4
+        for (int b = 0; b < 32; ++b) if (test(j0 + b)) lo |= 1u << b;
+#pragma unroll 4
+        for (int b = 0; b < 32; ++b) if (test(j0 + 32 + b)) hi |= 1u << b;
+      } else {
+        for (int b = 0; b < 32; ++b) { const int j = j0 + b; if (j > i && j < n && test(j)) lo |= 1u << b; }
+        for (int b = 0; b < 32; ++b) { const int j = j0 + 32 + b; if (j > i && j < n && test(j)) hi |= 1u << b; }
       }
+      bits = ((unsigned long long)hi << 32) | lo;
     }
     mask[(long long)i * 16 + w] = bits;
   }
   __syncthreads();
-  if (tid < 64) {
+  // Greedy scan, one wave, 64 boxes (one mask word) per step: the intra-chunk part is resolved on
+  // the scalar unit from the diagonal words (lane b holds row b), then the rows of the survivors
+  // are OR-ed into the later words by all 64 lanes in parallel.
+  if (tid < 64 && p.debug != 1) {
     const int lane = tid;
-    unsigned long long removed = lane < 16 ? sremoved[lane] : 0ull;
-    for (int i = 0; i < n; ++i) {
-      const unsigned long long rw = __shfl(removed, i >> 6);
-      if (!((rw >> (i & 63)) & 1ull)) {
-        if (lane == 0) keep[i] = 1;
-        if (lane < nw) removed |= mask[(long long)i * 16 + lane];
+    unsigned long long removed = lane < 16 ? sremoved[lane] : 0ull;   // lane w holds word w
+    for (int c = 0; c < nw; ++c) {
+      const int base = c * 64;
+      const int cnt = (n - base) < 64 ? (n - base) : 64;
+      const unsigned long long rem_c = __shfl(removed, c);
+      const unsigned long long diag = lane < cnt ? mask[(long long)(base + lane) * 16 + c] : 0ull;
+      const int dlo = (int)(unsigned)(diag & 0xFFFFFFFFull), dhi = (int)(unsigned)(diag >> 32);
+      unsigned long long alive = ~rem_c;
+      if (cnt < 64) alive &= (1ull << cnt) - 1ull;
+      unsigned alo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive & 0xFFFFFFFFull));
+      unsigned ahi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive >> 32));
+      unsigned long long al = ((unsigned long long)ahi << 32) | alo;
+      unsigned long long kept = 0ull;
+      while (al) {
+        const int b = __builtin_ctzll(al);
+        kept |= 1ull << b;
+        const unsigned rlo = (unsigned)__builtin_amdgcn_readlane(dlo, b);
+        const unsigned rhi = (unsigned)__builtin_amdgcn_readlane(dhi, b);
+        al &= ~(((unsigned long long)rhi << 32) | rlo);
+        al &= ~(1ull << b);
       }
+      if (lane < cnt) keep[base + lane] = (uint8_t)((kept >> lane) & 1ull);
+      const int w = lane & 15;
+      unsigned long long part = 0ull;
+      if (w > c && w < nw) {
+        for (int b = lane >> 4; b < cnt; b += 4)
+          if ((kept >> b) & 1ull) part |= mask[(long long)(base + b) * 16 + w];
+      }
+      part |= __shfl_xor(part, 16);
+      part |= __shfl_xor(part, 32);
+      if (lane < 16) removed |= part;
     }
   }
 }
@@ -302,11 +377,20 @@ __global__ __launch_bounds__(1024) void rpn_merge_kernel(const RpnMergeParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// ROIAlign (aligned = true, adaptive sampling), C == 256, one workgroup (4 waves) per RoI
+// ROIAlign (aligned = true, adaptive sampling), C == 256, one workgroup per RoI.
+// Phase 1: the P*gh row samples and P*gw column samples of the RoI are computed ONCE (address
+// offset of the low/high neighbour + the two interpolation weights, zero weights for samples the
+// reference skips) into LDS.  Phase 2: each half-wave owns one bin at a time; a lane carries 8
+// consecutive channels (16-byte loads, 512 contiguous bytes per half-wave per neighbour), so the
+// per-sample VALU work is 4 weight products + 32 multiply/adds instead of the full coordinate
+// arithmetic.  Operation order of the accumulation follows torchvision's kernel exactly.
 // ---------------------------------------------------------------------------------------------
+#define RS_ROI_MAXS 512
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) {
+  __shared__ int s_lo[2][RS_ROI_MAXS], s_hi[2][RS_ROI_MAXS];     // [0] = y (row offsets), [1] = x (column offsets), in elements
+  __shared__ float s_l[2][RS_ROI_MAXS], s_h[2][RS_ROI_MAXS];
   const int entry = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   int n_entries = p.S;
   if (p.n_entries) { const int c = *p.n_entries; n_entries = c < n_entries ? c : n_entries; }
   if (entry >= n_entries) return;
@@ -314,13 +398,16 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   const int n = slot / p.slots_per_image;
   const int P = p.P, PP = P + 2 * p.out_pad;
   half_t* out = p.out + (long long)entry * PP * PP * 256;
+  const int hw = tid >> 5, l32 = tid & 31;       // half-wave id, lane inside it (8 channels each)
   bool valid = true;
   if (p.per_image_count) valid = (slot - n * p.slots_per_image) < p.per_image_count[n];
   if (!valid) {
-    for (int b = wave; b < P * P; b += 4) {
+    half8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (half_t)0.f;
+    for (int b = hw; b < P * P; b += 8) {
       const int ph = b / P, pw = b - ph * P;
-      half4 z; z[0] = z[1] = z[2] = z[3] = (half_t)0.f;
-      *(half4*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + lane * 4) = z;
+      *(half8*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) = z;
     }
     return;
   }
@@ -335,7 +422,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   if (p.out_level) { if (tid == 0) p.out_level[entry] = lvl; }
   const int H = p.H[lvl], W = p.W[lvl];
   const float sc = p.scale[lvl];
-  const half_t* feat = p.feat[lvl] + (long long)n * (H + 2) * (W + 2) * 256 + lane * 4;
+  const half_t* feat = p.feat[lvl] + (long long)n * (H + 2) * (W + 2) * 256 + l32 * 8;
   const float roi_start_w = x1 * sc - 0.5f;
   const float roi_start_h = y1 * sc - 0.5f;
   const float roi_end_w = x2 * sc - 0.5f;
@@ -344,42 +431,78 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   const float roi_h = roi_end_h - roi_start_h;
   const float bin_h = roi_h / (float)P;
   const float bin_w = roi_w / (float)P;
-  const int gh = (int)ceilf(roi_h / (float)P);
-  const int gw = (int)ceilf(roi_w / (float)P);
+  int gh = (int)ceilf(roi_h / (float)P);
+  int gw = (int)ceilf(roi_w / (float)P);
+  if (gh < 0) gh = 0;
+  if (gw < 0) gw = 0;
   const float count = (float)((gh * gw) > 1 ? (gh * gw) : 1);
-  for (int b = wave; b < P * P; b += 4) {
-    const int ph = b / P, pw = b - ph * P;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int iy = 0; iy < gh; ++iy) {
-      float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
-      const bool oob_y = (y < -1.0f || y > (float)H);
-      if (y <= 0.f) y = 0.f;
-      int y_low = (int)y, y_high;
-      if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
-      const float ly = y - (float)y_low, hy = 1.f - ly;
-      for (int ix = 0; ix < gw; ++ix) {
-        float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
-        if (oob_y || x < -1.0f || x > (float)W) continue;
-        if (x <= 0.f) x = 0.f;
-        int x_low = (int)x, x_high;
-        if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
-        const float lx = x - (float)x_low, hx = 1.f - lx;
-        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        const half4 v1 = *(const half4*)(feat + ((long long)(y_low + 1) * (W + 2) + x_low + 1) * 256);
-        const half4 v2 = *(const half4*)(feat + ((long long)(y_low + 1) * (W + 2) + x_high + 1) * 256);
-        const half4 v3 = *(const half4*)(feat + ((long long)(y_high + 1) * (W + 2) + x_low + 1) * 256);
-        const half4 v4 = *(const half4*)(feat + ((long long)(y_high + 1) * (W + 2) + x_high + 1) * 256);
+  const bool fast = (P * gh <= RS_ROI_MAXS) && (P * gw <= RS_ROI_MAXS);
+
+  // one sample coordinate -> (low offset, high offset, l, h); out-of-range samples get zero weights
+  auto prep = [&](float c, int size, int pitch, int& lo, int& hi, float& l, float& h) {
+    const bool oob = (c < -1.0f || c > (float)size);
+    if (c <= 0.f) c = 0.f;
+    int c_low = (int)c, c_high;
+    if (c_low >= size - 1) { c_high = c_low = size - 1; c = (float)c_low; } else { c_high = c_low + 1; }
+    l = c - (float)c_low;
+    h = 1.f - l;
+    if (oob) { l = 0.f; h = 0.f; c_low = 0; c_high = 0; }
+    lo = (c_low + 1) * pitch;
+    hi = (c_high + 1) * pitch;
+  };
+  if (fast) {
+    for (int t = tid; t < P * gh; t += 256) {
+      const int ph = t / gh, iy = t - ph * gh;
+      const float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+      prep(y, H, (W + 2) * 256, s_lo[0][t], s_hi[0][t], s_l[0][t], s_h[0][t]);
+    }
+    for (int t = tid; t < P * gw; t += 256) {
+      const int pw = t / gw, ix = t - pw * gw;
+      const float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+      prep(x, W, 256, s_lo[1][t], s_hi[1][t], s_l[1][t], s_h[1][t]);
+    }
+  }
+  __syncthreads();
+  for (int b0 = 0; b0 < P * P; b0 += 8) {
+    const int b = b0 + hw;
+    const bool live = b < P * P;
+    const int bb = live ? b : P * P - 1;
+    const int ph = bb / P, pw = bb - ph * P;
+    float acc[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      int ylo, yhi; float ly, hy;
+      if (fast) { const int t = ph * gh + iy; ylo = s_lo[0][t]; yhi = s_hi[0][t]; ly = s_l[0][t]; hy = s_h[0][t]; }
+      else {
+        const float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+        prep(y, H, (W + 2) * 256, ylo, yhi, ly, hy);
+      }
+      for (int ix = 0; ix < gw; ++ix) {
+        int xlo, xhi; float lx, hx;
+        if (fast) { const int t = pw * gw + ix; xlo = s_lo[1][t]; xhi = s_hi[1][t]; lx = s_l[1][t]; hx = s_h[1][t]; }
+        else {
+          const float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+          prep(x, W, 256, xlo, xhi, lx, hx);
+        }
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const half8 v1 = *(const half8*)(feat + ylo + xlo);
+        const half8 v2 = *(const half8*)(feat + ylo + xhi);
+        const half8 v3 = *(const half8*)(feat + yhi + xlo);
+        const half8 v4 = *(const half8*)(feat + yhi + xhi);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
           const float val = w1 * (float)v1[c] + w2 * (float)v2[c] + w3 * (float)v3[c] + w4 * (float)v4[c];
           acc[c] += val;
         }
       }
     }
-    half4 o;
+    if (live) {
+      half8 o;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = (half_t)(acc[c] / count);
-    *(half4*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + lane * 4) = o;
+      for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] / count);
+      *(half8*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) = o;
+    }
   }
 }
 
@@ -615,7 +738,9 @@ int launch_nms(const NmsParams& p, int segments, hipStream_t s) {
     done = true;
   }
   RS_CHECK(p.cap >= 1024 || p.cap > 0, RS_ERR_ARG, "nms: cap");
-  hipLaunchKernelGGL(nms_kernel, dim3(segments), dim3(1024), lds, s, p);
+  NmsParams q = p;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("RS_NMS_DEBUG"); dbg = e ? atoi(e) : 0; } q.debug = dbg; }
+  hipLaunchKernelGGL(nms_kernel, dim3(segments), dim3(1024), lds, s, q);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

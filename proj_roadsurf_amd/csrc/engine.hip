@@ -431,7 +431,7 @@ int rs_engine::build() {
     rp.head[l] = ho;
     rp.H[l] = P[l].H; rp.W[l] = P[l].W; rp.stride[l] = 4 << l;
     uint32_t* keys = nullptr;
-    if ((rc = alloc((void**)&keys, (size_t)NB * P[l].H * P[l].W * A * 4))) return rc;
+    if ((rc = alloc((void**)&keys, (size_t)NB * P[l].H * P[l].W * A * 4 * 2))) return rc;   // keys + candidate list
     rp.keys[l] = keys;
     for (int a = 0; a < A; ++a)
       for (int d = 0; d < 4; ++d) rp.base[l][a][d] = S.cell_anchors[l][a][d];

@@ -133,7 +133,7 @@ def synthetic_weights(spec: EngineSpec, seed: int = 0) -> Dict[str, np.ndarray]:
         # ConvTranspose2d weight is (Cin, Cout, 2, 2)
         W["roi_heads.mask_head.deconv.weight"] = (rng.standard_normal((d, d, 2, 2)) * (s2 / math.sqrt(d))).astype(np.float32)
         W["roi_heads.mask_head.deconv.bias"] = (rng.standard_normal(d) * 0.05).astype(np.float32)
-        W["roi_heads.mask_head.predictor.weight"] = (rng.standard_normal((K, d, 1, 1)) * (2.0 / math.sqrt(d))).astype(np.float32)
+        W["roi_heads.mask_head.predictor.weight"] = (rng.standard_normal((K, d, 1, 1)) * (6.0 / math.sqrt(d))).astype(np.float32)   # crisp masks: logits std ~4, like a trained head
         W["roi_heads.mask_head.predictor.bias"] = (rng.standard_normal(K) * 0.05).astype(np.float32)
     return W
 
