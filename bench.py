@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-stage table to stderr")
+    ap.add_argument("--profile-mode", type=int, default=3,
+                    help="HIP-event stage timing during the timed steps: 3 = every 4th step (default), 2 = every step, 0 = off")
     args = ap.parse_args()
 
     import torch
@@ -102,7 +104,7 @@ def main():
     for _ in range(args.warmup):
         eng.infer_device(ptr, B)
     eng.sync()
-    eng.set_profiling(2)                 # HIP events around every launch, on the engine's stream, no host wait
+    eng.set_profiling(args.profile_mode)   # HIP events around the launches, on the engine stream, no host wait
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

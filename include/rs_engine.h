@@ -106,7 +106,8 @@ void* rs_engine_stream(rs_engine* e);
 
 /* Per-stage timing with HIP events on the engine's stream.  mode 0 = off; 1 = record + wait per
  * stage (serialises the host, debugging); 2 = record only, events are read back when
- * rs_engine_stage_info() is next called (up to 32 forwards' worth; extra forwards are not timed). */
+ * rs_engine_stage_info() is next called (up to 32 forwards' worth; extra forwards are not timed);
+ * 3 = like 2 but only every 4th forward is bracketed (the others replay the captured hipGraph). */
 int rs_engine_set_profiling(rs_engine* e, int mode);
 int rs_engine_stage_count(rs_engine* e);
 /* name_out: >= 96 bytes.  ms_total / calls accumulate since the last rs_engine_set_profiling().

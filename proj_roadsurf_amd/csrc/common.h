@@ -61,8 +61,14 @@ struct ConvParams {
   int out_Hp, out_Wp, out_Cs, out_pad;
   int up_Hp, up_Wp, up_Cs, up_pad;
   int relu;
-  int mode;             // 0 = conv, 1 = 2x2 stride-2 transposed conv as 4 GEMMs + pixel shuffle
+  int mode;             // 0 = conv, 1 = 2x2 stride-2 transposed conv as 4 GEMMs + pixel shuffle,
+                        // 2 = mode 1 + fused mask predictor: out is not written, per output pixel the dot product
+                        //     of relu(deconv) with dot_w[class] is accumulated into dot_out (see conv_igemm.hip)
   int out_f32;
+  const float* dot_w;   // mode 2: [K][Cout] predictor weights (fp32)
+  const int* dot_cls;   // mode 2: [slots] predicted class
+  const int* dot_slot;  // mode 2: [entries] entry -> slot
+  float* dot_out;       // mode 2: [slots][2*Ho][2*Wo] logits (without bias), zeroed by the caller
   int stages;           // LDS K-step buffers: 0/2 = double buffered, 1 = single (set by launch_conv for shallow K)
 };
 

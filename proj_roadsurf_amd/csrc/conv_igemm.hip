@@ -58,7 +58,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of
   // logical tiles, channel tiles fastest, so the tiles that re-read one activation panel (other
   // channel tile, neighbouring rows of a 3x3) hit the same L2.
-  const int tiles_n = (p.Cout * (p.mode == 1 ? 4 : 1) + BN - 1) / BN;
+  const int tiles_n = (p.Cout * (p.mode != 0 ? 4 : 1) + BN - 1) / BN;
   const int nblk = gridDim.x;
   int L;
   {
@@ -170,6 +170,31 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     return off;
   };
   stage(0, 0, SMALLC ? 0 : next_off());
+
+  // Shallow-K (HBM-bound) layers: fetch the residual tile together with the operands, so the block
+  // pays one memory round trip instead of two (operands, then residual in the epilogue).
+  const int ch_local = wch * MI * 16 + fq * 4 * MI;
+  const int crow = n0 + ch_local;                 // row in the (possibly 4x grouped) weight matrix
+  int g = 0, cb = crow;
+  if (p.mode != 0) { g = crow / p.Cout; cb = crow % p.Cout; }
+  half4 rres[NJ][MI];
+  const bool pre = (nst == 1) && (p.res != nullptr);
+  if (pre) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      int m = m0 + wpx * NJ * 16 + j * 16 + fi;
+      if (m >= M) m = M - 1;
+      const int x = m % p.Wo;
+      const int t = m / p.Wo;
+      const int y = t % p.Ho;
+      const int n = t / p.Ho;
+      const long long opix = (long long)(n * p.out_Hp + y + p.out_pad) * p.out_Wp + x + p.out_pad;
+      const half_t* rp = p.res + opix * p.out_Cs + cb;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) rres[j][i] = *(const half4*)(rp + i * 4);
+    }
+  }
+
   for (int t = 0; t < nk; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -196,16 +221,16 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   }
 
   // ---- epilogue: lane holds channels cb .. cb+4*MI-1 of pixel (nj, fi) ------------------------
-  const int ch_local = wch * MI * 16 + fq * 4 * MI;
-  const int crow = n0 + ch_local;                 // row in the (possibly 4x grouped) weight matrix
-  int g = 0, cb = crow;
-  if (p.mode == 1) { g = crow / p.Cout; cb = crow % p.Cout; }
   float bias[4 * MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
     bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
   }
+  float dotp[NJ];
+  long long dot_idx[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { dotp[j] = 0.f; dot_idx[j] = -1; }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int m = m0 + wpx * NJ * 16 + j * 16 + fi;
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     const int y = t % p.Ho;
     const int n = t / p.Ho;
     int oy = y, ox = x;
-    if (p.mode == 1) { oy = 2 * y + (g >> 1); ox = 2 * x + (g & 1); }
+    if (p.mode != 0) { oy = 2 * y + (g >> 1); ox = 2 * x + (g & 1); }
     const long long opix = (long long)(n * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad;
     float v[4 * MI];
 #pragma unroll
@@ -226,7 +251,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       const half_t* rp = p.res + opix * p.out_Cs + cb;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const half4 h = *(const half4*)(rp + i * 4);
+        const half4 h = pre ? rres[j][i] : *(const half4*)(rp + i * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
       }
@@ -245,7 +270,20 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
 #pragma unroll
       for (int e = 0; e < 4 * MI; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
     }
-    if (p.out_f32) {
+    if (p.mode == 2) {
+      // fused mask predictor: partial dot product of this lane's 4*MI channels with the predicted class' weights
+      const int slot = p.dot_slot[n];
+      const float* wv = p.dot_w + (long long)p.dot_cls[slot] * p.Cout + cb;
+      float sdot = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const f32x4 w4 = *(const f32x4*)(wv + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sdot += v[i * 4 + r] * w4[r];
+      }
+      dotp[j] = sdot;
+      dot_idx[j] = (long long)slot * (4 * p.Ho * p.Wo) + (long long)oy * (2 * p.Wo) + ox;
+    } else if (p.out_f32) {
       float* op = (float*)p.out + opix * p.out_Cs + cb;
 #pragma unroll
       for (int i = 0; i < MI; ++i) *(f32x4*)(op + i * 4) = f32x4{v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
@@ -264,12 +302,38 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       }
     }
   }
+  if (p.mode == 2) {
+    // Reduce the per-lane partials to one value per output pixel in a FIXED order (bitwise reproducible):
+    // lanes of one pixel (k-slices fq = 0..3) by shuffles, the WCH channel waves through LDS; the two
+    // channel tiles of a (dy,dx) group live in different workgroups and meet in one float atomicAdd each
+    // on a zero-initialised word -- two addends commute exactly.
+    float* red = (float*)smem;      // [WCH-1][WPX][NJ][16]; the K-loop buffers are dead (all waves passed its last barrier)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float v0 = dotp[j];
+      v0 += __shfl_xor(v0, 16);
+      v0 += __shfl_xor(v0, 32);
+      dotp[j] = v0;
+      if (wch > 0 && fq == 0) red[(((wch - 1) * WPX + wpx) * NJ + j) * 16 + fi] = v0;
+    }
+    __syncthreads();
+    if (wch == 0 && fq == 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float v0 = dotp[j];
+#pragma unroll
+        for (int c = 1; c < WCH; ++c) v0 += red[(((c - 1) * WPX + wpx) * NJ + j) * 16 + fi];
+        if (dot_idx[j] >= 0) atomicAdd(p.dot_out + dot_idx[j], v0);
+      }
+    }
+  }
 }
 
 template <int WPX, int WCH, int MI, int NJ, bool SMALLC>
 int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
   using T = Tile<WPX, WCH, MI, NJ>;
-  const int rows = p.Cout * (p.mode == 1 ? 4 : 1);
+  const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   const int tiles_n = cdiv(rows, T::BN);
   const int tiles_m = cdiv(p.M, T::BM);
   const long long nblk = (long long)tiles_n * tiles_m;
@@ -313,10 +377,11 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     RS_CHECK(p.Cin % 64 == 0, RS_ERR_ARG, "conv: Cin %d not a multiple of 64", p.Cin);
     RS_CHECK(p.KH * p.KW * p.Cin <= p.Kpad, RS_ERR_ARG, "conv: K exceeds Kpad");
   }
-  const int rows = p.Cout * (p.mode == 1 ? 4 : 1);
+  const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   int v = force_variant;
   if (v < 0) v = rows <= 16 ? 2 : (rows % 128 == 0 ? 0 : 1);
-  RS_CHECK(!(p.mode == 1 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
+  RS_CHECK(!(p.mode != 0 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
+  RS_CHECK(!(p.mode == 2 && !(p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && v == 0)), RS_ERR_ARG, "fused mask predictor needs its pointers and the 128x128 tile");
   if (smallc) {
     RS_CHECK(v == 1, RS_ERR_ARG, "conv: small-Cin path is built for the 256x64 tile only (Cout=%d)", p.Cout);
     return launch_variant<4, 1, 4, 4, true>(p, stream, use_glds);

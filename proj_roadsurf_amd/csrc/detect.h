@@ -20,6 +20,7 @@ struct RpnParams {
   uint8_t* cand_valid;      // [N][L][1024]
   int* cand_count;          // [N][L]
   int* cand_index;          // optional [N][L][1024]: anchor index (y*W+x)*A+a
+  int debug;                // timing experiments only: stop after phase <debug>
 };
 
 struct NmsParams {
@@ -118,4 +119,5 @@ int launch_box_candidates(const BoxCandParams& p, int N, hipStream_t s);
 int launch_det_merge(const DetMergeParams& p, int N, hipStream_t s);
 int launch_det_compact(const int* det_count, int N, int D, int* slot_list, int* total, hipStream_t s);
 int launch_mask_predict(const MaskPredictParams& p, int capacity_entries, hipStream_t s);
+int launch_mask_sigmoid(const MaskPredictParams& p, int capacity_entries, hipStream_t s);
 int launch_paste_masks(const PasteParams& p, int capacity_entries, hipStream_t s);

@@ -140,8 +140,10 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     sh_prefix |= ((unsigned)b) << shift;
     sh_tie = (unsigned)hist[b];        // elements in bin b under the current prefix
   };
+  if (p.debug == 1) return;
   if (tid == 0) pick_desc(24);
   __syncthreads();
+  if (p.debug == 2) return;
   // Scan B: everything above the selected top-digit bin is in; the bin itself (typically ~10 % of the
   // anchors) is compacted to a candidate list, so the remaining digit passes touch only candidates.
   {
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     }
   }
   __syncthreads();
+  if (p.debug == 3) return;
   const int nc = (int)sh_ccount;
   for (int d = 1; d < 4; ++d) {
     const int shift = 24 - 8 * d;
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     if (tid == 0) pick_desc(shift);
     __syncthreads();
   }
+  if (p.debug == 4) return;
   const uint32_t T = sh_prefix;       // k-th largest key
   // ties on the threshold key: take the lowest anchor indices (radix select on the index)
   if (sh_tie > sh_need) {              // uniform
@@ -226,7 +230,9 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     }
   }
   __syncthreads();
+  if (p.debug == 5) return;
   bitonic_sort_desc<1024>(list, 1024, tid);
+  if (p.debug == 6) return;
 
   const long long ob = ((long long)n * p.L + l) * 1024;
   if (tid == 0) p.cand_count[n * p.L + l] = k;
@@ -711,6 +717,19 @@ __global__ __launch_bounds__(256) void mask_predict_kernel(const MaskPredictPara
   }
 }
 
+// logits accumulated by the fused deconv+predictor GEMM -> + class bias -> sigmoid, in place ([slots][S][S])
+__global__ __launch_bounds__(256) void mask_sigmoid_kernel(const MaskPredictParams p) {
+  const int total = *p.n_entries;
+  const int SS = p.S * p.S;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)total * SS) return;
+  const int entry = (int)(gid / SS);
+  const int slot = p.slot_list[entry];
+  float* o = p.out + (long long)slot * SS + (gid - (long long)entry * SS);
+  const float logit = *o + p.b[p.det_classes[slot]];
+  *o = 1.f / (1.f + expf(-logit));
+}
+
 // ---------------------------------------------------------------------------------------------
 // paste_masks_in_image: one thread = 8 horizontally adjacent output pixels = one output byte
 // ---------------------------------------------------------------------------------------------
@@ -762,7 +781,9 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
 // ----------------------------------------------------------------------------------------------- launchers
 int launch_rpn_select(const RpnParams& p, hipStream_t s) {
   RS_CHECK(p.topk <= 1024 && p.A <= RS_MAX_ANCHORS && p.L <= RS_MAX_LEVELS, RS_ERR_UNSUPPORTED, "rpn: topk %d / A %d / L %d out of range", p.topk, p.A, p.L);
-  hipLaunchKernelGGL(rpn_select_kernel, dim3(p.L, p.N), dim3(1024), 0, s, p);
+  RpnParams q = p;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("RS_SELECT_DEBUG"); dbg = e ? atoi(e) : 0; } q.debug = dbg; }
+  hipLaunchKernelGGL(rpn_select_kernel, dim3(p.L, p.N), dim3(1024), 0, s, q);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
@@ -832,6 +853,13 @@ int launch_det_compact(const int* det_count, int N, int D, int* slot_list, int* 
 int launch_mask_predict(const MaskPredictParams& p, int capacity_entries, hipStream_t s) {
   const long long npix = (long long)capacity_entries * p.S * p.S;
   hipLaunchKernelGGL(mask_predict_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_mask_sigmoid(const MaskPredictParams& p, int capacity_entries, hipStream_t s) {
+  const long long npix = (long long)capacity_entries * p.S * p.S;
+  hipLaunchKernelGGL(mask_sigmoid_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -177,6 +178,11 @@ struct rs_engine {
                int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile = 1,
                const int* m_count = nullptr);
   int run(const uint8_t* tiles, int n);
+  int run_stages(int n, bool record);
+  int use_graph = 0;
+  long long forward_index = 0;
+  std::set<int> warmed;
+  std::map<int, hipGraphExec_t> graphs;
 };
 
 int rs_engine::parse_blob(const void* data, size_t nbytes) {
@@ -649,34 +655,63 @@ int rs_engine::build() {
       if ((rc = add_conv("mask.fcn" + std::to_string(i + 1), "roi_heads.mask_head." + nm, curm, o, 3, 1, 1, true, nullptr, nullptr, 256, D, det_total))) return rc;
       curm = o;
     }
-    Act dec;
-    if ((rc = new_act(&dec, "mask_deconv", R, 2 * MR, 2 * MR, 256, 0))) return rc;
-    {
-      const BlobEntry* w = find("roi_heads.mask_head.deconv.w");
-      const BlobEntry* b = find("roi_heads.mask_head.deconv.b");
-      RS_CHECK(w && b && w->dims[0] == 1024, RS_ERR_BLOB, "deconv weights missing / wrong rows");
-      ConvParams p;
-      memset(&p, 0, sizeof p);
-      p.in = curm.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev; p.out = dec.p;
-      p.Ho = MR; p.Wo = MR; p.in_Hp = curm.Hp(); p.in_Wp = curm.Wp(); p.in_Cs = 256; p.in_off = 1; p.stride = 1; p.KH = p.KW = 1;
-      p.Cin = 256; p.Kpad = (int)w->dims[1]; p.Cout = 256; p.out_Hp = 2 * MR; p.out_Wp = 2 * MR; p.out_Cs = 256; p.out_pad = 0; p.relu = 1;
-      p.mode = 1; p.m_count = det_total; p.m_mul = MR * MR;
-      const int glds = use_glds, Dc = D, per_roi = MR * MR;
-      Stage st;
-      st.name = "mask.deconv";
-      st.flops_per_image = 2.0 * D * per_roi * 256 * 1024;
-      st.bytes_per_image = (double)D * per_roi * 256 * 2 * 5;
-      st.fn = [p, per_roi, Dc, glds](int n, hipStream_t s) mutable { p.M = n * Dc * per_roi; return launch_conv(p, s, -1, glds); };
-      stages.push_back(st);
-    }
     if ((rc = alloc((void**)&mask_probs, (size_t)R * RS_MASK_SIDE * RS_MASK_SIDE * 4))) return rc;
     reg("mask_probs", mask_probs, DT_F32, {NB, D, RS_MASK_SIDE, RS_MASK_SIDE}, 0);
-    {
-      const BlobEntry* w = find("roi_heads.mask_head.predictor.w");
-      const BlobEntry* b = find("roi_heads.mask_head.predictor.b");
-      RS_CHECK(w && b && w->dtype == DT_F32, RS_ERR_BLOB, "mask predictor weights missing");
+    const BlobEntry* dw = find("roi_heads.mask_head.deconv.w");
+    const BlobEntry* db = find("roi_heads.mask_head.deconv.b");
+    const BlobEntry* pw = find("roi_heads.mask_head.predictor.w");
+    const BlobEntry* pb = find("roi_heads.mask_head.predictor.b");
+    RS_CHECK(dw && db && dw->dims[0] == 1024, RS_ERR_BLOB, "deconv weights missing / wrong rows");
+    RS_CHECK(pw && pb && pw->dtype == DT_F32, RS_ERR_BLOB, "mask predictor weights missing");
+    const char* fe = getenv("RS_FUSE_MASK_PREDICTOR");
+    const bool fuse = fe ? atoi(fe) != 0 : true;
+    ConvParams dp;
+    memset(&dp, 0, sizeof dp);
+    dp.in = curm.p; dp.w = (const half_t*)dw->dev; dp.bias = (const float*)db->dev;
+    dp.Ho = MR; dp.Wo = MR; dp.in_Hp = curm.Hp(); dp.in_Wp = curm.Wp(); dp.in_Cs = 256; dp.in_off = 1; dp.stride = 1; dp.KH = dp.KW = 1;
+    dp.Cin = 256; dp.Kpad = (int)dw->dims[1]; dp.Cout = 256; dp.out_Hp = 2 * MR; dp.out_Wp = 2 * MR; dp.out_Cs = 256; dp.out_pad = 0; dp.relu = 1;
+    dp.m_count = det_total; dp.m_mul = MR * MR;
+    const int per_roi = MR * MR;
+    if (fuse) {
+      // deconv 2x2 s2 + ReLU + predictor 1x1 (predicted class only) in one launch: the 28x28x256 map (40 MB per
+      // tile) is never written; a small kernel then adds the class bias and applies the sigmoid in place.
+      dp.mode = 2; dp.out = nullptr;
+      dp.dot_w = (const float*)pw->dev; dp.dot_cls = det_classes; dp.dot_slot = slot_list; dp.dot_out = mask_probs;
+      const int glds = use_glds, Dc = D;
+      float* probs = mask_probs;
+      const size_t zero_per_tile = (size_t)D * RS_MASK_SIDE * RS_MASK_SIDE * 4;
+      Stage st;
+      st.name = "mask.deconv_predict";
+      st.flops_per_image = 2.0 * D * per_roi * 256 * 1024 + 2.0 * D * RS_MASK_SIDE * RS_MASK_SIDE * 256;
+      st.bytes_per_image = (double)D * per_roi * 256 * 2 + (double)D * RS_MASK_SIDE * RS_MASK_SIDE * 4;
+      st.fn = [dp, per_roi, Dc, glds, probs, zero_per_tile](int n, hipStream_t s) mutable {
+        RS_HIP(hipMemsetAsync(probs, 0, zero_per_tile * n, s));
+        dp.M = n * Dc * per_roi;
+        return launch_conv(dp, s, 0, glds);
+      };
+      stages.push_back(st);
       MaskPredictParams mp;
-      mp.in = dec.p; mp.w = (const float*)w->dev; mp.b = (const float*)b->dev; mp.slot_list = slot_list; mp.det_classes = det_classes;
+      mp.in = nullptr; mp.w = nullptr; mp.b = (const float*)pb->dev; mp.slot_list = slot_list; mp.det_classes = det_classes;
+      mp.n_entries = det_total; mp.out = mask_probs; mp.S = RS_MASK_SIDE;
+      Stage st2;
+      st2.name = "mask.bias_sigmoid";
+      st2.fn = [mp, Dc](int n, hipStream_t s) { return launch_mask_sigmoid(mp, n * Dc, s); };
+      stages.push_back(st2);
+    } else {
+      Act dec;
+      if ((rc = new_act(&dec, "mask_deconv", R, 2 * MR, 2 * MR, 256, 0))) return rc;
+      dp.mode = 1; dp.out = dec.p;
+      {
+        const int glds = use_glds, Dc = D;
+        Stage st;
+        st.name = "mask.deconv";
+        st.flops_per_image = 2.0 * D * per_roi * 256 * 1024;
+        st.bytes_per_image = (double)D * per_roi * 256 * 2 * 5;
+        st.fn = [dp, per_roi, Dc, glds](int n, hipStream_t s) mutable { dp.M = n * Dc * per_roi; return launch_conv(dp, s, -1, glds); };
+        stages.push_back(st);
+      }
+      MaskPredictParams mp;
+      mp.in = dec.p; mp.w = (const float*)pw->dev; mp.b = (const float*)pb->dev; mp.slot_list = slot_list; mp.det_classes = det_classes;
       mp.n_entries = det_total; mp.out = mask_probs; mp.S = RS_MASK_SIDE;
       Stage st;
       st.name = "mask.predict_sigmoid";
@@ -704,16 +739,11 @@ int rs_engine::build() {
   return RS_OK;
 }
 
-int rs_engine::run(const uint8_t* tiles, int n) {
-  RS_CHECK(n >= 1 && n <= max_batch, RS_ERR_ARG, "batch %d outside [1, %d]", n, max_batch);
-  if (tiles != tiles_dev) {
-    // tiles already resident elsewhere on the device: stage them into the engine's input buffer
-    RS_HIP(hipMemcpyAsync(tiles_dev, tiles, (size_t)n * tile_h * tile_w * tile_c, hipMemcpyDeviceToDevice, stream));
-  }
+int rs_engine::run_stages(int n, bool record) {
   for (size_t si = 0; si < stages.size(); ++si) {
     Stage& st = stages[si];
-    const bool pooled = profiling == 2 && ev_used < ev_pool.size();
-    if (profiling == 1) RS_HIP(hipEventRecord(ev0, stream));
+    const bool pooled = record && profiling >= 2 && ev_used < ev_pool.size();
+    if (record && profiling == 1) RS_HIP(hipEventRecord(ev0, stream));
     if (pooled) RS_HIP(hipEventRecord(ev_pool[ev_used].first, stream));
     int rc = st.fn(n, stream);
     if (rc) return rc;
@@ -723,7 +753,7 @@ int rs_engine::run(const uint8_t* tiles, int n) {
       ev_batch[ev_used] = n;
       ++ev_used;
     }
-    if (profiling == 1) {
+    if (record && profiling == 1) {
       RS_HIP(hipEventRecord(ev1, stream));
       RS_HIP(hipEventSynchronize(ev1));
       float ms = 0.f;
@@ -734,6 +764,40 @@ int rs_engine::run(const uint8_t* tiles, int n) {
       st.last_bytes = st.bytes_per_image * n;
     }
   }
+  return RS_OK;
+}
+
+// One forward.  The ~110 launches of a forward are replayed from a hipGraph (captured per batch size
+// after one eager warm-up run, which also performs the one-time hipFuncSetAttribute calls); forwards
+// that are being event-profiled run eagerly so every launch can be bracketed.
+int rs_engine::run(const uint8_t* tiles, int n) {
+  RS_CHECK(n >= 1 && n <= max_batch, RS_ERR_ARG, "batch %d outside [1, %d]", n, max_batch);
+  if (tiles != tiles_dev) {
+    // tiles already resident elsewhere on the device: stage them into the engine's input buffer
+    RS_HIP(hipMemcpyAsync(tiles_dev, tiles, (size_t)n * tile_h * tile_w * tile_c, hipMemcpyDeviceToDevice, stream));
+  }
+  const long long idx = forward_index++;
+  const bool record = profiling == 1 || profiling == 2 || (profiling == 3 && (idx & 3) == 0);
+  if (record || !use_graph || !warmed.count(n)) {
+    int rc = run_stages(n, record);
+    if (rc) return rc;
+    warmed.insert(n);
+    return RS_OK;
+  }
+  auto it = graphs.find(n);
+  if (it == graphs.end()) {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    RS_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_stages(n, false);
+    hipError_t he = hipStreamEndCapture(stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    RS_HIP(he);
+    RS_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    it = graphs.emplace(n, ge).first;
+  }
+  RS_HIP(hipGraphLaunch(it->second, stream));
   return RS_OK;
 }
 
@@ -784,6 +848,8 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   e->max_batch = max_batch; e->tile_h = tile_h; e->tile_w = tile_w; e->tile_c = tile_c;
   const char* g = getenv("RS_USE_GLDS");
   e->use_glds = g ? atoi(g) : 1;
+  const char* gg = getenv("RS_USE_GRAPH");
+  e->use_graph = gg ? atoi(gg) : 0;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
   else {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -805,6 +871,7 @@ void rs_engine_destroy(rs_engine* e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   for (void* p : e->allocs) hipFree(p);
   if (e->blob_dev) hipFree(e->blob_dev);
+  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
   for (auto& pr : e->ev_pool) { if (pr.first) hipEventDestroy(pr.first); if (pr.second) hipEventDestroy(pr.second); }
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -859,11 +926,13 @@ void* rs_engine_stream(rs_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int rs_engine_set_profiling(rs_engine* e, int enabled) {
   RS_CHECK(e, RS_ERR_ARG, "null engine");
-  RS_CHECK(enabled >= 0 && enabled <= 2, RS_ERR_ARG, "profiling mode %d", enabled);
+  RS_CHECK(enabled >= 0 && enabled <= 3, RS_ERR_ARG, "profiling mode %d", enabled);
+  if (e->ev_used) { int rc = e->resolve_profile(); if (rc) return rc; }
+  e->forward_index = 0;
   e->ev_used = 0;
   e->profiling = enabled;
   for (Stage& s : e->stages) { s.ms_total = 0; s.calls = 0; }
-  if (enabled == 2 && e->ev_pool.empty()) {
+  if (enabled >= 2 && e->ev_pool.empty()) {
     const size_t want = e->stages.size() * 32;   // 32 forwards' worth of event pairs
     e->ev_pool.resize(want);
     e->ev_stage.resize(want);
