@@ -171,35 +171,43 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   };
   stage(0, 0, SMALLC ? 0 : next_off());
 
-  // Shallow-K (HBM-bound) layers: fetch the residual tile together with the operands, so the block
-  // pays one memory round trip instead of two (operands, then residual in the epilogue).
+  // (Fetching the residual tile here, together with the operands, was tried for the shallow-K layers: no
+  //  gain -- those layers sit at ~3.3 TB/s regardless -- and it costs 32-64 VGPRs.)
   const int ch_local = wch * MI * 16 + fq * 4 * MI;
   const int crow = n0 + ch_local;                 // row in the (possibly 4x grouped) weight matrix
   int g = 0, cb = crow;
   if (p.mode != 0) { g = crow / p.Cout; cb = crow % p.Cout; }
-  half4 rres[NJ][MI];
-  const bool pre = (nst == 1) && (p.res != nullptr);
-  if (pre) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      int m = m0 + wpx * NJ * 16 + j * 16 + fi;
-      if (m >= M) m = M - 1;
-      const int x = m % p.Wo;
-      const int t = m / p.Wo;
-      const int y = t % p.Ho;
-      const int n = t / p.Ho;
-      const long long opix = (long long)(n * p.out_Hp + y + p.out_pad) * p.out_Wp + x + p.out_pad;
-      const half_t* rp = p.res + opix * p.out_Cs + cb;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) rres[j][i] = *(const half4*)(rp + i * 4);
-    }
-  }
 
+  // (256x256 tile: issuing the next step's LDS-DMA pieces between the MFMA groups with sched_group_barrier was
+  //  tried and measured 1-6 % slower than issuing them right after the barrier.)
   for (int t = 0; t < nk; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (nst == 2 && t + 1 < nk) stage((t + 1) & 1, t + 1, SMALLC ? 0 : next_off());
     const char* sb = smem + (nst == 2 ? (t & 1) : 0) * T::STAGE;
+    if constexpr (NJ == 8) {
+      // 8 waves in lockstep behind one barrier: all of them read fragments at the same time, so the second
+      // half-step's fragments are requested before the first half-step's MFMAs instead of after them.
+      half8 wf0[MI], xf0[NJ], wf1[MI], xf1[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) wf0[i] = *(const half8*)(sb + w_off[i] + c0_off);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xf0[j] = *(const half8*)(sb + x_off[j] + c0_off);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) wf1[i] = *(const half8*)(sb + w_off[i] + c1_off);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xf1[j] = *(const half8*)(sb + x_off[j] + c1_off);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+    } else
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int co = kk ? c1_off : c0_off;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       const half_t* rp = p.res + opix * p.out_Cs + cb;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const half4 h = pre ? rres[j][i] : *(const half4*)(rp + i * 4);
+        const half4 h = *(const half4*)(rp + i * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
       }
@@ -367,6 +375,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     if (nk_single < 0) { const char* e = getenv("RS_CONV_SINGLE_STAGE_NK"); nk_single = e ? atoi(e) : 4; }
     const int nk = p.Cin < 64 ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6);
     if (p.stages == 0) p.stages = nk <= nk_single ? 1 : 2;
+
   }
   RS_CHECK(p.M > 0, RS_ERR_ARG, "conv: M=%d", p.M);
   RS_CHECK(p.Kpad % 64 == 0, RS_ERR_ARG, "conv: Kpad %d not a multiple of 64", p.Kpad);
@@ -379,7 +388,18 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
   }
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   int v = force_variant;
-  if (v < 0) v = rows <= 16 ? 2 : (rows % 128 == 0 ? 0 : 1);
+  if (v < 0) {
+    v = rows <= 16 ? 2 : (rows % 128 == 0 ? 0 : 1);
+    // Deep-K GEMMs with many rows: a 256-wide workgroup tile halves the L2->LDS bytes per FLOP (the 128x128
+    // tile needs ~34 TB/s of L2 at full MFMA rate, which is the whole L2).  RS_CONV_BIG_TILE: 0 off, 3 = 256x128, 4 = 256x256.
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("RS_CONV_BIG_TILE"); big = e ? atoi(e) : 4; }
+    const int nk = smallc ? 0 : p.KH * p.KW * (p.Cin >> 6);
+    if (big && v == 0 && p.mode == 0 && nk >= 8 && p.M >= 16384) {
+      if (big == 4 && rows % 256 == 0) v = 4;
+      else v = 3;
+    }
+  }
   RS_CHECK(!(p.mode != 0 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
   RS_CHECK(!(p.mode == 2 && !(p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && v == 0)), RS_ERR_ARG, "fused mask predictor needs its pointers and the 128x128 tile");
   if (smallc) {
@@ -396,6 +416,12 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     case 2:
       RS_CHECK(rows % 16 == 0 && p.out_f32, RS_ERR_ARG, "conv: variant 2 is the 16-channel-tile fp32-out head kernel");
       return launch_variant<4, 1, 1, 4, false>(p, stream, use_glds);
+    case 3:
+      RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 3 needs Cout %% 128 == 0");
+      return launch_variant<4, 2, 4, 4, false>(p, stream, use_glds);
+    case 4:
+      RS_CHECK(rows % 256 == 0, RS_ERR_ARG, "conv: variant 4 needs Cout %% 256 == 0");
+      return launch_variant<2, 4, 4, 8, false>(p, stream, use_glds);
     default:
       rs_set_error("conv: unknown variant %d", v);
       return RS_ERR_ARG;
