@@ -67,6 +67,8 @@ typedef struct rs_spec {
   int32_t mask_conv_dim;          /* :215 */
   float mask_threshold;           /* detector_postprocess default 0.5 */
   float scale_clamp;              /* Box2BoxTransform: log(1000/16) */
+  int32_t precision;              /* 0 = production (fp16 operands, fp32 accumulate on MFMA); 1 = fp32 validation mode:
+                                     every conv/linear layer in plain fp32 (slow), needs "<layer>.w32" blob entries */
 } rs_spec;
 
 /* Caller-allocated result block for n tiles, D = detections_per_image slots per tile.

@@ -88,8 +88,12 @@ struct PreprocParams {
   int ksh, ksv;
   int need_h, need_v;
   int flip;               // 1: model channel c reads source channel C-1-c
+  int out_f32;            // fp32 validation mode: out is float
   float mean[4], stdv[4];
 };
 int launch_preprocess(const PreprocParams& p, hipStream_t s);
 int launch_maxpool(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
+int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
+int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
+int launch_conv_f32(const ConvParams& p, hipStream_t stream);

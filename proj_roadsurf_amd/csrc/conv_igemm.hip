@@ -366,6 +366,7 @@ int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
 
 // variant: 0 = 128x128, 1 = 256x64, 2 = 256x16 (small heads), -1 = choose
 int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, int use_glds) {
+  if (use_glds < 0) return launch_conv_f32(p_in, stream);   // fp32 validation mode (ref_f32.hip)
   ConvParams p = p_in;
   {
     // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second

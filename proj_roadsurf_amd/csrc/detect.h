@@ -59,6 +59,7 @@ struct RoiAlignParams {
   half_t* out;              // [entry][P+2*out_pad][P+2*out_pad][256]
   int P, out_pad;
   int* out_level;           // optional [entry]
+  int f32;                  // fp32 validation mode: features and output are float
 };
 
 struct BoxCandParams {
@@ -99,6 +100,7 @@ struct MaskPredictParams {
   const int* n_entries;
   float* out;               // [slots][S][S]
   int S;
+  int f32;                  // fp32 validation mode: `in` is float
 };
 
 struct PasteParams {

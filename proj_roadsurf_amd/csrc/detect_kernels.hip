@@ -440,17 +440,17 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   const int slot = p.slot_list ? p.slot_list[entry] : entry;
   const int n = slot / p.slots_per_image;
   const int P = p.P, PP = P + 2 * p.out_pad;
-  half_t* out = p.out + (long long)entry * PP * PP * 256;
+  const int es = p.f32 ? 4 : 2;                 // element size of features / output
+  char* out = (char*)p.out + (long long)entry * PP * PP * 256 * es;
   const int hw = tid >> 5, l32 = tid & 31;       // half-wave id, lane inside it (8 channels each)
   bool valid = true;
   if (p.per_image_count) valid = (slot - n * p.slots_per_image) < p.per_image_count[n];
   if (!valid) {
-    half8 z;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = (half_t)0.f;
     for (int b = hw; b < P * P; b += 8) {
       const int ph = b / P, pw = b - ph * P;
-      *(half8*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) = z;
+      char* o = out + (((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) * es;
+      if (p.f32) { ((f32x4*)o)[0] = f32x4{0.f, 0.f, 0.f, 0.f}; ((f32x4*)o)[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      else { half8 z; for (int i = 0; i < 8; ++i) z[i] = (half_t)0.f; *(half8*)o = z; }
     }
     return;
   }
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   if (p.out_level) { if (tid == 0) p.out_level[entry] = lvl; }
   const int H = p.H[lvl], W = p.W[lvl];
   const float sc = p.scale[lvl];
-  const half_t* feat = p.feat[lvl] + (long long)n * (H + 2) * (W + 2) * 256 + l32 * 8;
+  const char* feat = (const char*)p.feat[lvl] + ((long long)n * (H + 2) * (W + 2) * 256 + l32 * 8) * es;
   const float roi_start_w = x1 * sc - 0.5f;
   const float roi_start_h = y1 * sc - 0.5f;
   const float roi_end_w = x2 * sc - 0.5f;
@@ -529,22 +529,40 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
           prep(x, W, 256, xlo, xhi, lx, hx);
         }
         const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        const half8 v1 = *(const half8*)(feat + ylo + xlo);
-        const half8 v2 = *(const half8*)(feat + ylo + xhi);
-        const half8 v3 = *(const half8*)(feat + yhi + xlo);
-        const half8 v4 = *(const half8*)(feat + yhi + xhi);
+        float f1[8], f2[8], f3[8], f4[8];
+        if (p.f32) {
+          const f32x4* q1 = (const f32x4*)(feat + (long long)(ylo + xlo) * 4);
+          const f32x4* q2 = (const f32x4*)(feat + (long long)(ylo + xhi) * 4);
+          const f32x4* q3 = (const f32x4*)(feat + (long long)(yhi + xlo) * 4);
+          const f32x4* q4 = (const f32x4*)(feat + (long long)(yhi + xhi) * 4);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) { f1[c] = q1[c >> 2][c & 3]; f2[c] = q2[c >> 2][c & 3]; f3[c] = q3[c >> 2][c & 3]; f4[c] = q4[c >> 2][c & 3]; }
+        } else {
+          const half8 v1 = *(const half8*)(feat + (long long)(ylo + xlo) * 2);
+          const half8 v2 = *(const half8*)(feat + (long long)(ylo + xhi) * 2);
+          const half8 v3 = *(const half8*)(feat + (long long)(yhi + xlo) * 2);
+          const half8 v4 = *(const half8*)(feat + (long long)(yhi + xhi) * 2);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) { f1[c] = (float)v1[c]; f2[c] = (float)v2[c]; f3[c] = (float)v3[c]; f4[c] = (float)v4[c]; }
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const float val = w1 * (float)v1[c] + w2 * (float)v2[c] + w3 * (float)v3[c] + w4 * (float)v4[c];
+          const float val = w1 * f1[c] + w2 * f2[c] + w3 * f3[c] + w4 * f4[c];
           acc[c] += val;
         }
       }
     }
     if (live) {
-      half8 o;
+      char* op = out + (((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) * es;
+      if (p.f32) {
+        ((f32x4*)op)[0] = f32x4{acc[0] / count, acc[1] / count, acc[2] / count, acc[3] / count};
+        ((f32x4*)op)[1] = f32x4{acc[4] / count, acc[5] / count, acc[6] / count, acc[7] / count};
+      } else {
+        half8 o;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] / count);
-      *(half8*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) = o;
+        for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] / count);
+        *(half8*)op = o;
+      }
     }
   }
 }
@@ -698,14 +716,21 @@ __global__ __launch_bounds__(256) void mask_predict_kernel(const MaskPredictPara
   const int entry = (int)(pix / SS);
   const int slot = p.slot_list[entry];
   const int cls = p.det_classes[slot];
-  const half_t* x = p.in + pix * 256 + sub * 16;
   const float* w = p.w + (long long)cls * 256 + sub * 16;
-  const half8 a = *(const half8*)x, b = *(const half8*)(x + 8);
+  float xv[16];
+  if (p.f32) {
+    const float* x = (const float*)p.in + pix * 256 + sub * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xv[i] = x[i];
+  } else {
+    const half_t* x = p.in + pix * 256 + sub * 16;
+    const half8 a = *(const half8*)x, b = *(const half8*)(x + 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xv[i] = (float)a[i]; xv[8 + i] = (float)b[i]; }
+  }
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += (float)a[i] * w[i];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += (float)b[i] * w[8 + i];
+  for (int i = 0; i < 16; ++i) s += xv[i] * w[i];
   s += __shfl_xor(s, 8, 16);
   s += __shfl_xor(s, 4, 16);
   s += __shfl_xor(s, 2, 16);

@@ -118,7 +118,8 @@ struct rs_engine {
   bool own_stream = false;
   int max_batch = 0, tile_h = 0, tile_w = 0, tile_c = 0;
   int net_h = 0, net_w = 0, pad_h = 0, pad_w = 0;
-  int use_glds = 1;
+  int use_glds = 1;    // -1 = fp32 validation path (launch_conv forwards to launch_conv_f32)
+  bool f32 = false;    // rs_spec.precision == 1: activations and weights are float
   int profiling = 0;   // 0 off, 1 = events + host sync per stage, 2 = events only (resolved later)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // mode 2
@@ -162,16 +163,18 @@ struct rs_engine {
   }
   int new_act(Act* a, const std::string& name, int N, int H, int W, int C, int pad) {
     a->N = N; a->H = H; a->W = W; a->C = C; a->pad = pad;
-    const size_t bytes = (size_t)N * a->Hp() * a->Wp() * C * 2;
+    const size_t bytes = (size_t)N * a->Hp() * a->Wp() * C * (f32 ? 4 : 2);
     int rc = alloc((void**)&a->p, bytes);
     if (rc) return rc;
-    reg(name, a->p, DT_F16, {N, a->Hp(), a->Wp(), C}, pad);
+    reg(name, a->p, f32 ? DT_F32 : DT_F16, {N, a->Hp(), a->Wp(), C}, pad);
     return RS_OK;
   }
   const BlobEntry* find(const std::string& n) {
     auto it = blob.find(n);
     return it == blob.end() ? nullptr : &it->second;
   }
+  // GEMM weights of a layer: "<layer>.w" (fp16) or "<layer>.w32" in the fp32 validation mode
+  const BlobEntry* findw(const std::string& layer) { return find(layer + (f32 ? ".w32" : ".w")); }
   int parse_blob(const void* data, size_t nbytes);
   int build();
   int add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k, int stride,
@@ -226,10 +229,10 @@ int rs_engine::parse_blob(const void* data, size_t nbytes) {
 int rs_engine::add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k,
                         int stride, int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile,
                         const int* m_count) {
-  const BlobEntry* w = find(wname + ".w");
+  const BlobEntry* w = findw(wname);
   const BlobEntry* b = find(wname + ".b");
   RS_CHECK(w && b, RS_ERR_BLOB, "weights for %s missing from blob", wname.c_str());
-  RS_CHECK(w->dtype == DT_F16 && b->dtype == DT_F32, RS_ERR_BLOB, "weights for %s have wrong dtype", wname.c_str());
+  RS_CHECK(w->dtype == (f32 ? DT_F32 : DT_F16) && b->dtype == DT_F32, RS_ERR_BLOB, "weights for %s have wrong dtype", wname.c_str());
   ConvParams p;
   memset(&p, 0, sizeof p);
   p.in = in.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev; p.out = out.p;
@@ -318,7 +321,7 @@ int rs_engine::build() {
   Act x0;
   if ((rc = new_act(&x0, "net_input", NB, pad_h, pad_w, 8, 3))) return rc;
   pp.out = x0.p; pp.H = tile_h; pp.W = tile_w; pp.C = tile_c; pp.new_h = net_h; pp.new_w = net_w;
-  pp.out_Hp = x0.Hp(); pp.out_Wp = x0.Wp(); pp.flip = S.flip_channels;
+  pp.out_Hp = x0.Hp(); pp.out_Wp = x0.Wp(); pp.flip = S.flip_channels; pp.out_f32 = f32 ? 1 : 0;
   for (int c = 0; c < 4; ++c) { pp.mean[c] = S.pixel_mean[c]; pp.stdv[c] = S.pixel_std[c] == 0.f ? 1.f : S.pixel_std[c]; }
   {
     Stage st;
@@ -343,7 +346,11 @@ int rs_engine::build() {
     Stage st;
     st.name = "stem.maxpool";
     st.bytes_per_image = 2.0 * ((double)h2 * w2 + (double)h4 * w4) * S.stem_out_channels;
-    st.fn = [stem, c1](int n, hipStream_t s) { return launch_maxpool(stem.p, c1.p, n, stem.H, stem.W, c1.H, c1.W, c1.C, s); };
+    const bool f = f32;
+    st.fn = [stem, c1, f](int n, hipStream_t s) {
+      return f ? launch_maxpool_f32((const float*)stem.p, (float*)c1.p, n, stem.H, stem.W, c1.H, c1.W, c1.C, s)
+               : launch_maxpool(stem.p, c1.p, n, stem.H, stem.W, c1.H, c1.W, c1.C, s);
+    };
     stages.push_back(st);
   }
 
@@ -396,7 +403,11 @@ int rs_engine::build() {
     Stage st;
     st.name = "fpn.p6";
     Act a = P[3], b = P[4];
-    st.fn = [a, b](int n, hipStream_t s) { return launch_subsample2(a.p, b.p, n, a.H, a.W, b.H, b.W, 256, s); };
+    const bool f = f32;
+    st.fn = [a, b, f](int n, hipStream_t s) {
+      return f ? launch_subsample2_f32((const float*)a.p, (float*)b.p, n, a.H, a.W, b.H, b.W, 256, s)
+               : launch_subsample2(a.p, b.p, n, a.H, a.W, b.H, b.W, 256, s);
+    };
     stages.push_back(st);
   }
 
@@ -415,7 +426,7 @@ int rs_engine::build() {
     reg("rpn_head" + ln, ho, DT_F32, {NB, P[l].H, P[l].W, head_cs}, 0);
     // 1x1 heads (objectness + deltas fused), fp32 out
     {
-      const BlobEntry* w = find("proposal_generator.rpn_head.heads.w");
+      const BlobEntry* w = findw("proposal_generator.rpn_head.heads");
       const BlobEntry* b = find("proposal_generator.rpn_head.heads.b");
       RS_CHECK(w && b, RS_ERR_BLOB, "rpn head weights missing");
       RS_CHECK((int)w->dims[0] == head_cs, RS_ERR_BLOB, "rpn head rows %lld != %d", (long long)w->dims[0], head_cs);
@@ -502,7 +513,7 @@ int rs_engine::build() {
   RoiAlignParams ra;
   memset(&ra, 0, sizeof ra);
   for (int l = 0; l < 4; ++l) { ra.feat[l] = P[l].p; ra.H[l] = P[l].H; ra.W[l] = P[l].W; ra.scale[l] = 1.0f / (float)(4 << l); }
-  ra.nlevels = 4; ra.C = 256;
+  ra.nlevels = 4; ra.C = 256; ra.f32 = f32 ? 1 : 0;
   Act boxfeat;   // [NB*PC] "images" of PR x PR x 256
   if ((rc = new_act(&boxfeat, "box_pooled", NB * PC, PR, PR, 256, 0))) return rc;
   int* box_level = nullptr;
@@ -525,7 +536,7 @@ int rs_engine::build() {
   if ((rc = new_act(&f1, "box_fc1", 1, NB * PC, 1, FC, 0))) return rc;
   if ((rc = new_act(&f2, "box_fc2", 1, NB * PC, 1, FC, 0))) return rc;
   auto add_fc = [&](const std::string& name, const std::string& wn, const Act& in, const Act& out, bool relu, float* out32, int rows32) -> int {
-    const BlobEntry* w = find(wn + ".w");
+    const BlobEntry* w = findw(wn);
     const BlobEntry* b = find(wn + ".b");
     RS_CHECK(w && b, RS_ERR_BLOB, "weights for %s missing", wn.c_str());
     ConvParams p;
@@ -657,14 +668,14 @@ int rs_engine::build() {
     }
     if ((rc = alloc((void**)&mask_probs, (size_t)R * RS_MASK_SIDE * RS_MASK_SIDE * 4))) return rc;
     reg("mask_probs", mask_probs, DT_F32, {NB, D, RS_MASK_SIDE, RS_MASK_SIDE}, 0);
-    const BlobEntry* dw = find("roi_heads.mask_head.deconv.w");
+    const BlobEntry* dw = findw("roi_heads.mask_head.deconv");
     const BlobEntry* db = find("roi_heads.mask_head.deconv.b");
     const BlobEntry* pw = find("roi_heads.mask_head.predictor.w");
     const BlobEntry* pb = find("roi_heads.mask_head.predictor.b");
     RS_CHECK(dw && db && dw->dims[0] == 1024, RS_ERR_BLOB, "deconv weights missing / wrong rows");
     RS_CHECK(pw && pb && pw->dtype == DT_F32, RS_ERR_BLOB, "mask predictor weights missing");
     const char* fe = getenv("RS_FUSE_MASK_PREDICTOR");
-    const bool fuse = fe ? atoi(fe) != 0 : true;
+    const bool fuse = f32 ? false : (fe ? atoi(fe) != 0 : true);
     ConvParams dp;
     memset(&dp, 0, sizeof dp);
     dp.in = curm.p; dp.w = (const half_t*)dw->dev; dp.bias = (const float*)db->dev;
@@ -691,6 +702,7 @@ int rs_engine::build() {
       };
       stages.push_back(st);
       MaskPredictParams mp;
+      mp.f32 = 0;
       mp.in = nullptr; mp.w = nullptr; mp.b = (const float*)pb->dev; mp.slot_list = slot_list; mp.det_classes = det_classes;
       mp.n_entries = det_total; mp.out = mask_probs; mp.S = RS_MASK_SIDE;
       Stage st2;
@@ -712,7 +724,7 @@ int rs_engine::build() {
       }
       MaskPredictParams mp;
       mp.in = dec.p; mp.w = (const float*)pw->dev; mp.b = (const float*)pb->dev; mp.slot_list = slot_list; mp.det_classes = det_classes;
-      mp.n_entries = det_total; mp.out = mask_probs; mp.S = RS_MASK_SIDE;
+      mp.n_entries = det_total; mp.out = mask_probs; mp.S = RS_MASK_SIDE; mp.f32 = f32 ? 1 : 0;
       Stage st;
       st.name = "mask.predict_sigmoid";
       st.bytes_per_image = (double)D * RS_MASK_SIDE * RS_MASK_SIDE * (256 * 2 + 4);
@@ -848,6 +860,8 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   e->max_batch = max_batch; e->tile_h = tile_h; e->tile_w = tile_w; e->tile_c = tile_c;
   const char* g = getenv("RS_USE_GLDS");
   e->use_glds = g ? atoi(g) : 1;
+  e->f32 = spec->precision == 1;
+  if (e->f32) e->use_glds = -1;
   const char* gg = getenv("RS_USE_GRAPH");
   e->use_graph = gg ? atoi(gg) : 0;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }

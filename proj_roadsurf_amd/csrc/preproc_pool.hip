@@ -25,8 +25,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) 
   if (p.need_h) { xmin = p.hb[X * 2]; nx = p.hb[X * 2 + 1]; }
   const uint8_t* img = p.tiles + (long long)n * p.H * p.W * p.C;
   half8 o;
+  float of[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) o[c] = (half_t)0.f;
+  for (int c = 0; c < 8; ++c) { o[c] = (half_t)0.f; of[c] = 0.f; }
   for (int c = 0; c < p.C; ++c) {
     const int cs = p.flip ? (p.C - 1 - c) : c;
     int vacc = 1 << 21;
@@ -51,9 +52,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) 
     }
     const float f = ((float)val - p.mean[c]) / p.stdv[c];
     o[c] = (half_t)f;
+    of[c] = f;
   }
-  half_t* dst = p.out + (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 8;
-  *(half8*)dst = o;
+  const long long oidx = (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 8;
+  if (p.out_f32) {
+    float* dst = (float*)p.out + oidx;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dst[c] = of[c];
+  } else {
+    *(half8*)(p.out + oidx) = o;
+  }
 }
 
 int launch_preprocess(const PreprocParams& p, hipStream_t s) {
@@ -115,6 +123,48 @@ __global__ __launch_bounds__(256) void subsample2_kernel(const half_t* in, half_
 int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s) {
   const long long total = (long long)N * Ho * Wo * (C >> 3);
   hipLaunchKernelGGL(subsample2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, N, Hi, Wi, Ho, Wo, C);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+// ---- fp32 validation variants (rs_spec.precision == 1): same indexing, float storage ----
+__global__ __launch_bounds__(256) void maxpool3x3s2_f32_kernel(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Ho * Wo * C;
+  if (gid >= total) return;
+  const int c = (int)(gid % C);
+  long long t = gid / C;
+  const int x = (int)(t % Wo); t /= Wo;
+  const int y = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  float m = 0.f;
+  for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx) {
+      const float v = in[(((long long)n * (Hi + 2) + 2 * y + dy) * (Wi + 2) + 2 * x + dx) * C + c];
+      m = v > m ? v : m;
+    }
+  out[(((long long)n * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * C + c] = m;
+}
+__global__ __launch_bounds__(256) void subsample2_f32_kernel(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Ho * Wo * C;
+  if (gid >= total) return;
+  const int c = (int)(gid % C);
+  long long t = gid / C;
+  const int x = (int)(t % Wo); t /= Wo;
+  const int y = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  out[(((long long)n * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * C + c] = in[(((long long)n * (Hi + 2) + 2 * y + 1) * (Wi + 2) + 2 * x + 1) * C + c];
+}
+int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s) {
+  const long long total = (long long)N * Ho * Wo * C;
+  hipLaunchKernelGGL(maxpool3x3s2_f32_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, N, Hi, Wi, Ho, Wo, C);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s) {
+  const long long total = (long long)N * Ho * Wo * C;
+  hipLaunchKernelGGL(subsample2_f32_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, N, Hi, Wi, Ho, Wo, C);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

@@ -43,6 +43,7 @@ class RsSpec(C.Structure):
         ("box_fc_dim", C.c_int32), ("box_pooler_resolution", C.c_int32),
         ("mask_on", C.c_int32), ("mask_pooler_resolution", C.c_int32), ("mask_num_conv", C.c_int32),
         ("mask_conv_dim", C.c_int32), ("mask_threshold", C.c_float), ("scale_clamp", C.c_float),
+        ("precision", C.c_int32),
     ]
 
 
@@ -150,6 +151,7 @@ def make_rs_spec(spec: EngineSpec) -> RsSpec:
     s.mask_on, s.mask_pooler_resolution = int(spec.mask_on), spec.mask_pooler_resolution
     s.mask_num_conv, s.mask_conv_dim = spec.mask_num_conv, spec.mask_conv_dim
     s.mask_threshold, s.scale_clamp = spec.mask_threshold, spec.scale_clamp
+    s.precision = {"fp16": 0, "fp32": 1}[spec.precision]
     return s
 
 

@@ -168,7 +168,7 @@ def _fold_bn(W: Dict[str, np.ndarray], name: str, eps: float) -> Tuple[np.ndarra
     return w * scale[:, None, None, None], b - m * scale
 
 
-def _ohwi(w: np.ndarray, cin_pad: int) -> np.ndarray:
+def _ohwi(w: np.ndarray, cin_pad: int, dtype=np.float16) -> np.ndarray:
     """(Cout,Cin,KH,KW) fp32 -> (Cout, KH*KW*cin_pad) with K padded to K_ALIGN, fp16."""
     cout, cin, kh, kw = w.shape
     t = np.zeros((cout, kh, kw, cin_pad), np.float32)
@@ -177,7 +177,7 @@ def _ohwi(w: np.ndarray, cin_pad: int) -> np.ndarray:
     kpad = (t.shape[1] + K_ALIGN - 1) // K_ALIGN * K_ALIGN
     out = np.zeros((cout, kpad), np.float32)
     out[:, : t.shape[1]] = t
-    return out.astype(np.float16)
+    return out.astype(dtype)
 
 
 def _pad_rows(w: np.ndarray, b: np.ndarray, mult: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -192,7 +192,7 @@ def _pad_rows(w: np.ndarray, b: np.ndarray, mult: int) -> Tuple[np.ndarray, np.n
     return w2, b2
 
 
-def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], w_dtype=np.float16) -> Dict[str, np.ndarray]:
     """Kernel-ready tensors keyed ``<layer>.w`` (fp16 [Cout_pad][Kpad]) / ``<layer>.b`` (fp32)."""
     T: Dict[str, np.ndarray] = {}
     for name, cin, cout, k, has_norm in conv_layers(spec):
@@ -203,34 +203,34 @@ def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray]) -> Dict[str, np.n
         else:
             w, b = W[name + ".weight"].astype(np.float32), W[name + ".bias"].astype(np.float32)
         cin_pad = STEM_CIN_PAD if name.endswith("stem.conv1") else cin
-        T[name + ".w"] = _ohwi(w, cin_pad)
+        T[name + ".w"] = _ohwi(w, cin_pad, w_dtype)
         T[name + ".b"] = b.astype(np.float32)
     # RPN heads fused into one 1x1 conv: rows [0,A) objectness, [A,5A) deltas (a*4+d), padded to 16
     p = "proposal_generator.rpn_head."
     w = np.concatenate([W[p + "objectness_logits.weight"], W[p + "anchor_deltas.weight"]], 0).astype(np.float32)
     b = np.concatenate([W[p + "objectness_logits.bias"], W[p + "anchor_deltas.bias"]], 0).astype(np.float32)
-    wp, bp = _pad_rows(_ohwi(w, w.shape[1]), b, 16)
+    wp, bp = _pad_rows(_ohwi(w, w.shape[1], w_dtype), b, 16)
     T[p + "heads.w"], T[p + "heads.b"] = wp, bp
     # box head: fc1 consumes RoI features laid out [7][7][C] (channels fastest) on the device,
     # detectron2 flattens (C,7,7): permute the K axis once here.
     r = spec.box_pooler_resolution
     c = spec.fpn_out_channels
     fc1 = W["roi_heads.box_head.fc1.weight"].astype(np.float32).reshape(-1, c, r, r).transpose(0, 2, 3, 1).reshape(-1, r * r * c)
-    T["roi_heads.box_head.fc1.w"] = _ohwi(fc1[:, :, None, None], fc1.shape[1])
+    T["roi_heads.box_head.fc1.w"] = _ohwi(fc1[:, :, None, None], fc1.shape[1], w_dtype)
     T["roi_heads.box_head.fc1.b"] = W["roi_heads.box_head.fc1.bias"].astype(np.float32)
     fc2 = W["roi_heads.box_head.fc2.weight"].astype(np.float32)
-    T["roi_heads.box_head.fc2.w"] = _ohwi(fc2[:, :, None, None], fc2.shape[1])
+    T["roi_heads.box_head.fc2.w"] = _ohwi(fc2[:, :, None, None], fc2.shape[1], w_dtype)
     T["roi_heads.box_head.fc2.b"] = W["roi_heads.box_head.fc2.bias"].astype(np.float32)
     # predictor: rows [0,K+1) class logits, [K+1, K+1+4K) box deltas, padded to 16
     w = np.concatenate([W["roi_heads.box_predictor.cls_score.weight"], W["roi_heads.box_predictor.bbox_pred.weight"]], 0).astype(np.float32)
     b = np.concatenate([W["roi_heads.box_predictor.cls_score.bias"], W["roi_heads.box_predictor.bbox_pred.bias"]], 0).astype(np.float32)
-    wp, bp = _pad_rows(_ohwi(w[:, :, None, None], w.shape[1]), b, 16)
+    wp, bp = _pad_rows(_ohwi(w[:, :, None, None], w.shape[1], w_dtype), b, 16)
     T["roi_heads.box_predictor.w"], T["roi_heads.box_predictor.b"] = wp, bp
     if spec.mask_on:
         # deconv 2x2 s2 == 4 independent 1x1 convs: row (g*Cout + co), g = dy*2+dx
         dw = W["roi_heads.mask_head.deconv.weight"].astype(np.float32)          # (Cin, Cout, 2, 2)
         g = dw.transpose(2, 3, 1, 0).reshape(4 * dw.shape[1], dw.shape[0])      # (dy,dx,co) x ci
-        T["roi_heads.mask_head.deconv.w"] = _ohwi(g[:, :, None, None], g.shape[1])
+        T["roi_heads.mask_head.deconv.w"] = _ohwi(g[:, :, None, None], g.shape[1], w_dtype)
         T["roi_heads.mask_head.deconv.b"] = np.tile(W["roi_heads.mask_head.deconv.bias"].astype(np.float32), 4)
         pw = W["roi_heads.mask_head.predictor.weight"].astype(np.float32)[:, :, 0, 0]      # (K, C)
         T["roi_heads.mask_head.predictor.w"] = pw.astype(np.float32)           # fp32: tiny, used by a VALU dot
@@ -266,4 +266,11 @@ def serialize(tensors: Dict[str, np.ndarray]) -> bytes:
 
 
 def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray]) -> bytes:
-    return serialize(engine_tensors(spec, W))
+    T = engine_tensors(spec, W)
+    if spec.precision == "fp32":
+        # fp32 validation mode: same layout, GEMM weights additionally kept in fp32 ("<layer>.w32")
+        T32 = engine_tensors(spec, W, w_dtype=np.float32)
+        for k, v in T32.items():
+            if k.endswith(".w") and k != "roi_heads.mask_head.predictor.w":
+                T[k + "32"] = v
+    return serialize(T)

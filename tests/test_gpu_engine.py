@@ -264,3 +264,56 @@ def test_full_size_512_tile(gpu_required):
         assert fw["max_dscore"] <= 0.02 and fw["min_mask_iou"] >= 0.8 and fw["agg_mask_iou"] >= 0.9, fw
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32 validation mode (rs_spec.precision = 1): every conv/linear layer in plain fp32.  Here the
+# SURVEY.md §8d "fp32 validation" bar applies end to end against the fp32 oracle:
+# >= 98 % of detections matched both ways, |dbox| <= 1e-2 px, |dscore| <= 1e-4 on matched pairs.
+# ---------------------------------------------------------------------------------------------
+def _strict_compare(ref, det, tag):
+    r = {"boxes": ref["boxes"].numpy(), "scores": ref["scores"].numpy(), "classes": ref["classes"].numpy(), "masks": ref["masks"].numpy()}
+    g = {"boxes": det.pred_boxes, "scores": det.scores, "classes": det.pred_classes, "masks": det.pred_masks}
+    fw, bw = match_detections(r, g, min_score=0.05, iou_thr=0.99), match_detections(g, r, min_score=0.05, iou_thr=0.99)
+    print(tag, fw, bw)
+    assert fw["frac_matched"] >= 0.98 and bw["frac_matched"] >= 0.98, (fw, bw)
+    assert fw["max_dscore"] <= 1e-4, fw
+    assert fw["agg_mask_iou"] >= 0.995, fw
+    assert fw["max_dbox"] <= 1e-2, fw          # matched pairs (two detections with scores 1e-6 apart may swap rank)
+
+
+def test_fp32_mode_end_to_end_small(gpu_required):
+    O = _oracle()
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300,
+                      precision="fp32")
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(3, 256, 256, 3, seed=77)
+    eng = Engine(spec, W, (256, 256, 3), max_batch=3)
+    try:
+        dets = eng.infer(tiles)
+        feats = O.OracleModel(spec, W)
+        ref = feats([tiles[i] for i in range(3)], keep=True)
+        # backbone maps now agree to fp32 rounding
+        for name in ["res2", "res5", "p2", "p6"]:
+            got = torch.from_numpy(eng.tensor(name, n=3)).permute(0, 3, 1, 2)
+            want = torch.stack([ref[i]["inter"]["feats"][name] for i in range(3)])
+            rel = float((got - want).norm() / want.norm())
+            assert rel <= 2e-5, f"{name}: rel L2 err {rel}"
+        for i in range(3):
+            _strict_compare(ref[i], dets[i], f"fp32_small[{i}]")
+    finally:
+        eng.close()
+
+
+def test_fp32_mode_full_size_tile(gpu_required):
+    O = _oracle()
+    spec = EngineSpec(num_classes=2, precision="fp32")
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(1, 512, 512, 3, seed=1234)
+    eng = Engine(spec, W, (512, 512, 3), max_batch=1)
+    try:
+        dets = eng.infer(tiles)
+        ref = O.OracleModel(spec, W)([tiles[0]])
+        _strict_compare(ref[0], dets[0], "fp32_full")
+    finally:
+        eng.close()

@@ -55,6 +55,7 @@ def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
     used = set()
     matched, dscore, miou = 0, 0.0, 1.0
     inter_sum, union_sum = 0, 0
+    dbox = 0.0
     for i in sel:
         cand = [(iou[i, j], j) for j in range(len(gb)) if j not in used and gc[j] == rc[i] and iou[i, j] >= iou_thr]
         if not cand:
@@ -63,6 +64,7 @@ def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
         used.add(j)
         matched += 1
         dscore = max(dscore, abs(float(rs[i]) - float(gs[j])))
+        dbox = max(dbox, float(np.abs(rb[i] - gb[j]).max()))
         if "masks" in ref and "masks" in got:
             a, b = np.asarray(ref["masks"][i], bool), np.asarray(got["masks"][j], bool)
             u = np.logical_or(a, b).sum()
@@ -73,4 +75,4 @@ def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
                 miou = min(miou, it / u)
     n = len(sel)
     return {"frac_matched": matched / n if n else 1.0, "max_dscore": dscore, "min_mask_iou": miou, "n_ref": n,
-            "agg_mask_iou": (inter_sum / union_sum) if union_sum else 1.0}
+            "agg_mask_iou": (inter_sum / union_sum) if union_sum else 1.0, "max_dbox": dbox}
