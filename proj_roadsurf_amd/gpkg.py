@@ -1,0 +1,112 @@
+"""Minimal GeoPackage (OGC 12-128r15) writer/reader for polygon features, on the stdlib ``sqlite3``.
+
+The reference's detector step writes ``<dataset>_detections_at_<thr>_threshold.gpkg`` with columns
+``score``, ``det_class``, ``geometry`` (R:config/config_obj_detec.yaml:100-103,119-122; consumers:
+R:scripts/road_segmentation/determine_class.py:22-25, final_metrics.py:214-221) through geopandas, which is
+not available offline.  This writes the same table with the standard GeoPackage binary geometry
+(GP header + little-endian WKB Polygon), so ``geopandas.read_file`` / GDAL can open it.
+"""
+from __future__ import annotations
+
+import sqlite3
+import struct
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+_SRS = {
+    3857: ("WGS 84 / Pseudo-Mercator", 'PROJCS["WGS 84 / Pseudo-Mercator",GEOGCS["WGS 84",DATUM["WGS_1984",SPHEROID["WGS 84",6378137,298.257223563]],PRIMEM["Greenwich",0],UNIT["degree",0.0174532925199433]],PROJECTION["Mercator_1SP"],PARAMETER["central_meridian",0],PARAMETER["scale_factor",1],PARAMETER["false_easting",0],PARAMETER["false_northing",0],UNIT["metre",1],AUTHORITY["EPSG","3857"]]'),
+    2056: ("CH1903+ / LV95", 'PROJCS["CH1903+ / LV95",GEOGCS["CH1903+",DATUM["CH1903+",SPHEROID["Bessel 1841",6377397.155,299.1528128]],PRIMEM["Greenwich",0],UNIT["degree",0.0174532925199433]],PROJECTION["Hotine_Oblique_Mercator_Azimuth_Center"],PARAMETER["latitude_of_center",46.9524055555556],PARAMETER["longitude_of_center",7.43958333333333],PARAMETER["azimuth",90],PARAMETER["rectified_grid_angle",90],PARAMETER["scale_factor",1],PARAMETER["false_easting",2600000],PARAMETER["false_northing",1200000],UNIT["metre",1],AUTHORITY["EPSG","2056"]]'),
+    4326: ("WGS 84", 'GEOGCS["WGS 84",DATUM["WGS_1984",SPHEROID["WGS 84",6378137,298.257223563]],PRIMEM["Greenwich",0],UNIT["degree",0.0174532925199433],AUTHORITY["EPSG","4326"]]'),
+}
+
+
+def polygon_wkb(rings: Sequence[Sequence[Sequence[float]]]) -> bytes:
+    out = [struct.pack("<BII", 1, 3, len(rings))]
+    for r in rings:
+        out.append(struct.pack("<I", len(r)))
+        for x, y in r:
+            out.append(struct.pack("<dd", float(x), float(y)))
+    return b"".join(out)
+
+
+def gpkg_geom(rings: Sequence[Sequence[Sequence[float]]], srs_id: int) -> bytes:
+    xs = [p[0] for r in rings for p in r]
+    ys = [p[1] for r in rings for p in r]
+    # magic 'GP', version 0, flags: little-endian (bit0) + envelope type 1 = [minx,maxx,miny,maxy] (bits 1-3)
+    hdr = struct.pack("<2sBBi4d", b"GP", 0, 0b00000011, srs_id, min(xs), max(xs), min(ys), max(ys))
+    return hdr + polygon_wkb(rings)
+
+
+def write_gpkg(path: str, features: Iterable[dict], table: str = "detections", epsg: Optional[int] = None) -> int:
+    """Write GeoJSON-like polygon features (``properties``: score, det_class, image).  Returns the row count."""
+    srs_id = int(epsg) if epsg else -1
+    con = sqlite3.connect(path)
+    try:
+        cur = con.cursor()
+        cur.execute("PRAGMA application_id = 1196444487")    # 'GPKG'
+        cur.execute("PRAGMA user_version = 10200")
+        cur.executescript("""
+            DROP TABLE IF EXISTS gpkg_spatial_ref_sys; DROP TABLE IF EXISTS gpkg_contents; DROP TABLE IF EXISTS gpkg_geometry_columns;
+            CREATE TABLE gpkg_spatial_ref_sys (srs_name TEXT NOT NULL, srs_id INTEGER NOT NULL PRIMARY KEY, organization TEXT NOT NULL,
+                organization_coordsys_id INTEGER NOT NULL, definition TEXT NOT NULL, description TEXT);
+            CREATE TABLE gpkg_contents (table_name TEXT NOT NULL PRIMARY KEY, data_type TEXT NOT NULL, identifier TEXT UNIQUE, description TEXT DEFAULT '',
+                last_change DATETIME NOT NULL DEFAULT (strftime('%Y-%m-%dT%H:%M:%fZ','now')), min_x DOUBLE, min_y DOUBLE, max_x DOUBLE, max_y DOUBLE, srs_id INTEGER);
+            CREATE TABLE gpkg_geometry_columns (table_name TEXT NOT NULL, column_name TEXT NOT NULL, geometry_type_name TEXT NOT NULL, srs_id INTEGER NOT NULL,
+                z TINYINT NOT NULL, m TINYINT NOT NULL, CONSTRAINT pk_geom_cols PRIMARY KEY (table_name, column_name));
+        """)
+        cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES ('Undefined cartesian SRS', -1, 'NONE', -1, 'undefined', 'undefined cartesian coordinate reference system')")
+        cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES ('Undefined geographic SRS', 0, 'NONE', 0, 'undefined', 'undefined geographic coordinate reference system')")
+        name4326, def4326 = _SRS[4326]
+        cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES (?, 4326, 'EPSG', 4326, ?, NULL)", (name4326, def4326))
+        if srs_id not in (-1, 0, 4326):
+            name, definition = _SRS.get(srs_id, (f"EPSG:{srs_id}", "undefined"))
+            cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES (?, ?, 'EPSG', ?, ?, NULL)", (name, srs_id, srs_id, definition))
+        cur.execute(f'DROP TABLE IF EXISTS "{table}"')
+        cur.execute(f'CREATE TABLE "{table}" (fid INTEGER PRIMARY KEY AUTOINCREMENT NOT NULL, geom BLOB, score REAL, det_class INTEGER, image TEXT)')
+        n = 0
+        bx = [float("inf"), float("inf"), float("-inf"), float("-inf")]
+        for f in features:
+            rings = f["geometry"]["coordinates"]
+            pr = f.get("properties", {})
+            cur.execute(f'INSERT INTO "{table}" (geom, score, det_class, image) VALUES (?, ?, ?, ?)',
+                        (gpkg_geom(rings, srs_id), pr.get("score"), pr.get("det_class"), pr.get("image")))
+            for r in rings:
+                for x, y in r:
+                    bx[0] = min(bx[0], x); bx[1] = min(bx[1], y); bx[2] = max(bx[2], x); bx[3] = max(bx[3], y)
+            n += 1
+        if n == 0:
+            bx = [None, None, None, None]
+        cur.execute("INSERT INTO gpkg_contents (table_name, data_type, identifier, min_x, min_y, max_x, max_y, srs_id) VALUES (?, 'features', ?, ?, ?, ?, ?, ?)",
+                    (table, table, bx[0], bx[1], bx[2], bx[3], srs_id))
+        cur.execute("INSERT INTO gpkg_geometry_columns VALUES (?, 'geom', 'POLYGON', ?, 0, 0)", (table, srs_id))
+        con.commit()
+        return n
+    finally:
+        con.close()
+
+
+def read_gpkg(path: str, table: str = "detections") -> List[dict]:
+    """Read back what ``write_gpkg`` wrote (used by the tests; a reader for consumers without geopandas)."""
+    con = sqlite3.connect(path)
+    try:
+        rows = con.execute(f'SELECT geom, score, det_class, image FROM "{table}" ORDER BY fid').fetchall()
+    finally:
+        con.close()
+    out = []
+    for blob, score, cls, image in rows:
+        magic, _ver, flags, srs = struct.unpack_from("<2sBBi", blob, 0)
+        assert magic == b"GP" and flags & 1
+        env = {0: 0, 1: 32, 2: 48, 3: 48, 4: 64}[(flags >> 1) & 7]
+        off = 8 + env
+        bo, typ, nr = struct.unpack_from("<BII", blob, off)
+        assert bo == 1 and typ == 3
+        off += 9
+        rings = []
+        for _ in range(nr):
+            (npt,) = struct.unpack_from("<I", blob, off)
+            off += 4
+            pts = [list(struct.unpack_from("<dd", blob, off + 16 * i)) for i in range(npt)]
+            off += 16 * npt
+            rings.append(pts)
+        out.append({"type": "Feature", "geometry": {"type": "Polygon", "coordinates": rings},
+                    "properties": {"score": score, "det_class": cls, "image": image}, "srs_id": srs})
+    return out

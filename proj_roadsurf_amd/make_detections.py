@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Process-level drop-in for the STDL object-detector's ``make_detections.py`` as proj-roadsurf invokes it
+(R:README.md:78): same argv (one YAML path), same YAML section ``make_detections.py:``
+(R:config/config_obj_detec.yaml:74-90), same output files
+(``<dataset>_detections_at_<thr>_threshold.gpkg`` with columns ``score``, ``det_class``, ``geometry`` --
+R:config/config_obj_detec.yaml:100-103; plus a ``.geojson`` twin).
+
+    python -m proj_roadsurf_amd.make_detections config/config_obj_detec.yaml
+    python -m torch.distributed.run --nproc-per-node 8 -m proj_roadsurf_amd.make_detections config/config_obj_detec.yaml
+
+Host Python only does what BASELINE.json:north_star leaves on the host: YAML/COCO-JSON I/O, tile decode,
+weight loading, mask polygonisation and file writing.  The detector itself is ``librs_engine.so``.
+With several ranks (RANK/WORLD_SIZE in the environment) the tile list of every dataset is sharded, one
+GPU per rank, no collectives on the data path; rank 0 gathers the features and writes the files.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+import time
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import yaml
+
+from .gpkg import write_gpkg
+from .shard import run_sharded
+from .spec import load_d2_yaml
+from .vectorize import instances_to_features
+from .weights import infer_num_classes, load_checkpoint, synthetic_weights
+
+SECTION = "make_detections.py"
+log = logging.getLogger("make_detections")
+
+
+def read_tile(path: str) -> np.ndarray:
+    """``cv2.imread`` stand-in: HWC uint8, channels in BGR(A) order (what DefaultPredictor expects)."""
+    from PIL import Image
+
+    im = np.asarray(Image.open(path))
+    if im.ndim == 2:
+        im = np.stack([im] * 3, axis=-1)
+    if im.dtype != np.uint8:
+        raise ValueError(f"{path}: expected 8-bit tiles, got {im.dtype}")
+    return np.ascontiguousarray(im[:, :, ::-1])
+
+
+def tile_extent(meta: Dict[str, Any], file_name: str) -> Tuple[Optional[Sequence[float]], Optional[int]]:
+    """Georeference of one tile from ``img_metadata.json`` (R:config/config_obj_detec.yaml:78): returns
+    ((xmin, ymin, xmax, ymax), epsg) or (None, None).  Keys are matched by path or basename; the extent may be
+    stored as ``extent``/``bbox`` [xmin, ymin, xmax, ymax] or as west/south/east/north."""
+    rec = meta.get(file_name) or meta.get(os.path.basename(file_name))
+    if rec is None:
+        for k, v in meta.items():
+            if os.path.basename(k) == os.path.basename(file_name):
+                rec = v
+                break
+    if not isinstance(rec, dict):
+        return None, None
+    ext = rec.get("extent") or rec.get("bbox")
+    if isinstance(ext, dict):
+        ext = [ext.get("xmin"), ext.get("ymin"), ext.get("xmax"), ext.get("ymax")]
+    if ext is None and all(k in rec for k in ("west", "south", "east", "north")):
+        ext = [rec["west"], rec["south"], rec["east"], rec["north"]]
+    epsg = None
+    for k in ("crs", "srs", "epsg"):
+        if k in rec:
+            s = str(rec[k])
+            digits = "".join(ch for ch in s.split(":")[-1] if ch.isdigit())
+            epsg = int(digits) if digits else None
+            break
+    return (list(map(float, ext)) if ext is not None else None), epsg
+
+
+def thr_tag(thr: float) -> str:
+    return str(thr).replace(".", "dot")
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("config_file", help="YAML with a 'make_detections.py' section (R:config/config_obj_detec.yaml)")
+    ap.add_argument("--batch", type=int, default=16, help="tiles per engine call")
+    ap.add_argument("--synthetic-weights", action="store_true",
+                    help="use seeded synthetic weights instead of model_weights.pth_file (demo / smoke tests)")
+    ap.add_argument("--max-tiles", type=int, default=0, help="debug: only the first N tiles of every dataset")
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s", stream=sys.stderr)
+
+    with open(args.config_file) as f:
+        cfg = yaml.safe_load(f)[SECTION]
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=os.environ.get("RS_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+
+    os.chdir(cfg["working_directory"])
+    os.makedirs(cfg.get("log_subfolder", "logs"), exist_ok=True)
+    meta: Dict[str, Any] = {}
+    if cfg.get("image_metadata_json") and os.path.exists(cfg["image_metadata_json"]):
+        with open(cfg["image_metadata_json"]) as f:
+            meta = json.load(f)
+    coco = {}
+    for name, path in cfg["COCO_files"].items():
+        with open(path) as f:
+            coco[name] = json.load(f)
+    cats = sorted({c["id"] for d in coco.values() for c in d.get("categories", [])})
+    thr = float(cfg.get("score_lower_threshold", 0.05))
+    rdp_cfg = cfg.get("rdp_simplification", {}) or {}
+
+    if args.synthetic_weights:
+        spec = load_d2_yaml(cfg["detectron2_config_file"], num_classes=max(len(cats), 1)).replace(score_thresh_test=thr)
+        W = synthetic_weights(spec, seed=0)
+    else:
+        W = load_checkpoint(cfg["model_weights"]["pth_file"])
+        k = infer_num_classes(W)
+        if cats and len(cats) != k:
+            raise SystemExit(f"checkpoint has {k} classes but the COCO files define {len(cats)} categories")
+        spec = load_d2_yaml(cfg["detectron2_config_file"], num_classes=k).replace(score_thresh_test=thr)
+
+    from .engine import Predictor      # fails loudly without librs_engine.so / a HIP device
+    predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank)
+
+    def predict_batch(entries: Sequence[dict]) -> List[List[dict]]:
+        ims = [read_tile(e["file_name"]) for e in entries]
+        outs = predictor.predict_batch(ims)
+        res = []
+        for e, o in zip(entries, outs):
+            ext, _ = tile_extent(meta, e["file_name"])
+            res.append(instances_to_features(o["instances"], os.path.basename(e["file_name"]), ext,
+                                             bool(rdp_cfg.get("enabled", False)), float(rdp_cfg.get("epsilon", 0.75))))
+        return res
+
+    for dataset, d in coco.items():
+        images = d.get("images", [])
+        if args.max_tiles:
+            images = images[: args.max_tiles]
+        t0 = time.time()
+        per_tile = run_sharded(images, predict_batch, args.batch, rank, world)
+        if rank != 0:
+            continue
+        feats = [f for tile in per_tile for f in tile]
+        epsg = None
+        for e in images:
+            _, epsg = tile_extent(meta, e["file_name"])
+            if epsg:
+                break
+        base = f"{dataset}_detections_at_{thr_tag(thr)}_threshold"
+        n = write_gpkg(base + ".gpkg", feats, table=base, epsg=epsg)
+        with open(base + ".geojson", "w") as f:
+            json.dump({"type": "FeatureCollection", "features": feats}, f)
+        dt = time.time() - t0
+        log.info("%s: %d tiles -> %d features in %.1f s (%.1f tiles/s) -> %s.gpkg", dataset, len(images), n, dt,
+                 len(images) / max(dt, 1e-9), base)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,140 @@
+"""Host tail of the detector step: mask polygonisation, RDP, GeoPackage writer (CPU) and the
+``make_detections`` CLI end to end on a small synthetic tileset (GPU)."""
+import json
+import os
+import sqlite3
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from proj_roadsurf_amd.gpkg import read_gpkg, write_gpkg
+from proj_roadsurf_amd.vectorize import instances_to_features, mask_to_polygons, rdp, ring_area
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _area(polys):
+    return sum(sum(ring_area(r) for r in p) for p in polys)
+
+
+def test_polygonize_rect_with_hole():
+    m = np.zeros((6, 7), bool)
+    m[1:5, 1:6] = True
+    m[2:4, 3] = False
+    P = mask_to_polygons(m)
+    assert len(P) == 1 and len(P[0]) == 2
+    assert P[0][0][0] == P[0][0][-1] and len(P[0][0]) == 5          # closed rectangle, corner vertices only
+    assert ring_area(P[0][0]) == 20 and ring_area(P[0][1]) == -2 and _area(P) == m.sum()
+
+
+def test_polygonize_diagonal_pixels_are_separate_regions():
+    m = np.zeros((3, 3), bool)
+    m[0, 0] = m[1, 1] = m[2, 2] = True
+    assert len(mask_to_polygons(m)) == 3                              # 4-connectivity (rasterio default)
+
+
+def test_polygonize_random_masks_area_and_components():
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        m = rng.random((15, 17)) > rng.uniform(0.3, 0.7)
+        P = mask_to_polygons(m)
+        assert abs(_area(P) - m.sum()) < 1e-9
+        assert len(P) == ndimage.label(m)[1]
+        holes = ndimage.label(~np.pad(m, 1))[1] - 1                   # background regions not touching the border... (8-conn for holes)
+        assert sum(len(p) - 1 for p in P) >= 0 and holes >= 0
+    assert mask_to_polygons(np.zeros((4, 4), bool)) == []
+
+
+def test_rdp_known_answers():
+    line = [(0, 0), (1, 0.1), (2, -0.1), (3, 5), (4, 6), (5, 7), (6, 8.1), (7, 9), (8, 9), (9, 9)]
+    assert rdp(line, 1.0) == [(0.0, 0.0), (2.0, -0.1), (3.0, 5.0), (7.0, 9.0), (9.0, 9.0)]
+    assert rdp(line, 0.0) == [tuple(map(float, p)) for p in line]
+    sq = [(0, 0), (4, 0), (4, 4), (0, 4), (0, 0)]                      # closed ring: chord degenerate -> distance to start
+    assert rdp(sq, 0.75) == [tuple(map(float, p)) for p in sq]
+    stair = [(0, 0), (1, 0), (1, 1), (2, 1), (2, 2), (3, 2), (3, 3)]    # 0.5-px staircase collapses at eps 0.75
+    assert rdp(stair, 0.75) == [(0.0, 0.0), (3.0, 3.0)]
+
+
+class _Inst:
+    image_size = (8, 8)
+
+    def __init__(self):
+        self.pred_masks = np.zeros((1, 8, 8), bool)
+        self.pred_masks[0, 2:6, 1:7] = True
+        self.scores = np.array([0.9], np.float32)
+        self.pred_classes = np.array([1])
+        self.pred_boxes = np.array([[1, 2, 7, 6]], np.float32)
+
+    def __len__(self):
+        return 1
+
+    def has(self, k):
+        return True
+
+
+def test_features_georeference_and_gpkg_roundtrip(tmp_path):
+    feats = instances_to_features(_Inst(), "18_1_2.tif", extent=(1000.0, 2000.0, 1080.0, 2080.0), rdp_enabled=True, rdp_epsilon=0.75)
+    assert len(feats) == 1
+    ring = feats[0]["geometry"]["coordinates"][0]
+    xs, ys = [p[0] for p in ring], [p[1] for p in ring]
+    assert (min(xs), max(xs)) == (1010.0, 1070.0) and (min(ys), max(ys)) == (2020.0, 2060.0)      # 10 CRS units per pixel, y flipped
+    assert feats[0]["properties"] == {"score": pytest.approx(0.9), "det_class": 1, "image": "18_1_2.tif"}
+    p = str(tmp_path / "val_detections_at_0dot05_threshold.gpkg")
+    assert write_gpkg(p, feats, table="val_detections", epsg=3857) == 1
+    back = read_gpkg(p, "val_detections")
+    assert back[0]["geometry"]["coordinates"] == feats[0]["geometry"]["coordinates"] and back[0]["srs_id"] == 3857
+    con = sqlite3.connect(p)
+    assert con.execute("PRAGMA application_id").fetchone()[0] == 0x47504B47
+    assert con.execute("SELECT geometry_type_name, srs_id FROM gpkg_geometry_columns").fetchone() == ("POLYGON", 3857)
+    assert con.execute("SELECT data_type FROM gpkg_contents").fetchone()[0] == "features"
+    con.close()
+
+
+@pytest.mark.gpu
+def test_make_detections_cli_end_to_end(gpu_required, tmp_path):
+    """Same argv and YAML keys as the reference CLI (R:config/config_obj_detec.yaml:74-90), synthetic tiles and weights."""
+    from PIL import Image
+    import yaml
+    from proj_roadsurf_amd import make_detections
+    from proj_roadsurf_amd.spec import EngineSpec
+    from tests.util import synthetic_tiles
+
+    wd = tmp_path / "outputs" / "obj_detector"
+    (wd / "val-images").mkdir(parents=True)
+    tiles = synthetic_tiles(5, 128, 128, 3, seed=9)
+    images, meta = [], {}
+    for i in range(5):
+        fn = f"val-images/18_{100 + i}_200.tif"
+        Image.fromarray(tiles[i][:, :, ::-1]).save(str(wd / fn))           # tiles are BGR; files hold RGB
+        images.append({"id": i, "file_name": fn, "width": 128, "height": 128})
+        meta[fn] = {"extent": [1000.0 * i, 0.0, 1000.0 * i + 52.0, 52.0], "crs": "EPSG:3857"}
+    cats = [{"id": 1, "name": "artificial"}, {"id": 2, "name": "natural"}]
+    json.dump({"images": images, "annotations": [], "categories": cats}, open(wd / "COCO_val.json", "w"))
+    json.dump(meta, open(wd / "img_metadata.json", "w"))
+    # a small detectron2 YAML (the reference's keys, smaller sizes so the test is quick)
+    d2 = {"INPUT": {"FORMAT": "RGB", "MIN_SIZE_TEST": 192, "MAX_SIZE_TEST": 320},
+          "MODEL": {"RPN": {"PRE_NMS_TOPK_TEST": 200, "POST_NMS_TOPK_TEST": 200}, "ROI_HEADS": {"NUM_CLASSES": 1}},
+          "TEST": {"DETECTIONS_PER_IMAGE": 20}}
+    yaml.safe_dump(d2, open(tmp_path / "d2.yaml", "w"))
+    cfg = {"make_detections.py": {"working_directory": str(wd), "log_subfolder": "logs", "sample_tagged_img_subfolder": "sample_detection_images",
+                                  "image_metadata_json": "img_metadata.json", "COCO_files": {"val": "COCO_val.json"},
+                                  "detectron2_config_file": str(tmp_path / "d2.yaml"), "model_weights": {"pth_file": "logs/model_0005999.pth"},
+                                  "rdp_simplification": {"enabled": True, "epsilon": 0.75}, "score_lower_threshold": 0.05}}
+    yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
+    cwd = os.getcwd()
+    try:
+        assert make_detections.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--batch", "2"]) == 0
+    finally:
+        os.chdir(cwd)
+    out = wd / "val_detections_at_0dot05_threshold.gpkg"
+    assert out.exists() and (wd / "logs").is_dir()
+    feats = read_gpkg(str(out), "val_detections_at_0dot05_threshold")
+    assert len(feats) > 0
+    for f in feats:
+        assert 0.05 < f["properties"]["score"] <= 1.0 and f["properties"]["det_class"] in (0, 1)
+        i = int(f["properties"]["image"].split("_")[1]) - 100
+        xs = [p[0] for p in f["geometry"]["coordinates"][0]]
+        assert 1000.0 * i - 1e-6 <= min(xs) and max(xs) <= 1000.0 * i + 52.0 + 1e-6       # georeferenced into its own tile
+    gj = json.load(open(wd / "val_detections_at_0dot05_threshold.geojson"))
+    assert len(gj["features"]) == len(feats)
