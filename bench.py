@@ -137,27 +137,37 @@ def main():
         conv = [s for s in stages if s["flops"] > 0 and s["calls"] > 0]
         by_time = sorted(stages, key=lambda s: -s["ms_total"])
         tot_ms = sum(s["ms_total"] for s in stages)
-        # (res2 conv1/conv2 and the stem have Cout 64 -> 256x64 variant, the small heads the 256x16 one;
-        #  every other GEMM stage runs the 128x128 variant)
-        big = [s for s in conv if not (s["name"].startswith("res2.") and s["name"].endswith((".conv1", ".conv2")))
-               and not s["name"].startswith(("rpn.heads", "box.predictor", "stem.conv1"))]
-        fl = sum(s["flops"] * s["calls"] for s in big)
-        ms = sum(s["ms_total"] for s in big)
-        nlaunch = sum(s["calls"] for s in big)
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # group the GEMM stages by the kernel symbol (tile variant) they launched; the dominant kernel is the
+        # one with the largest share of the step
+        groups = {}
+        for s in conv:
+            g = groups.setdefault(s["kernel"] or "?", {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            g["ms"] += s["ms_total"]
+            g["flops"] += s["flops"] * s["calls"]
+            g["bytes"] += s["bytes"] * s["calls"]
+            g["launches"] += s["calls"]
+        dom = max(groups, key=lambda k: groups[k]["ms"])
+        G = groups[dom]
+        achieved = G["flops"] / (G["ms"] * 1e-3) / 1e12 if G["ms"] > 0 else 0.0
         total_flops_step = sum(s["flops"] for s in conv)
-        alg_bytes = sum(s["bytes"] * s["calls"] for s in big) / max(nlaunch, 1)
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")     # written by tools/pmc_summary.py from two --pmc passes
         if os.path.exists(pmc) and B == 16 and T == 512:
+            want = dom.split(">")[0].replace("conv_igemm_kernel<", "").replace(",", ", ")      # "2, 4, 4, 8"
             for k in json.load(open(pmc)):
-                if "conv_igemm_kernel<2, 2, 4, 4, false, true>" in k["kernel"]:
-                    traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; (2*FETCH+WRITE)*1024)"
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<2,2,4,4> (128x128 tile, fp16 MFMA 16x16x32)",
+                if f"conv_igemm_kernel<{want}, false, true>" in k["kernel"]:
+                    traffic = k["hbm_bytes_per_launch_corrected"]
+                    traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, (2*FETCH+WRITE)*1024 per launch"
+        roofline = {"bound": "mfma", "kernel": dom + " (fp16 MFMA 16x16x32, fp32 accumulate)",
                     "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch_avg": alg_bytes, "launches": nlaunch, "avg_launch_ms": ms / max(nlaunch, 1),
-                    "flops_per_launch_avg": fl / max(nlaunch, 1), "share_of_step_time": ms / tot_ms if tot_ms else None,
-                    "whole_path_tflops": total_flops_step * args.steps * world / dt / 1e12}
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch_avg": G["bytes"] / max(G["launches"], 1), "launches": G["launches"],
+                    "avg_launch_ms": G["ms"] / max(G["launches"], 1), "flops_per_launch_avg": G["flops"] / max(G["launches"], 1),
+                    "share_of_step_time": G["ms"] / tot_ms if tot_ms else None,
+                    "whole_path_tflops": total_flops_step * args.steps * world / dt / 1e12,
+                    "other_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0,
+                                          "share_of_step_time": v["ms"] / tot_ms if tot_ms else None, "launches": v["launches"]}
+                                      for k, v in groups.items() if k != dom}}
         if args.stages:
             print(f"{'stage':28s} {'ms/call':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}", file=sys.stderr)
             for s in stages:

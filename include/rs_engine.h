@@ -116,6 +116,8 @@ int rs_engine_stage_count(rs_engine* e);
  * flops = algorithmic FLOPs of one call at the last batch size (0 for non-GEMM stages),
  * bytes = algorithmic HBM bytes of one call (inputs read once + outputs written once). */
 int rs_engine_stage_info(rs_engine* e, int i, char* name_out, double* ms_total, int* calls, double* flops, double* bytes);
+/* Kernel symbol (tile variant) the stage's last call launched, "" for non-GEMM stages. name_out: >= 96 bytes. */
+int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out);
 
 /* Intermediate tensors by name (parity tests): device pointer, dtype (1 f16, 2 f32, 3 i32, 4 u8),
  * up to 5 dims (dims[ndim..] = 1) and the spatial halo of NHWC activations. */

@@ -73,6 +73,7 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant /* -1 auto */, int use_glds);
+extern thread_local int g_last_conv_variant;
 
 // ------------------------------------------------------------------ tile ingest / pooling
 struct PreprocParams {

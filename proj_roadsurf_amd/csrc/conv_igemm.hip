@@ -364,9 +364,13 @@ int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
 
 }  // namespace
 
-// variant: 0 = 128x128, 1 = 256x64, 2 = 256x16 (small heads), -1 = choose
+// Tile variant picked by the most recent launch_conv() on this thread (-1 = fp32 validation kernel);
+// the engine tags its stages with it so that bench.py can attribute time and FLOPs per kernel symbol.
+thread_local int g_last_conv_variant = -2;
+
+// variant: 0 = 128x128, 1 = 256x64, 2 = 256x16 (small heads), 3 = 256x128, 4 = 256x256, -1 = choose
 int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, int use_glds) {
-  if (use_glds < 0) return launch_conv_f32(p_in, stream);   // fp32 validation mode (ref_f32.hip)
+  if (use_glds < 0) { g_last_conv_variant = -1; return launch_conv_f32(p_in, stream); }   // fp32 validation mode (ref_f32.hip)
   ConvParams p = p_in;
   {
     // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second
@@ -398,11 +402,12 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     const int nk = smallc ? 0 : p.KH * p.KW * (p.Cin >> 6);
     if (big && v == 0 && p.mode == 0 && nk >= 8 && p.M >= 16384) {
       if (big == 4 && rows % 256 == 0) v = 4;
-      else v = 3;
+      else if (big == 3) v = 3;            // 256x128 was measured slower than 128x128 everywhere: experiments only
     }
   }
   RS_CHECK(!(p.mode != 0 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
   RS_CHECK(!(p.mode == 2 && !(p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && v == 0)), RS_ERR_ARG, "fused mask predictor needs its pointers and the 128x128 tile");
+  g_last_conv_variant = smallc ? 5 : v;
   if (smallc) {
     RS_CHECK(v == 1, RS_ERR_ARG, "conv: small-Cin path is built for the 256x64 tile only (Cout=%d)", p.Cout);
     return launch_variant<4, 1, 4, 4, true>(p, stream, use_glds);

@@ -51,6 +51,7 @@ struct Stage {
   double ms_total = 0;
   int calls = 0;
   double last_flops = 0, last_bytes = 0;
+  int variant = -2;      // conv tile variant of the last call (-2 = not a conv stage)
 };
 
 struct BlobEntry { const void* host; void* dev; int dtype; int ndim; int64_t dims[4]; size_t nbytes; };
@@ -757,8 +758,10 @@ int rs_engine::run_stages(int n, bool record) {
     const bool pooled = record && profiling >= 2 && ev_used < ev_pool.size();
     if (record && profiling == 1) RS_HIP(hipEventRecord(ev0, stream));
     if (pooled) RS_HIP(hipEventRecord(ev_pool[ev_used].first, stream));
+    g_last_conv_variant = -2;
     int rc = st.fn(n, stream);
     if (rc) return rc;
+    st.variant = g_last_conv_variant;
     if (pooled) {
       RS_HIP(hipEventRecord(ev_pool[ev_used].second, stream));
       ev_stage[ev_used] = (int)si;
@@ -968,6 +971,17 @@ int rs_engine_stage_info(rs_engine* e, int i, char* name_out, double* ms_total, 
   if (calls) *calls = s.calls;
   if (flops) *flops = s.last_flops;
   if (bytes) *bytes = s.last_bytes;
+  return RS_OK;
+}
+
+int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
+  RS_CHECK(e && i >= 0 && i < (int)e->stages.size() && name_out, RS_ERR_ARG, "stage index");
+  static const char* names[] = {"conv_igemm_kernel<2,2,4,4> 128x128", "conv_igemm_kernel<4,1,4,4> 256x64", "conv_igemm_kernel<4,1,1,4> 256x16 f32-out",
+                                "conv_igemm_kernel<4,2,4,4> 256x128", "conv_igemm_kernel<2,4,4,8> 256x256", "conv_igemm_kernel<4,1,4,4,smallC> 256x64 stem"};
+  const int v = e->stages[i].variant;
+  const char* s = v == -1 ? "conv_f32_kernel" : (v >= 0 && v <= 5 ? names[v] : "");
+  strncpy(name_out, s, 95);
+  name_out[95] = 0;
   return RS_OK;
 }
 

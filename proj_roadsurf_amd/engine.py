@@ -77,6 +77,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_set_profiling.argtypes = [vp, i32]
     lib.rs_engine_stage_count.argtypes = [vp]
     lib.rs_engine_stage_info.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_double), i32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.rs_engine_stage_kernel.argtypes = [vp, i32, C.c_char_p]
     lib.rs_engine_tensor.argtypes = [vp, C.c_char_p, C.POINTER(vp), i32p, i32p, C.POINTER(C.c_int64), i32p]
     lib.rs_engine_tensor_count.argtypes = [vp]
     lib.rs_engine_tensor_name.argtypes = [vp, i32, C.c_char_p]
@@ -331,7 +332,10 @@ class Engine:
         ms, fl, by, calls = C.c_double(), C.c_double(), C.c_double(), C.c_int32()
         for i in range(self.lib.rs_engine_stage_count(self._h)):
             self.lib.rs_engine_stage_info(self._h, i, name, C.byref(ms), C.byref(calls), C.byref(fl), C.byref(by))
-            out.append({"name": name.value.decode(), "ms_total": ms.value, "calls": calls.value, "flops": fl.value, "bytes": by.value})
+            kn = C.create_string_buffer(96)
+            self.lib.rs_engine_stage_kernel(self._h, i, kn)
+            out.append({"name": name.value.decode(), "ms_total": ms.value, "calls": calls.value, "flops": fl.value, "bytes": by.value,
+                        "kernel": kn.value.decode()})
         return out
 
     def close(self) -> None:
