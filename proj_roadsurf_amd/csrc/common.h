@@ -78,7 +78,7 @@ extern thread_local int g_last_conv_variant;
 // ------------------------------------------------------------------ tile ingest / pooling
 struct PreprocParams {
   const uint8_t* tiles;   // [N][H][W][C] uint8, channel order as cv2.imread (BGR)
-  half_t* out;            // [N][Hp+6][Wp+6][8] fp16, halo 3
+  half_t* out;            // [N][Hp+6][Wp+6][4] fp16, halo 3
   const int* hb;          // [new_w][2]  (first source column, tap count)
   const int* hk;          // [new_w][ksh] Pillow fixed-point coefficients (22 bit)
   const int* vb;          // [new_h][2]

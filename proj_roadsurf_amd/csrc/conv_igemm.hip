@@ -386,7 +386,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
   RS_CHECK(p.Kpad % 64 == 0, RS_ERR_ARG, "conv: Kpad %d not a multiple of 64", p.Kpad);
   const bool smallc = p.Cin < 64;
   if (smallc) {
-    RS_CHECK(p.Cin == 8 && p.koff != nullptr, RS_ERR_ARG, "conv: small-Cin path needs Cin == 8 and a koff table");
+    RS_CHECK((p.Cin == 8 || p.Cin == 4) && p.koff != nullptr, RS_ERR_ARG, "conv: small-Cin path needs Cin 4 or 8 and a koff table");
   } else {
     RS_CHECK(p.Cin % 64 == 0, RS_ERR_ARG, "conv: Cin %d not a multiple of 64", p.Cin);
     RS_CHECK(p.KH * p.KW * p.Cin <= p.Kpad, RS_ERR_ARG, "conv: K exceeds Kpad");

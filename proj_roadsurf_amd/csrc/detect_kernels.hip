@@ -759,30 +759,34 @@ __global__ __launch_bounds__(256) void mask_sigmoid_kernel(const MaskPredictPara
 // paste_masks_in_image: one thread = 8 horizontally adjacent output pixels = one output byte
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
+  // one thread = one 32-bit word = 32 horizontally adjacent output pixels (4 output bytes, one dword store)
   const int total = *p.n_entries;
-  const int Wb = (p.out_w + 7) >> 3;
+  const int Wb = (p.out_w + 7) >> 3;          // bytes per output row
+  const int Ww = (Wb + 3) >> 2;               // words per output row
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long per = (long long)p.out_h * Wb;
+  const long long per = (long long)p.out_h * Ww;
   if (gid >= (long long)total * per) return;
   const int entry = (int)(gid / per);
   const int rem = (int)(gid - (long long)entry * per);
-  const int y = rem / Wb, xb = rem - y * Wb;
+  const int y = rem / Ww, xw = rem - y * Ww;
   const int slot = p.slot_list[entry];
   const float* bx = p.det_boxes + (long long)slot * 4;
   const float x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
   const float* m = p.probs + (long long)slot * p.S * p.S;
   const int S = p.S;
-  unsigned int byte = 0;
+  unsigned int word = 0;
   // img_y = (y + 0.5 - y0) / (y1 - y0) * 2 - 1 ; iy = ((img_y + 1) * S - 1) / 2
   const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.f - 1.f;
   const float iy = ((gy + 1.f) * (float)S - 1.f) / 2.f;
   const float fy = floorf(iy);
   const int iy0 = (int)fy, iy1 = iy0 + 1;
   const float wy1 = iy - fy, wy0 = 1.f - wy1;
-  if (iy1 >= 0 && iy0 < S) {
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int x = xb * 8 + b;
+  // conservative column range that can sample inside the SxS map (one mask texel of margin on both sides)
+  const float margin = fabsf(x1 - x0) / (float)S + 1.f;
+  const int xa = xw * 32, xz = xa + 31;
+  if (iy1 >= 0 && iy0 < S && (float)xz + 0.5f >= fminf(x0, x1) - margin && (float)xa + 0.5f <= fmaxf(x0, x1) + margin) {
+    for (int b = 0; b < 32; ++b) {
+      const int x = xa + b;
       if (x >= p.out_w) break;
       const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
       const float ix = ((gx + 1.f) * (float)S - 1.f) / 2.f;
@@ -795,10 +799,15 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
       if (iy0 >= 0 && ix1 < S) v += m[iy0 * S + ix1] * (wx1 * wy0);
       if (iy1 < S && ix0 >= 0) v += m[iy1 * S + ix0] * (wx0 * wy1);
       if (iy1 < S && ix1 < S) v += m[iy1 * S + ix1] * (wx1 * wy1);
-      if (v >= p.threshold) byte |= 1u << b;
+      if (v >= p.threshold) word |= 1u << b;
     }
   }
-  p.out[(long long)slot * per + rem] = (uint8_t)byte;
+  uint8_t* o = p.out + (long long)slot * p.out_h * Wb + (long long)y * Wb + xw * 4;
+  if ((Wb & 3) == 0) {
+    *(unsigned int*)o = word;
+  } else {
+    for (int k = 0; k < 4 && xw * 4 + k < Wb; ++k) o[k] = (uint8_t)(word >> (8 * k));
+  }
 }
 
 }  // namespace
@@ -890,7 +899,7 @@ int launch_mask_sigmoid(const MaskPredictParams& p, int capacity_entries, hipStr
 }
 
 int launch_paste_masks(const PasteParams& p, int capacity_entries, hipStream_t s) {
-  const long long total = (long long)capacity_entries * p.out_h * ((p.out_w + 7) >> 3);
+  const long long total = (long long)capacity_entries * p.out_h * ((((p.out_w + 7) >> 3) + 3) >> 2);
   hipLaunchKernelGGL(paste_masks_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;

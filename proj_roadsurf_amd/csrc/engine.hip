@@ -252,10 +252,18 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
   RS_CHECK((out.H - 1) * stride + k - 2 * pad <= in.H + (stride - 1), RS_ERR_ARG, "%s: geometry", name.c_str());
   if (res) RS_CHECK(res->H == out.H && res->W == out.W && res->C == out.C && res->pad == out.pad, RS_ERR_ARG, "%s: residual geometry", name.c_str());
   if (in.C < 64) {
-    // small-Cin (stem) path: per-16-byte-chunk element offsets, one tap per chunk
-    RS_CHECK(in.C == 8, RS_ERR_UNSUPPORTED, "%s: Cin %d", name.c_str(), in.C);
+    // small-Cin (stem) path: per-16-byte-chunk element offsets.  C == 8: one tap per chunk.  C == 4: the tap row
+    // is padded to 8 taps (the 8th has zero weights) and a chunk holds two horizontally adjacent taps, so
+    // K = kh*8*4 = 224 -> 256 instead of 49*8 = 392 -> 448.
+    RS_CHECK(in.C == 8 || in.C == 4, RS_ERR_UNSUPPORTED, "%s: Cin %d", name.c_str(), in.C);
     std::vector<int> koff(p.Kpad / 8, 0);
-    for (int t = 0; t < k * k && t < (int)koff.size(); ++t) koff[t] = ((t / k) * p.in_Wp + (t % k)) * in.C;
+    if (in.C == 8) {
+      for (int t = 0; t < k * k && t < (int)koff.size(); ++t) koff[t] = ((t / k) * p.in_Wp + (t % k)) * in.C;
+    } else {
+      RS_CHECK(k == 7 && (p.in_Wp & 1) == 0 && ((in.pad - pad) & 1) == 0 && stride == 2, RS_ERR_UNSUPPORTED, "%s: C=4 stem needs 7x7 s2 and even pitch", name.c_str());
+      p.KW = 8;
+      for (int t = 0; t < k * 4 && t < (int)koff.size(); ++t) koff[t] = ((t / 4) * p.in_Wp + (t % 4) * 2) * in.C;
+    }
     int* d = nullptr;
     int rc = alloc((void**)&d, koff.size() * 4);
     if (rc) return rc;
@@ -320,14 +328,14 @@ int rs_engine::build() {
     pp.hb = dhb; pp.hk = dhk; pp.vb = dvb; pp.vk = dvk; pp.ksh = ksh; pp.ksv = ksv;
   }
   Act x0;
-  if ((rc = new_act(&x0, "net_input", NB, pad_h, pad_w, 8, 3))) return rc;
+  if ((rc = new_act(&x0, "net_input", NB, pad_h, pad_w, 4, 3))) return rc;
   pp.out = x0.p; pp.H = tile_h; pp.W = tile_w; pp.C = tile_c; pp.new_h = net_h; pp.new_w = net_w;
   pp.out_Hp = x0.Hp(); pp.out_Wp = x0.Wp(); pp.flip = S.flip_channels; pp.out_f32 = f32 ? 1 : 0;
   for (int c = 0; c < 4; ++c) { pp.mean[c] = S.pixel_mean[c]; pp.stdv[c] = S.pixel_std[c] == 0.f ? 1.f : S.pixel_std[c]; }
   {
     Stage st;
     st.name = "preprocess";
-    st.bytes_per_image = (double)tile_h * tile_w * tile_c + (double)net_h * net_w * 16;
+    st.bytes_per_image = (double)tile_h * tile_w * tile_c + (double)net_h * net_w * 8;
     pp.tiles = tiles_dev;
     st.fn = [pp](int n, hipStream_t s) mutable {
       pp.N = n;

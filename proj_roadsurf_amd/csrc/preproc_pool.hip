@@ -6,7 +6,7 @@
 //    BGR->RGB flip, Pillow's 2-pass fixed-point bilinear resize (uint8 rounding between the
 //    passes, antialiased when shrinking -- coefficient tables come from the host, bit-exact with
 //    Pillow's precompute_coeffs/normalize_coeffs_8bpc), (x-mean)/std, fp16 NHWC with the channel
-//    dim padded to 8 and a 3-pixel zero halo for the 7x7 stem.
+//    dim padded to 4 (8 bytes per pixel) and a 3-pixel zero halo for the 7x7 stem.
 //  * maxpool3x3s2_kernel: stem max_pool2d(3, 2, 1) [EXT d2: modeling/backbone/resnet.py BasicStem].
 //    The input is post-ReLU (>= 0), so the zero halo is equivalent to -inf padding.
 //  * subsample2_kernel: LastLevelMaxPool = max_pool2d(k=1, s=2) [EXT d2: modeling/backbone/fpn.py].
@@ -24,10 +24,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) 
   if (p.need_v) { ymin = p.vb[Y * 2]; ny = p.vb[Y * 2 + 1]; }
   if (p.need_h) { xmin = p.hb[X * 2]; nx = p.hb[X * 2 + 1]; }
   const uint8_t* img = p.tiles + (long long)n * p.H * p.W * p.C;
-  half8 o;
-  float of[8];
+  half4 o;
+  float of[4];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { o[c] = (half_t)0.f; of[c] = 0.f; }
+  for (int c = 0; c < 4; ++c) { o[c] = (half_t)0.f; of[c] = 0.f; }
   for (int c = 0; c < p.C; ++c) {
     const int cs = p.flip ? (p.C - 1 - c) : c;
     int vacc = 1 << 21;
@@ -54,13 +54,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) 
     o[c] = (half_t)f;
     of[c] = f;
   }
-  const long long oidx = (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 8;
+  const long long oidx = (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 4;
   if (p.out_f32) {
-    float* dst = (float*)p.out + oidx;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) dst[c] = of[c];
+    *(f32x4*)((float*)p.out + oidx) = f32x4{of[0], of[1], of[2], of[3]};
   } else {
-    *(half8*)(p.out + oidx) = o;
+    *(half4*)(p.out + oidx) = o;
   }
 }
 

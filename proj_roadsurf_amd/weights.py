@@ -26,7 +26,8 @@ BLOB_VERSION = 1
 DT_F16, DT_F32, DT_I32 = 1, 2, 3
 ALIGN = 256
 K_ALIGN = 64          # GEMM K padding (elements) -- one LDS K-step of the conv kernel
-STEM_CIN_PAD = 8      # stem input channels padded to one 16-byte chunk
+STEM_CIN_PAD = 4      # stem input channels padded to 4 (8 bytes per pixel)
+STEM_KW_PAD = 8       # stem tap rows padded 7 -> 8 so that a 16-byte chunk = two adjacent taps (the 8th has zero weights)
 
 
 # ----------------------------------------------------------------------------- topology
@@ -202,8 +203,12 @@ def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], w_dtype=np.float1
             w, b = _fold_bn(W, name, spec.bn_eps)
         else:
             w, b = W[name + ".weight"].astype(np.float32), W[name + ".bias"].astype(np.float32)
-        cin_pad = STEM_CIN_PAD if name.endswith("stem.conv1") else cin
-        T[name + ".w"] = _ohwi(w, cin_pad, w_dtype)
+        if name.endswith("stem.conv1"):
+            wpad = np.zeros(w.shape[:3] + (STEM_KW_PAD,), np.float32)
+            wpad[..., : w.shape[3]] = w
+            T[name + ".w"] = _ohwi(wpad, STEM_CIN_PAD, w_dtype)
+        else:
+            T[name + ".w"] = _ohwi(w, cin, w_dtype)
         T[name + ".b"] = b.astype(np.float32)
     # RPN heads fused into one 1x1 conv: rows [0,A) objectness, [A,5A) deltas (a*4+d), padded to 16
     p = "proposal_generator.rpn_head."

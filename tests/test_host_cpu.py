@@ -113,8 +113,10 @@ def test_pack_weights_blob_roundtrip_and_bn_fold():
     assert np.array_equal(back, want)
     bias = T[p + ".b"]
     assert np.allclose(bias, W[p + ".norm.bias"] - W[p + ".norm.running_mean"] * scale)
-    # stem: Cin padded 3 -> 8, K padded to a multiple of 64
-    assert T["backbone.bottom_up.stem.conv1.w"].shape == (64, 448)
+    # stem: Cin padded 3 -> 4, tap rows 7 -> 8 (two taps per 16-byte chunk): K = 7*8*4 = 224 -> 256
+    assert T["backbone.bottom_up.stem.conv1.w"].shape == (64, 256)
+    st = T["backbone.bottom_up.stem.conv1.w"].astype(np.float32).reshape(64, 8, 8, 4)[:, :7]
+    assert not st[:, :, 7].any() and not st[..., 3].any()
     # fc1 K-axis permuted to (h, w, c)
     fc1 = T["roi_heads.box_head.fc1.w"].astype(np.float32)
     src = W["roi_heads.box_head.fc1.weight"].reshape(1024, 256, 7, 7)
