@@ -69,6 +69,7 @@ struct ConvParams {
   const int* dot_cls;   // mode 2: [slots] predicted class
   const int* dot_slot;  // mode 2: [entries] entry -> slot
   float* dot_out;       // mode 2: [slots][2*Ho][2*Wo] logits (without bias), zeroed by the caller
+  int persist;          // >0: persistent launch with this many workgroups per CU; -1: per-variant default; 0: one per tile
   int stages;           // LDS K-step buffers: 0/2 = double buffered, 1 = single (set by launch_conv for shallow K)
 };
 

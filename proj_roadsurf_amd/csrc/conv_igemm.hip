@@ -37,7 +37,7 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int WPX, int WCH, int MI, int NJ, bool SMALLC, bool GLDS>
+template <int WPX, int WCH, int MI, int NJ, bool SMALLC, bool GLDS, bool PERSIST>
 __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvParams p) {
   using T = Tile<WPX, WCH, MI, NJ>;
   constexpr int NW = T::NW, BM = T::BM, BN = T::BN;
@@ -55,47 +55,51 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     long long mc = (long long)(*p.m_count) * p.m_mul;
     if (mc < M) M = (int)mc;
   }
-  // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of
-  // logical tiles, channel tiles fastest, so the tiles that re-read one activation panel (other
-  // channel tile, neighbouring rows of a 3x3) hit the same L2.
+  // Tiles are walked in a grid-stride loop: launched with one workgroup per tile it runs once; launched
+  // "persistent" (fewer workgroups than tiles) a workgroup streams through tiles q, q+G, q+2G ... and the
+  // operands of the NEXT tile's first K step are already in flight while the current tile's epilogue
+  // (residual reads, stores) runs -- that overlap is what the HBM-bound shallow-K layers lack otherwise.
   const int tiles_n = (p.Cout * (p.mode != 0 ? 4 : 1) + BN - 1) / BN;
-  const int nblk = gridDim.x;
-  int L;
-  {
-    const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7;
-    L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-  }
-  const int tile_n = L % tiles_n;
-  const int tile_m = L / tiles_n;
-  const int m0 = tile_m * BM;
-  const int n0 = tile_n * BN;
-  if (m0 >= M) return;
+  const int ntiles = tiles_n * ((M + BM - 1) / BM);
+  const int G = gridDim.x;
+  int q = blockIdx.x;
+  if (q >= ntiles) return;
 
-  // ---- per-lane staging source pointers -------------------------------------------------
   const int lrow = lane >> 3;      // row inside an 8-row glds piece
   const int lchk = lane & 7;       // 16-byte slot inside the 128-byte LDS row
   const half_t* aptr[PA];
-#pragma unroll
-  for (int ps = 0; ps < PA; ++ps) {
-    int m = m0 + ps * NW * 8 + wave * 8 + lrow;
-    if (m >= M) m = M - 1;
-    const int x = m % p.Wo;
-    const int t = m / p.Wo;
-    const int y = t % p.Ho;
-    const int n = t / p.Ho;
-    const long long base =
-        ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x * p.stride + p.in_off) * p.in_Cs;
-    // LDS slot lchk of row r holds data chunk (lchk ^ (r & 7)); r & 7 == lrow here.
-    aptr[ps] = p.in + base + (SMALLC ? 0 : ((lchk ^ lrow) * 8));
-  }
   const half_t* wptr[PW];
+  int m0 = 0, n0 = 0;
+  // XCD-aware tile order: positions q and q+8 share an XCD (L2); each XCD gets a contiguous run of logical
+  // tiles, channel tiles fastest, so tiles that re-read one activation panel hit the same L2.
+  auto setup_tile = [&](int qq) {
+    const int qn = ntiles >> 3, r = ntiles & 7, x = qq & 7;
+    const int L = (x < r ? x * (qn + 1) : r * (qn + 1) + (x - r) * qn) + (qq >> 3);
+    const int tile_n = L % tiles_n;
+    const int tile_m = L / tiles_n;
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
 #pragma unroll
-  for (int ps = 0; ps < PW; ++ps) {
-    const int row = ps * NW * 8 + wave * 8 + lrow;
-    const int key = (row & 3) | (((row / (4 * MI)) & 1) << 2);
-    const int rr = row < BN ? row : BN - 1;
-    wptr[ps] = p.w + (long long)(n0 + rr) * p.Kpad + (lchk ^ key) * 8;
-  }
+    for (int ps = 0; ps < PA; ++ps) {
+      int m = m0 + ps * NW * 8 + wave * 8 + lrow;
+      if (m >= M) m = M - 1;
+      const int x2 = m % p.Wo;
+      const int t = m / p.Wo;
+      const int y = t % p.Ho;
+      const int n = t / p.Ho;
+      const long long base =
+          ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x2 * p.stride + p.in_off) * p.in_Cs;
+      // LDS slot lchk of row r holds data chunk (lchk ^ (r & 7)); r & 7 == lrow here.
+      aptr[ps] = p.in + base + (SMALLC ? 0 : ((lchk ^ lrow) * 8));
+    }
+#pragma unroll
+    for (int ps = 0; ps < PW; ++ps) {
+      const int row = ps * NW * 8 + wave * 8 + lrow;
+      const int key = (row & 3) | (((row / (4 * MI)) & 1) << 2);
+      const int rr = row < BN ? row : BN - 1;
+      wptr[ps] = p.w + (long long)(n0 + rr) * p.Kpad + (lchk ^ key) * 8;
+    }
+  };
 
   const int nk = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> 6));
   const int nst = p.stages == 1 ? 1 : 2;   // LDS K-step buffers: 1 = shallow-K layers (more workgroups per CU)
@@ -137,12 +141,6 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     }
   };
 
-  f32x4 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   // ---- fragment read offsets (bytes inside a stage) ---------------------------------------
   const int fi = lane & 15;        // MFMA row (weights) / column (pixels) index of this lane
   const int fq = lane >> 4;        // k-slice of this lane
@@ -158,7 +156,6 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   const int c0_off = ((fq) ^ fkey) * 16;        // kk = 0
   const int c1_off = ((4 + fq) ^ fkey) * 16;    // kk = 1
 
-  // ---- K loop ------------------------------------------------------------------------------
   int kh = 0, kw = 0, c0 = 0;   // position of the NEXT K step to stage
   auto next_off = [&]() {
     const int off = (kh * p.in_Wp + kw) * p.in_Cs + c0;
@@ -169,176 +166,238 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     }
     return off;
   };
+
+  setup_tile(q);
   stage(0, 0, SMALLC ? 0 : next_off());
-
-  // (Fetching the residual tile here, together with the operands, was tried for the shallow-K layers: no
-  //  gain -- those layers sit at ~3.3 TB/s regardless -- and it costs 32-64 VGPRs.)
-  const int ch_local = wch * MI * 16 + fq * 4 * MI;
-  const int crow = n0 + ch_local;                 // row in the (possibly 4x grouped) weight matrix
-  int g = 0, cb = crow;
-  if (p.mode != 0) { g = crow / p.Cout; cb = crow % p.Cout; }
-
+  int gs = 0;                    // running K-step count: LDS buffer of step gs is (gs & 1) when double buffered
+  constexpr int STORES_F16 = MI % 2 == 0 ? MI / 2 : MI;   // store instructions per pixel of the fp16 epilogue
+  constexpr int STORES_F32 = MI;                          // ... of the fp32-out epilogue
+  int stores_in_flight = 0;      // stores this wave issued in the previous tile's epilogue (0 = unknown / first tile)
   // (256x256 tile: issuing the next step's LDS-DMA pieces between the MFMA groups with sched_group_barrier was
-  //  tried and measured 1-6 % slower than issuing them right after the barrier.)
-  for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nst == 2 && t + 1 < nk) stage((t + 1) & 1, t + 1, SMALLC ? 0 : next_off());
-    const char* sb = smem + (nst == 2 ? (t & 1) : 0) * T::STAGE;
-    if constexpr (NJ == 8) {
-      // 8 waves in lockstep behind one barrier: all of them read fragments at the same time, so the second
-      // half-step's fragments are requested before the first half-step's MFMAs instead of after them.
-      half8 wf0[MI], xf0[NJ], wf1[MI], xf1[NJ];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) wf0[i] = *(const half8*)(sb + w_off[i] + c0_off);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) xf0[j] = *(const half8*)(sb + x_off[j] + c0_off);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) wf1[i] = *(const half8*)(sb + w_off[i] + c1_off);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) xf1[j] = *(const half8*)(sb + x_off[j] + c1_off);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
-    } else
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int co = kk ? c1_off : c0_off;
-      half8 wf[MI], xf[NJ];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) wf[i] = *(const half8*)(sb + w_off[i] + co);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) xf[j] = *(const half8*)(sb + x_off[j] + co);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
-    if (nst == 1 && t + 1 < nk) {
-      __syncthreads();                               // everyone done reading the only buffer
-      stage(0, t + 1, SMALLC ? 0 : next_off());
-    }
-  }
-
-  // ---- epilogue: lane holds channels cb .. cb+4*MI-1 of pixel (nj, fi) ------------------------
-  float bias[4 * MI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
-    bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
-  }
-  float dotp[NJ];
-  long long dot_idx[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) { dotp[j] = 0.f; dot_idx[j] = -1; }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int m = m0 + wpx * NJ * 16 + j * 16 + fi;
-    if (m >= M) continue;
-    const int x = m % p.Wo;
-    const int t = m / p.Wo;
-    const int y = t % p.Ho;
-    const int n = t / p.Ho;
-    int oy = y, ox = x;
-    if (p.mode != 0) { oy = 2 * y + (g >> 1); ox = 2 * x + (g & 1); }
-    const long long opix = (long long)(n * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad;
-    float v[4 * MI];
+  //  tried and measured 1-6 % slower than issuing them right after the barrier.  Fetching the residual tile
+  //  together with the operands was tried too: no gain, 32-64 VGPRs.)
+  while (true) {
+    const int m0c = m0, n0c = n0;      // the tile being computed (setup_tile() below moves m0/n0 to the next one)
+    f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
-    if (p.res) {
-      const half_t* rp = p.res + opix * p.out_Cs + cb;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const half4 h = *(const half4*)(rp + i * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nk; ++t) {
+      if (PERSIST && t == 0 && stores_in_flight) {
+        // Follow-on tile of a persistent workgroup: the previous tile's epilogue stores are the YOUNGEST
+        // vector-memory operations of this wave and need not be waited for; everything older (the prefetched
+        // operands of this tile) must have landed.  vmcnt counts loads, stores and LDS-DMA in issue order, so a
+        // counted wait does exactly that.  __syncthreads() would drain the stores (its fence waits vmcnt(0)),
+        // hence the raw barrier.
+        if (stores_in_flight == NJ * STORES_F16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ * STORES_F16) : "memory");
+        else if (stores_in_flight == NJ * STORES_F32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ * STORES_F32) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
       }
-    }
-    if (p.up) {
-      const long long upix = (long long)(n * p.up_Hp + (y >> 1) + p.up_pad) * p.up_Wp + (x >> 1) + p.up_pad;
-      const half_t* up = p.up + upix * p.up_Cs + cb;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const half4 h = *(const half4*)(up + i * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
-      }
-    }
-    if (p.relu) {
-#pragma unroll
-      for (int e = 0; e < 4 * MI; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-    }
-    if (p.mode == 2) {
-      // fused mask predictor: partial dot product of this lane's 4*MI channels with the predicted class' weights
-      const int slot = p.dot_slot[n];
-      const float* wv = p.dot_w + (long long)p.dot_cls[slot] * p.Cout + cb;
-      float sdot = 0.f;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const f32x4 w4 = *(const f32x4*)(wv + i * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sdot += v[i * 4 + r] * w4[r];
-      }
-      dotp[j] = sdot;
-      dot_idx[j] = (long long)slot * (4 * p.Ho * p.Wo) + (long long)oy * (2 * p.Wo) + ox;
-    } else if (p.out_f32) {
-      float* op = (float*)p.out + opix * p.out_Cs + cb;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) *(f32x4*)(op + i * 4) = f32x4{v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
-    } else {
-      half_t* op = (half_t*)p.out + opix * p.out_Cs + cb;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        half4 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float f = v[i * 4 + r];
-          f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
-          h[r] = (half_t)f;
+      if (nst == 2) {
+        if (t + 1 < nk) {
+          stage((gs + 1) & 1, t + 1, SMALLC ? 0 : next_off());
+        } else if (PERSIST && q + G < ntiles) {     // last K step of this tile: start on the next tile
+          setup_tile(q + G);
+          kh = 0; kw = 0; c0 = 0;
+          stage((gs + 1) & 1, 0, SMALLC ? 0 : next_off());
         }
-        *(half4*)(op + i * 4) = h;
       }
+      const char* sb = smem + (nst == 2 ? (gs & 1) : 0) * T::STAGE;
+      if constexpr (NJ == 8) {
+        // 8 waves in lockstep behind one barrier: all of them read fragments at the same time, so the second
+        // half-step's fragments are requested before the first half-step's MFMAs instead of after them.
+        half8 wf0[MI], xf0[NJ], wf1[MI], xf1[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) wf0[i] = *(const half8*)(sb + w_off[i] + c0_off);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xf0[j] = *(const half8*)(sb + x_off[j] + c0_off);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) wf1[i] = *(const half8*)(sb + w_off[i] + c1_off);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xf1[j] = *(const half8*)(sb + x_off[j] + c1_off);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int co = kk ? c1_off : c0_off;
+          half8 wf[MI], xf[NJ];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) wf[i] = *(const half8*)(sb + w_off[i] + co);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) xf[j] = *(const half8*)(sb + x_off[j] + co);
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (nst == 1 && t + 1 < nk) {
+        __syncthreads();                               // everyone done reading the only buffer
+        stage(0, t + 1, SMALLC ? 0 : next_off());
+      }
+      ++gs;
     }
-  }
-  if (p.mode == 2) {
-    // Reduce the per-lane partials to one value per output pixel in a FIXED order (bitwise reproducible):
-    // lanes of one pixel (k-slices fq = 0..3) by shuffles, the WCH channel waves through LDS; the two
-    // channel tiles of a (dy,dx) group live in different workgroups and meet in one float atomicAdd each
-    // on a zero-initialised word -- two addends commute exactly.
-    float* red = (float*)smem;      // [WCH-1][WPX][NJ][16]; the K-loop buffers are dead (all waves passed its last barrier)
-    __syncthreads();
+
+    // ---- epilogue: lane holds channels cb .. cb+4*MI-1 of pixel (nj, fi) ------------------------
+    const int ch_local = wch * MI * 16 + fq * 4 * MI;
+    const int crow = n0c + ch_local;                 // row in the (possibly 4x grouped) weight matrix
+    int g = 0, cb = crow;
+    if (p.mode != 0) { g = crow / p.Cout; cb = crow % p.Cout; }
+    float bias[4 * MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
+      bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
+    }
+    float dotp[NJ];
+    long long dot_idx[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { dotp[j] = 0.f; dot_idx[j] = -1; }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      float v0 = dotp[j];
-      v0 += __shfl_xor(v0, 16);
-      v0 += __shfl_xor(v0, 32);
-      dotp[j] = v0;
-      if (wch > 0 && fq == 0) red[(((wch - 1) * WPX + wpx) * NJ + j) * 16 + fi] = v0;
+      const int m = m0c + wpx * NJ * 16 + j * 16 + fi;
+      if (m >= M) continue;
+      const int x = m % p.Wo;
+      const int t = m / p.Wo;
+      const int y = t % p.Ho;
+      const int n = t / p.Ho;
+      int oy = y, ox = x;
+      if (p.mode != 0) { oy = 2 * y + (g >> 1); ox = 2 * x + (g & 1); }
+      const long long opix = (long long)(n * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad;
+      float v[4 * MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+      if (p.res) {
+        const half_t* rp = p.res + opix * p.out_Cs + cb;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const half4 h = *(const half4*)(rp + i * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+        }
+      }
+      if (p.up) {
+        const long long upix = (long long)(n * p.up_Hp + (y >> 1) + p.up_pad) * p.up_Wp + (x >> 1) + p.up_pad;
+        const half_t* up = p.up + upix * p.up_Cs + cb;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const half4 h = *(const half4*)(up + i * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+        }
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4 * MI; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      if (p.mode == 2) {
+        // fused mask predictor: partial dot product of this lane's 4*MI channels with the predicted class' weights
+        const int slot = p.dot_slot[n];
+        const float* wv = p.dot_w + (long long)p.dot_cls[slot] * p.Cout + cb;
+        float sdot = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const f32x4 w4 = *(const f32x4*)(wv + i * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sdot += v[i * 4 + r] * w4[r];
+        }
+        dotp[j] = sdot;
+        dot_idx[j] = (long long)slot * (4 * p.Ho * p.Wo) + (long long)oy * (2 * p.Wo) + ox;
+      } else if (p.out_f32) {
+        float* op = (float*)p.out + opix * p.out_Cs + cb;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) *(f32x4*)(op + i * 4) = f32x4{v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+      } else {
+        half_t* op = (half_t*)p.out + opix * p.out_Cs + cb;
+        if constexpr (MI % 2 == 0) {
+#pragma unroll
+          for (int i = 0; i < MI; i += 2) {          // one 16-byte store per 8 channels (STORES_F16 per pixel)
+            half8 h;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              float f = v[i * 4 + r];
+              f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+              h[r] = (half_t)f;
+            }
+            *(half8*)(op + i * 4) = h;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float f = v[i * 4 + r];
+              f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+              h[r] = (half_t)f;
+            }
+            *(half4*)(op + i * 4) = h;
+          }
+        }
+      }
     }
-    __syncthreads();
-    if (wch == 0 && fq == 0) {
+    if (p.mode == 2) {
+      // Reduce the per-lane partials to one value per output pixel in a FIXED order (bitwise reproducible):
+      // lanes of one pixel (k-slices fq = 0..3) by shuffles, the WCH channel waves through LDS; the two
+      // channel tiles of a (dy,dx) group live in different workgroups and meet in one float atomicAdd each
+      // on a zero-initialised word -- two addends commute exactly.  (mode 2 is launched one workgroup per
+      // tile, so no next-tile prefetch is in flight into the LDS words used here.)
+      float* red = (float*)smem;      // [WCH-1][WPX][NJ][16]
+      __syncthreads();
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         float v0 = dotp[j];
-#pragma unroll
-        for (int c = 1; c < WCH; ++c) v0 += red[(((c - 1) * WPX + wpx) * NJ + j) * 16 + fi];
-        if (dot_idx[j] >= 0) atomicAdd(p.dot_out + dot_idx[j], v0);
+        v0 += __shfl_xor(v0, 16);
+        v0 += __shfl_xor(v0, 32);
+        dotp[j] = v0;
+        if (wch > 0 && fq == 0) red[(((wch - 1) * WPX + wpx) * NJ + j) * 16 + fi] = v0;
       }
+      __syncthreads();
+      if (wch == 0 && fq == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          float v0 = dotp[j];
+#pragma unroll
+          for (int c = 1; c < WCH; ++c) v0 += red[(((c - 1) * WPX + wpx) * NJ + j) * 16 + fi];
+          if (dot_idx[j] >= 0) atomicAdd(p.dot_out + dot_idx[j], v0);
+        }
+      }
+    }
+
+    // every pixel row of this wave was valid (no `continue` above) => the store count is exact
+    stores_in_flight = (p.mode != 2 && m0c + BM <= M) ? NJ * (p.out_f32 ? STORES_F32 : STORES_F16) : 0;
+    if constexpr (!PERSIST) break;
+    q += G;
+    if (q >= ntiles) break;
+    if (nst == 1) {                    // single buffer: no cross-tile prefetch; restart on the next tile
+      setup_tile(q);
+      kh = 0; kw = 0; c0 = 0;
+      __syncthreads();
+      stage(0, 0, SMALLC ? 0 : next_off());
     }
   }
 }
 
-template <int WPX, int WCH, int MI, int NJ, bool SMALLC>
+template <int WPX, int WCH, int MI, int NJ, bool SMALLC, bool CAN_PERSIST>
 int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
   using T = Tile<WPX, WCH, MI, NJ>;
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
@@ -347,18 +406,31 @@ int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
   const long long nblk = (long long)tiles_n * tiles_m;
   RS_CHECK(nblk > 0 && nblk < (1ll << 31), RS_ERR_ARG, "conv: bad grid %lld", nblk);
   RS_CHECK(rows % T::BN == 0 || T::BN <= 16, RS_ERR_ARG, "conv: Cout rows %d not a multiple of tile %d", rows, T::BN);
-  auto kg = conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, true>;
-  auto kr = conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, false>;
-  auto k = use_glds ? kg : kr;
-  static bool attr_g = false, attr_r = false;
-  bool& done = use_glds ? attr_g : attr_r;
-  if (!done) {
-    RS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS));
-    done = true;
-  }
   const int lds = (p.stages == 1 ? 1 : 2) * T::STAGE + 1024;
-  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), lds, stream, p);
-  RS_HIP(hipGetLastError());
+  // Persistent launch (p.persist = workgroups per CU, -1 = as many as the LDS admits): only with double
+  // buffering, never for the fused-dot mode, and only for the variants instantiated with PERSIST.
+  int bpc = CAN_PERSIST ? p.persist : 0;
+  if (bpc < 0) bpc = (160 * 1024) / lds < 1 ? 1 : (160 * 1024) / lds;
+  const bool persistent = bpc > 0 && p.stages != 1 && p.mode != 2 && use_glds && nblk > 256ll * bpc;
+  const void* k;
+  if constexpr (CAN_PERSIST) {
+    k = persistent ? (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, true, true>
+                   : (use_glds ? (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, true, false>
+                               : (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, false, false>);
+  } else {
+    k = use_glds ? (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, true, false>
+                 : (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, false, false>;
+  }
+  static bool attr[3] = {false, false, false};
+  const int ai = persistent ? 2 : (use_glds ? 1 : 0);
+  if (!attr[ai]) {
+    RS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS));
+    attr[ai] = true;
+  }
+  const unsigned grid = persistent ? 256u * (unsigned)bpc : (unsigned)nblk;
+  ConvParams pc = p;
+  void* args[] = {&pc};
+  RS_HIP(hipLaunchKernel(k, dim3(grid), dim3(T::NT), args, lds, stream));
   return RS_OK;
 }
 
@@ -379,7 +451,17 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     static int nk_single = -1;
     if (nk_single < 0) { const char* e = getenv("RS_CONV_SINGLE_STAGE_NK"); nk_single = e ? atoi(e) : 4; }
     const int nk = p.Cin < 64 ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6);
-    if (p.stages == 0) p.stages = nk <= nk_single ? 1 : 2;
+    // RS_CONV_PERSIST: 0 = one workgroup per tile everywhere (single LDS buffer for shallow K);
+    // (default 0: measured, the persistent form is correct but not faster -- 0.221 vs 0.225 ms on res2 conv3, slower on
+    //  conv1 -- these layers sit at ~3.3 TB/s either way) 1 = shallow-K layers run persistent + double buffered so that the next tile's operands load
+    // during the current tile's epilogue; 2 = every layer persistent.
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("RS_CONV_PERSIST"); persist = e ? atoi(e) : 0; }
+    if (p.stages == 0) {
+      const bool shallow = nk <= nk_single;
+      if (persist >= 1 && shallow && p.mode != 2) { p.stages = 2; p.persist = 2; }
+      else { p.stages = shallow ? 1 : 2; p.persist = persist >= 2 && p.mode != 2 ? -1 : 0; }
+    }
 
   }
   RS_CHECK(p.M > 0, RS_ERR_ARG, "conv: M=%d", p.M);
@@ -410,24 +492,24 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
   g_last_conv_variant = smallc ? 5 : v;
   if (smallc) {
     RS_CHECK(v == 1, RS_ERR_ARG, "conv: small-Cin path is built for the 256x64 tile only (Cout=%d)", p.Cout);
-    return launch_variant<4, 1, 4, 4, true>(p, stream, use_glds);
+    return launch_variant<4, 1, 4, 4, true, false>(p, stream, use_glds);
   }
   switch (v) {
     case 0:
       RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 0 needs Cout %% 128 == 0");
-      return launch_variant<2, 2, 4, 4, false>(p, stream, use_glds);
+      return launch_variant<2, 2, 4, 4, false, true>(p, stream, use_glds);
     case 1:
       RS_CHECK(rows % 64 == 0, RS_ERR_ARG, "conv: variant 1 needs Cout %% 64 == 0");
-      return launch_variant<4, 1, 4, 4, false>(p, stream, use_glds);
+      return launch_variant<4, 1, 4, 4, false, true>(p, stream, use_glds);
     case 2:
       RS_CHECK(rows % 16 == 0 && p.out_f32, RS_ERR_ARG, "conv: variant 2 is the 16-channel-tile fp32-out head kernel");
-      return launch_variant<4, 1, 1, 4, false>(p, stream, use_glds);
+      return launch_variant<4, 1, 1, 4, false, true>(p, stream, use_glds);
     case 3:
       RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 3 needs Cout %% 128 == 0");
-      return launch_variant<4, 2, 4, 4, false>(p, stream, use_glds);
+      return launch_variant<4, 2, 4, 4, false, false>(p, stream, use_glds);
     case 4:
       RS_CHECK(rows % 256 == 0, RS_ERR_ARG, "conv: variant 4 needs Cout %% 256 == 0");
-      return launch_variant<2, 4, 4, 8, false>(p, stream, use_glds);
+      return launch_variant<2, 4, 4, 8, false, false>(p, stream, use_glds);
     default:
       rs_set_error("conv: unknown variant %d", v);
       return RS_ERR_ARG;

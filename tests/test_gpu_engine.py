@@ -324,3 +324,52 @@ def test_fp32_mode_full_size_tile(gpu_required):
         _strict_compare(ref[0], dets[0], "fp32_full")
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# Other configurations of the boundary: 4-band tiles that are DOWN-scaled (BASELINE configs[3] geometry,
+# reduced), non-square tiles with size-divisibility padding, and the YAML's own NUM_CLASSES = 1.
+# All in fp32 validation mode so that the comparison with the oracle is strict.
+# ---------------------------------------------------------------------------------------------
+def _run_strict(spec, tiles, tag):
+    O = _oracle()
+    W = synthetic_weights(spec, seed=0)
+    eng = Engine(spec, W, tiles.shape[1:], max_batch=tiles.shape[0])
+    try:
+        dets = eng.infer(tiles)
+        ref = O.OracleModel(spec, W)([tiles[i] for i in range(tiles.shape[0])], keep=True)
+        x = eng.tensor("net_input", n=tiles.shape[0])
+        for i in range(tiles.shape[0]):
+            want = ref[i]["inter"]["net_input"].permute(1, 2, 0).numpy()
+            c = want.shape[2]
+            assert np.array_equal(x[i, :, :, :c], want), f"{tag}: pre-processing differs"
+            _strict_compare(ref[i], dets[i], f"{tag}[{i}]")
+        return eng.net_shape()
+    finally:
+        eng.close()
+
+
+def test_fp32_mode_4band_downscaled_tiles(gpu_required):
+    """RGB+NIR tiles, 400x400 -> 320x320: Pillow's antialiased down-scaling path, 4 input channels,
+    channel reversal of all 4 bands (what `im[:, :, ::-1]` does in DefaultPredictor)."""
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300,
+                      pixel_mean=(103.53, 116.28, 123.675, 110.0), pixel_std=(1.0, 1.0, 1.0, 1.0), precision="fp32")
+    tiles = synthetic_tiles(2, 400, 400, 4, seed=31)
+    assert _run_strict(spec, tiles, "4band") == (320, 320, 320, 320)
+
+
+def test_fp32_mode_non_square_tile_with_padding(gpu_required):
+    """200x300 tile -> ResizeShortestEdge gives 224x336, padded to 224x352 (size_divisibility 32): the padded
+    columns are zeros at the network input but real pixels from the stem on."""
+    spec = EngineSpec(num_classes=2, min_size_test=224, max_size_test=400, rpn_pre_nms_topk_test=200, rpn_post_nms_topk_test=200,
+                      precision="fp32")
+    tiles = synthetic_tiles(2, 200, 300, 3, seed=41)
+    assert _run_strict(spec, tiles, "nonsquare") == (224, 336, 224, 352)
+
+
+def test_fp32_mode_single_class(gpu_required):
+    """ROI_HEADS.NUM_CLASSES = 1 as written in the reference YAML (R:config/detectron2_config_3bands.yaml:191)."""
+    spec = EngineSpec(num_classes=1, min_size_test=256, max_size_test=426, rpn_pre_nms_topk_test=200, rpn_post_nms_topk_test=200,
+                      precision="fp32")
+    tiles = synthetic_tiles(2, 192, 192, 3, seed=51)
+    _run_strict(spec, tiles, "k1")
