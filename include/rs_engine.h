@@ -135,7 +135,8 @@ int rs_engine_net_shape(rs_engine* e, int* resized_h, int* resized_w, int* padde
  * out: [n][ho+2*out_halo][wo+2*out_halo][cout] fp16, or fp32 when out_f32.
  * residual (optional) has the geometry of out; upsample_add (optional) is
  * [n][ho/2+2*out_halo][wo/2+2*out_halo][cout] and is added at (y/2, x/2).
- * variant: -1 auto, 0 = 128x128 tile, 1 = 256x64, 2 = 256x16 (fp32 out). use_glds: 1 = direct
+ * variant: -1 auto, 0 = 128x128 tile, 1 = 256x64, 2 = 256x16 (fp32 out), 3 = 256x128, 4 = 256x256,
+ * 6 = experimental software-pipelined 256x256. use_glds: 1 = direct
  * global->LDS staging (production), 0 = register staging (cross-check). */
 int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual,
                  const void* upsample_add, int n, int hi, int wi, int cin, int in_halo, int kh, int kw,

@@ -99,3 +99,4 @@ int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int 
 int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_conv_f32(const ConvParams& p, hipStream_t stream);
+int launch_conv_pipe(const ConvParams& p, hipStream_t stream);

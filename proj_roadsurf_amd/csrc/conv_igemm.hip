@@ -475,6 +475,10 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
   }
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   int v = force_variant;
+  if (v == 6) {                         // experimental software-pipelined 256x256 kernel, on request only
+    g_last_conv_variant = 6;
+    return launch_conv_pipe(p, stream);
+  }
   if (v < 0) {
     v = rows <= 16 ? 2 : (rows % 128 == 0 ? 0 : 1);
     // Deep-K GEMMs with many rows: a 256-wide workgroup tile halves the L2->LDS bytes per FLOP (the 128x128
@@ -483,7 +487,11 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     if (big < 0) { const char* e = getenv("RS_CONV_BIG_TILE"); big = e ? atoi(e) : 4; }
     const int nk = smallc ? 0 : p.KH * p.KW * (p.Cin >> 6);
     if (big && v == 0 && p.mode == 0 && nk >= 8 && p.M >= 16384) {
-      if (big == 4 && rows % 256 == 0) v = 4;
+      if (big == 5 && rows % 256 == 0 && use_glds > 0) {     // software-pipelined 256x256 kernel (conv_pipe.hip)
+        g_last_conv_variant = 6;
+        return launch_conv_pipe(p, stream);
+      }
+      if (big >= 4 && rows % 256 == 0) v = 4;
       else if (big == 3) v = 3;            // 256x128 was measured slower than 128x128 everywhere: experiments only
     }
   }

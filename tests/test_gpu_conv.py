@@ -99,6 +99,20 @@ def test_conv3x3_256(gpu_required, glds, variant):
     _check_close(got, ref)
 
 
+@pytest.mark.parametrize("variant", [4, 6])
+def test_conv3x3_256_big_tiles(gpu_required, variant):
+    """256x256 workgroup tile (variant 4, production for deep-K layers) and the experimental software-pipelined
+    form (variant 6): ragged M (not a multiple of 256), residual + ReLU epilogue."""
+    g = torch.Generator().manual_seed(10)
+    x = _r16(torch.randn(3, 256, 33, 29, generator=g))
+    w = _r16(torch.randn(256, 256, 3, 3, generator=g) * 0.03)
+    b = torch.randn(256, generator=g)
+    res = _r16(torch.randn(3, 256, 33, 29, generator=g))
+    ref = F.relu(F.conv2d(x, w, b, padding=1) + res)
+    got = run_conv(x, w, b, pad=1, relu=True, res=res, variant=variant)
+    _check_close(got, ref)
+
+
 @pytest.mark.parametrize("glds", [1, 0])
 def test_conv1x1_residual_relu(gpu_required, glds):
     g = torch.Generator().manual_seed(1)
