@@ -486,6 +486,12 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     static int big = -1;
     if (big < 0) { const char* e = getenv("RS_CONV_BIG_TILE"); big = e ? atoi(e) : 4; }
     const int nk = smallc ? 0 : p.KH * p.KW * (p.Cin >> 6);
+    // Shallow-K layers (the 1x1 convs that expand to 256..2048 channels, mostly with a residual) are HBM-bound
+    // and latency-limited: small tiles = more workgroups in flight per CU.  Measured on res2 conv3 (+residual):
+    // 128x128 233 us, 64x128 170-190 us, 64x256 (8 waves, activation rows read once) 171 us.
+    static int small = -1;
+    if (small < 0) { const char* e = getenv("RS_CONV_SMALL_TILE"); small = e ? atoi(e) : 1; }
+    if (small && v == 0 && p.mode == 0 && !smallc && nk <= 4 && p.M >= 8192) v = rows % 256 == 0 ? 10 : 7;
     if (big && v == 0 && p.mode == 0 && nk >= 8 && p.M >= 16384) {
       if (big == 5 && rows % 256 == 0 && use_glds > 0) {     // software-pipelined 256x256 kernel (conv_pipe.hip)
         g_last_conv_variant = 6;
@@ -512,6 +518,18 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     case 2:
       RS_CHECK(rows % 16 == 0 && p.out_f32, RS_ERR_ARG, "conv: variant 2 is the 16-channel-tile fp32-out head kernel");
       return launch_variant<4, 1, 1, 4, false, true>(p, stream, use_glds);
+    case 7:   // experiment: 64 px x 128 ch tile (wave tile 32x64): half the accumulators, more workgroups per CU
+      RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 7 needs Cout %% 128 == 0");
+      return launch_variant<2, 2, 4, 2, false, false>(p, stream, use_glds);
+    case 9:   // experiment: 32 px x 128 ch tile (wave tile 16x64)
+      RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 9 needs Cout %% 128 == 0");
+      return launch_variant<2, 2, 4, 1, false, false>(p, stream, use_glds);
+    case 10:  // experiment: 64 px x 256 ch tile, 8 waves (wave tile 32x64): every activation row read once
+      RS_CHECK(rows % 256 == 0, RS_ERR_ARG, "conv: variant 10 needs Cout %% 256 == 0");
+      return launch_variant<2, 4, 4, 2, false, false>(p, stream, use_glds);
+    case 8:   // experiment: 128 px x 64 ch tile (wave tile 32x64, 4 px-waves)
+      RS_CHECK(rows % 64 == 0, RS_ERR_ARG, "conv: variant 8 needs Cout %% 64 == 0");
+      return launch_variant<4, 1, 4, 2, false, false>(p, stream, use_glds);
     case 3:
       RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 3 needs Cout %% 128 == 0");
       return launch_variant<4, 2, 4, 4, false, false>(p, stream, use_glds);

@@ -245,20 +245,20 @@ def test_batch_independence_and_determinism(small):
 def test_full_size_512_tile(gpu_required):
     """BASELINE config 1/2 geometry: 512x512x3 tiles -> 800x800 network input, 1000 proposals, 100 detections.
     fp16 production mode vs fp32 oracle is a STATISTICAL comparison on this random-weight workload (a single
-    flipped NMS decision cascades), so it is evaluated over 4 tiles: mean matched fraction >= 0.85, no tile
+    flipped NMS decision cascades), so it is evaluated over 3 tiles: mean matched fraction >= 0.85, no tile
     below 0.7; scores of matched pairs agree to 2e-2 (measured: 1e-3).  The strict end-to-end check is the
     fp32 validation mode below."""
     O = _oracle()
     spec = EngineSpec(num_classes=2)
     W = synthetic_weights(spec, seed=0)
-    tiles = synthetic_tiles(4, 512, 512, 3, seed=1234)
-    eng = Engine(spec, W, (512, 512, 3), max_batch=4)
+    tiles = synthetic_tiles(3, 512, 512, 3, seed=1234)
+    eng = Engine(spec, W, (512, 512, 3), max_batch=3)
     try:
         assert eng.net_shape() == (800, 800, 800, 800)
         dets = eng.infer(tiles)
         m = O.OracleModel(spec, W)
         fracs = []
-        for i in range(4):
+        for i in range(3):
             ref = m([tiles[i]])[0]
             r = {"boxes": ref["boxes"].numpy(), "scores": ref["scores"].numpy(), "classes": ref["classes"].numpy(), "masks": ref["masks"].numpy()}
             g = {"boxes": dets[i].pred_boxes, "scores": dets[i].scores, "classes": dets[i].pred_classes, "masks": dets[i].pred_masks}
