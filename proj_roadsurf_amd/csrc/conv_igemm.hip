@@ -480,32 +480,30 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     return launch_conv_pipe(p, stream);
   }
   if (v < 0) {
-    v = rows <= 16 ? 2 : (rows % 128 == 0 ? 0 : 1);
-    // Deep-K GEMMs with many rows: a 256-wide workgroup tile halves the L2->LDS bytes per FLOP (the 128x128
-    // tile needs ~34 TB/s of L2 at full MFMA rate, which is the whole L2).  RS_CONV_BIG_TILE: 0 off, 3 = 256x128, 4 = 256x256.
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("RS_CONV_BIG_TILE"); big = e ? atoi(e) : 4; }
+    // Tile choice from the offline sweep over every layer shape of the batch-16 forward
+    // (tools/ubench/tune_conv.py, profiles/r01/conv_tile_sweep.txt).  RS_CONV_TUNED=0 restores the
+    // first-round rule (128x128 / 256x64 only).
+    static int tuned = -1;
+    if (tuned < 0) { const char* e = getenv("RS_CONV_TUNED"); tuned = e ? atoi(e) : 1; }
     const int nk = smallc ? 0 : p.KH * p.KW * (p.Cin >> 6);
-    // Shallow-K layers (the 1x1 convs that expand to 256..2048 channels, mostly with a residual) are HBM-bound
-    // and latency-limited: small tiles = more workgroups in flight per CU.  Measured on res2 conv3 (+residual):
-    // 128x128 233 us, 64x128 170-190 us, 64x256 (8 waves, activation rows read once) 171 us.
-    static int small = -1;
-    if (small < 0) { const char* e = getenv("RS_CONV_SMALL_TILE"); small = e ? atoi(e) : 1; }
-    if (small && v == 0 && p.mode == 0 && !smallc && nk <= 4 && p.M >= 8192) v = rows % 256 == 0 ? 10 : 7;
-    if (big && v == 0 && p.mode == 0 && nk >= 8 && p.M >= 16384) {
-      if (big == 5 && rows % 256 == 0 && use_glds > 0) {     // software-pipelined 256x256 kernel (conv_pipe.hip)
-        g_last_conv_variant = 6;
-        return launch_conv_pipe(p, stream);
-      }
-      if (big >= 4 && rows % 256 == 0) v = 4;
-      else if (big == 3) v = 3;            // 256x128 was measured slower than 128x128 everywhere: experiments only
-    }
+    const long long tiles0 = (long long)cdiv(p.M, 128) * (rows / 128 > 0 ? rows / 128 : 1);
+    const long long tiles4 = (long long)cdiv(p.M, 256) * (rows / 256 > 0 ? rows / 256 : 1);
+    if (rows <= 16) v = 2;
+    else if (!tuned || p.mode != 0 || smallc) v = rows % 128 == 0 ? 0 : 1;
+    else if (rows % 128 != 0) v = 8;                                        // Cout = 64: 128x64 beats 256x64 everywhere
+    else if (rows % 256 == 0 && nk >= 8 && tiles4 >= 240) v = 4;            // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
+    else if (rows % 256 == 0 && nk <= 4 && p.M >= 100000) v = 10;           // HBM-bound 1x1 expansions on big maps: 64x256, rows read once
+    else if (nk <= 4 || tiles0 < 1250) v = 7;                               // few tiles or shallow K: 64x128 keeps more workgroups in flight
+    else v = 0;
   }
   RS_CHECK(!(p.mode != 0 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
   RS_CHECK(!(p.mode == 2 && !(p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && v == 0)), RS_ERR_ARG, "fused mask predictor needs its pointers and the 128x128 tile");
   g_last_conv_variant = smallc ? 5 : v;
   if (smallc) {
     RS_CHECK(v == 1, RS_ERR_ARG, "conv: small-Cin path is built for the 256x64 tile only (Cout=%d)", p.Cout);
+    static int stem_small = -1;
+    if (stem_small < 0) { const char* e = getenv("RS_STEM_SMALL_TILE"); stem_small = e ? atoi(e) : 1; }
+    if (stem_small) return launch_variant<4, 1, 4, 2, true, false>(p, stream, use_glds);     // 128x64
     return launch_variant<4, 1, 4, 4, true, false>(p, stream, use_glds);
   }
   switch (v) {
