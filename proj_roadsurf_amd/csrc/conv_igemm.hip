@@ -497,7 +497,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     else v = 0;
   }
   RS_CHECK(!(p.mode != 0 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
-  RS_CHECK(!(p.mode == 2 && !(p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && v == 0)), RS_ERR_ARG, "fused mask predictor needs its pointers and the 128x128 tile");
+  RS_CHECK(!(p.mode == 2 && !(p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && (v == 0 || v == 10))), RS_ERR_ARG, "fused mask predictor needs its pointers and the 128x128 or 64x256 tile");
   g_last_conv_variant = smallc ? 5 : v;
   if (smallc) {
     RS_CHECK(v == 1, RS_ERR_ARG, "conv: small-Cin path is built for the 256x64 tile only (Cout=%d)", p.Cout);

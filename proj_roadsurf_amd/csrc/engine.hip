@@ -707,7 +707,9 @@ int rs_engine::build() {
       st.fn = [dp, per_roi, Dc, glds, probs, zero_per_tile](int n, hipStream_t s) mutable {
         RS_HIP(hipMemsetAsync(probs, 0, zero_per_tile * n, s));
         dp.M = n * Dc * per_roi;
-        return launch_conv(dp, s, 0, glds);
+        static int dv = -1;
+        if (dv < 0) { const char* e = getenv("RS_DECONV_VARIANT"); dv = e ? atoi(e) : 10; }
+        return launch_conv(dp, s, dv, glds);      // 64x256 tile: one workgroup holds all 256 channels of a (dy,dx) group
       };
       stages.push_back(st);
       MaskPredictParams mp;
