@@ -100,3 +100,4 @@ int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int H
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_conv_f32(const ConvParams& p, hipStream_t stream);
 int launch_conv_pipe(const ConvParams& p, hipStream_t stream);
+int launch_conv_stag(const ConvParams& p, hipStream_t stream);

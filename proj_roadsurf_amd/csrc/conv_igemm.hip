@@ -109,6 +109,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     __syncthreads();
   }
 
+  int w_koff = 0;               // element offset of the current K step inside a weight row (set by next_off())
   auto stage = [&](int buf, int t, int a_off) {
     char* abase = smem + buf * T::STAGE;
     char* wbase = abase + BM * 128;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
 #pragma unroll
     for (int ps = 0; ps < PW; ++ps) {
       if (ps * NW * 8 + wave * 8 < BN) {   // wave-uniform
-        const half_t* g = wptr[ps] + t * 64;
+        const half_t* g = wptr[ps] + (SMALLC ? t * 64 : w_koff);
         char* dst = wbase + (ps * NW * 8 + wave * 8) * 128;
         if constexpr (GLDS) {
           glds16(g, dst);
@@ -157,12 +158,16 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   const int c1_off = ((4 + fq) ^ fkey) * 16;    // kk = 1
 
   int kh = 0, kw = 0, c0 = 0;   // position of the NEXT K step to stage
+  // K-step order: 64-channel slice OUTER, filter taps INNER.  All KH*KW taps of one channel slice touch the
+  // same ~(rows+2) x W x 128 B of the input, so a tile's live footprint between re-reads is 1/(Cin/64) of the
+  // taps-outer order and stays L2-resident (256-ch 3x3 @200x200: 85 KB instead of 338 KB per tile, 32 tiles
+  // per XCD against 4 MB of L2).  The weight row is addressed by (tap, slice), so its memory layout is unchanged.
   auto next_off = [&]() {
     const int off = (kh * p.in_Wp + kw) * p.in_Cs + c0;
-    c0 += 64;
-    if (c0 >= p.Cin) {
-      c0 = 0;
-      if (++kw == p.KW) { kw = 0; ++kh; }
+    w_koff = (kh * p.KW + kw) * p.Cin + c0;
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; c0 += 64; }
     }
     return off;
   };
@@ -479,6 +484,10 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     g_last_conv_variant = 6;
     return launch_conv_pipe(p, stream);
   }
+  if (v == 11) {                        // staggered two-group 256x256 kernel (conv_stag.hip)
+    g_last_conv_variant = 11;
+    return launch_conv_stag(p, stream);
+  }
   if (v < 0) {
     // Tile choice from the offline sweep over every layer shape of the batch-16 forward
     // (tools/ubench/tune_conv.py, profiles/r01/conv_tile_sweep.txt).  RS_CONV_TUNED=0 restores the
@@ -491,7 +500,12 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     if (rows <= 16) v = 2;
     else if (!tuned || p.mode != 0 || smallc) v = rows % 128 == 0 ? 0 : 1;
     else if (rows % 128 != 0) v = 8;                                        // Cout = 64: 128x64 beats 256x64 everywhere
-    else if (rows % 256 == 0 && nk >= 8 && tiles4 >= 240) v = 4;            // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
+    else if (rows % 256 == 0 && nk >= 8 && tiles4 >= 240) {                 // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
+      static int stag = -1;
+      if (stag < 0) { const char* e = getenv("RS_CONV_STAGGER"); stag = e ? atoi(e) : 0; }
+      if (stag && use_glds > 0) { g_last_conv_variant = 11; return launch_conv_stag(p, stream); }
+      v = 4;
+    }
     else if (rows % 256 == 0 && nk <= 4 && p.M >= 100000) v = 10;           // HBM-bound 1x1 expansions on big maps: 64x256, rows read once
     else if (nk <= 4 || tiles0 < 1250) v = 7;                               // few tiles or shallow K: 64x128 keeps more workgroups in flight
     else v = 0;
