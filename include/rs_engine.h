@@ -27,6 +27,7 @@ extern "C" {
 #define RS_ABI_VERSION 1
 #define RS_SPEC_MAX_LEVELS 5
 #define RS_SPEC_MAX_ANCHORS 8
+#define RS_NUM_PHASES 3 /* rs_engine_infer_phase: 0 preprocess..RPN proposals, 1 box head..detections, 2 mask head + paste */
 #define RS_MASK_SIDE 28 /* 2 * ROI_MASK_HEAD.POOLER_RESOLUTION (R:219) */
 
 /* POD mirror of the detectron2 YAML fields the inference path reads
@@ -102,6 +103,16 @@ int rs_engine_infer(rs_engine* e, const uint8_t* tiles_host, int n, rs_dets* out
 int rs_engine_infer_device(rs_engine* e, const uint8_t* tiles_dev, int n);
 int rs_engine_sync(rs_engine* e);
 int rs_engine_fetch(rs_engine* e, int n, rs_dets* out_host);
+
+/* The same forward, enqueued one phase at a time (phase 0, 1, 2 in order, same tiles/n for all three) so that a
+ * caller driving TWO engines created on one shared `stream` can interleave them: the latency-bound detection glue
+ * at the end of phases 0 and 1 runs on an engine-private side stream and is hidden behind the other engine's
+ * convolutions, which stay serialised on the shared stream.  Enqueue order per batch k (engine k mod 2):
+ *   phase0(k), phase2(k-1), phase1(k)          -- see proj_roadsurf_amd/engine.py:LanePipeline
+ * rs_engine_infer_device(e, t, n) == phases 0, 1, 2 back to back.  There is no reference counterpart
+ * (DefaultPredictor is synchronous, one image per call: [EXT d2: engine/defaults.py]). */
+int rs_engine_infer_phase(rs_engine* e, const uint8_t* tiles_dev, int n, int phase);
+int rs_engine_phase_count(void);
 
 /* Stream the engine launches on (hipStream_t), for event timing by the caller. */
 void* rs_engine_stream(rs_engine* e);

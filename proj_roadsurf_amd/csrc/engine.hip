@@ -52,6 +52,9 @@ struct Stage {
   int calls = 0;
   double last_flops = 0, last_bytes = 0;
   int variant = -2;      // conv tile variant of the last call (-2 = not a conv stage)
+  bool narrow = false;   // latency-bound detection glue (few workgroups): runs on the engine's side stream
+  int phase = 0;         // 0 = preprocess..RPN proposals, 1 = box head..detections, 2 = mask head + paste
+  hipEvent_t handoff = nullptr;   // recorded on the previous stage's stream when this stage switches streams
 };
 
 struct BlobEntry { const void* host; void* dev; int dtype; int ndim; int64_t dims[4]; size_t nbytes; };
@@ -115,8 +118,12 @@ extern "C" int rs_resize_coeffs(int in_size, int out_size, int32_t* bounds, int3
 struct rs_engine {
   rs_spec spec;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;         // "wide" stream: every kernel that fills the chip (may be shared between engines)
   bool own_stream = false;
+  hipStream_t narrow = nullptr;         // side stream for the latency-bound glue kernels (null = everything on `stream`)
+  bool on_narrow = false;               // which stream the most recently enqueued stage went to
+  hipEvent_t ev_join = nullptr;         // narrow -> wide join at the end of a forward that ends on the side stream
+  bool cur_record = false;              // profiling decision of the forward in flight (taken at phase 0)
   int max_batch = 0, tile_h = 0, tile_w = 0, tile_c = 0;
   int net_h = 0, net_w = 0, pad_h = 0, pad_w = 0;
   int use_glds = 1;    // -1 = fp32 validation path (launch_conv forwards to launch_conv_f32)
@@ -181,8 +188,9 @@ struct rs_engine {
   int add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k, int stride,
                int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile = 1,
                const int* m_count = nullptr);
-  int run(const uint8_t* tiles, int n);
-  int run_stages(int n, bool record);
+  int run(const uint8_t* tiles, int n, int phase = -1);
+  int run_stages(int n, bool record, int phase = -1);
+  int assign_phases();
   int use_graph = 0;
   long long forward_index = 0;
   std::set<int> warmed;
@@ -762,24 +770,58 @@ int rs_engine::build() {
   return RS_OK;
 }
 
-int rs_engine::run_stages(int n, bool record) {
+// Phase and stream of every stage.  With RS_SIDE_STREAM=1 (default) the detection glue runs on a side stream:
+// alone it changes nothing (the hand-off events keep the order), but two engines that share the wide stream can
+// then hide one batch's glue behind the other batch's convolutions (rs_engine_infer_phase).
+int rs_engine::assign_phases() {
+  const char* g = getenv("RS_SIDE_STREAM");
+  const bool side = (g ? atoi(g) : 1) != 0 && !use_graph;
+  static const char* kNarrow[] = {"rpn.select_decode", "rpn.nms", "rpn.merge", "box.candidates", "box.nms",
+                                  "box.merge_postprocess", "mask.compact"};
+  int phase = 0;
+  for (Stage& st : stages) {
+    if (st.name.rfind("box.", 0) == 0 && phase < 1) phase = 1;
+    if (st.name.rfind("mask.", 0) == 0 && st.name != "mask.compact" && phase < 2) phase = 2;
+    st.phase = phase;
+    for (const char* nm : kNarrow) if (side && st.name == nm) st.narrow = true;
+  }
+  if (!side) return RS_OK;
+  RS_HIP(hipStreamCreateWithFlags(&narrow, hipStreamNonBlocking));
+  RS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  bool prev = false;
+  for (Stage& st : stages) {
+    if (st.narrow != prev) RS_HIP(hipEventCreateWithFlags(&st.handoff, hipEventDisableTiming));
+    prev = st.narrow;
+  }
+  return RS_OK;
+}
+
+int rs_engine::run_stages(int n, bool record, int phase) {
   for (size_t si = 0; si < stages.size(); ++si) {
     Stage& st = stages[si];
+    if (phase >= 0 && st.phase != phase) continue;
+    if (st.narrow != on_narrow) {       // hand the dependency chain over to the other stream
+      hipStream_t from = on_narrow ? narrow : stream, to = st.narrow ? narrow : stream;
+      RS_HIP(hipEventRecord(st.handoff, from));
+      RS_HIP(hipStreamWaitEvent(to, st.handoff, 0));
+      on_narrow = st.narrow;
+    }
+    hipStream_t ss = st.narrow ? narrow : stream;
     const bool pooled = record && profiling >= 2 && ev_used < ev_pool.size();
-    if (record && profiling == 1) RS_HIP(hipEventRecord(ev0, stream));
-    if (pooled) RS_HIP(hipEventRecord(ev_pool[ev_used].first, stream));
+    if (record && profiling == 1) RS_HIP(hipEventRecord(ev0, ss));
+    if (pooled) RS_HIP(hipEventRecord(ev_pool[ev_used].first, ss));
     g_last_conv_variant = -2;
-    int rc = st.fn(n, stream);
+    int rc = st.fn(n, ss);
     if (rc) return rc;
     st.variant = g_last_conv_variant;
     if (pooled) {
-      RS_HIP(hipEventRecord(ev_pool[ev_used].second, stream));
+      RS_HIP(hipEventRecord(ev_pool[ev_used].second, ss));
       ev_stage[ev_used] = (int)si;
       ev_batch[ev_used] = n;
       ++ev_used;
     }
     if (record && profiling == 1) {
-      RS_HIP(hipEventRecord(ev1, stream));
+      RS_HIP(hipEventRecord(ev1, ss));
       RS_HIP(hipEventSynchronize(ev1));
       float ms = 0.f;
       RS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
@@ -789,24 +831,33 @@ int rs_engine::run_stages(int n, bool record) {
       st.last_bytes = st.bytes_per_image * n;
     }
   }
+  if ((phase < 0 || phase == RS_NUM_PHASES - 1) && on_narrow) {   // the forward ended on the side stream: join
+    RS_HIP(hipEventRecord(ev_join, narrow));
+    RS_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    on_narrow = false;
+  }
   return RS_OK;
 }
 
 // One forward.  The ~110 launches of a forward are replayed from a hipGraph (captured per batch size
 // after one eager warm-up run, which also performs the one-time hipFuncSetAttribute calls); forwards
 // that are being event-profiled run eagerly so every launch can be bracketed.
-int rs_engine::run(const uint8_t* tiles, int n) {
+int rs_engine::run(const uint8_t* tiles, int n, int phase) {
   RS_CHECK(n >= 1 && n <= max_batch, RS_ERR_ARG, "batch %d outside [1, %d]", n, max_batch);
-  if (tiles != tiles_dev) {
-    // tiles already resident elsewhere on the device: stage them into the engine's input buffer
-    RS_HIP(hipMemcpyAsync(tiles_dev, tiles, (size_t)n * tile_h * tile_w * tile_c, hipMemcpyDeviceToDevice, stream));
+  RS_CHECK(phase >= -1 && phase < RS_NUM_PHASES, RS_ERR_ARG, "phase %d outside [-1, %d)", phase, RS_NUM_PHASES);
+  if (phase <= 0) {
+    if (tiles != tiles_dev) {
+      // tiles already resident elsewhere on the device: stage them into the engine's input buffer
+      RS_HIP(hipMemcpyAsync(tiles_dev, tiles, (size_t)n * tile_h * tile_w * tile_c, hipMemcpyDeviceToDevice, stream));
+    }
+    const long long idx = forward_index++;
+    cur_record = profiling == 1 || profiling == 2 || (profiling == 3 && (idx & 3) == 0);
   }
-  const long long idx = forward_index++;
-  const bool record = profiling == 1 || profiling == 2 || (profiling == 3 && (idx & 3) == 0);
-  if (record || !use_graph || !warmed.count(n)) {
-    int rc = run_stages(n, record);
+  const bool record = cur_record;
+  if (phase >= 0 || record || !use_graph || !warmed.count(n)) {
+    int rc = run_stages(n, record, phase);
     if (rc) return rc;
-    warmed.insert(n);
+    if (phase < 0) warmed.insert(n);
     return RS_OK;
   }
   auto it = graphs.find(n);
@@ -829,6 +880,7 @@ int rs_engine::run(const uint8_t* tiles, int n) {
 int rs_engine::resolve_profile() {
   if (ev_used == 0) return RS_OK;
   RS_HIP(hipStreamSynchronize(stream));
+  if (narrow) RS_HIP(hipStreamSynchronize(narrow));
   for (size_t i = 0; i < ev_used; ++i) {
     float ms = 0.f;
     RS_HIP(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
@@ -887,6 +939,7 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { rs_set_error("hipEventCreate failed"); rc = RS_ERR_HIP; }
   if (!rc) rc = e->parse_blob(weights, nbytes);
   if (!rc) rc = e->build();
+  if (!rc) rc = e->assign_phases();
   if (rc) { rs_engine_destroy(e); return rc; }
   *out = e;
   return RS_OK;
@@ -896,6 +949,9 @@ void rs_engine_destroy(rs_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->narrow) { hipStreamSynchronize(e->narrow); hipStreamDestroy(e->narrow); }
+  if (e->ev_join) hipEventDestroy(e->ev_join);
+  for (Stage& st : e->stages) if (st.handoff) hipEventDestroy(st.handoff);
   for (void* p : e->allocs) hipFree(p);
   if (e->blob_dev) hipFree(e->blob_dev);
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -912,9 +968,18 @@ int rs_engine_infer_device(rs_engine* e, const uint8_t* tiles_dev, int n) {
   return e->run(tiles_dev, n);
 }
 
+int rs_engine_infer_phase(rs_engine* e, const uint8_t* tiles_dev, int n, int phase) {
+  RS_CHECK(e && tiles_dev, RS_ERR_ARG, "null argument");
+  RS_CHECK(phase >= 0 && phase < RS_NUM_PHASES, RS_ERR_ARG, "phase %d outside [0, %d)", phase, RS_NUM_PHASES);
+  RS_HIP(hipSetDevice(e->device));
+  return e->run(tiles_dev, n, phase);
+}
+int rs_engine_phase_count(void) { return RS_NUM_PHASES; }
+
 int rs_engine_sync(rs_engine* e) {
   RS_CHECK(e, RS_ERR_ARG, "null engine");
   RS_HIP(hipStreamSynchronize(e->stream));
+  if (e->narrow) RS_HIP(hipStreamSynchronize(e->narrow));
   return RS_OK;
 }
 

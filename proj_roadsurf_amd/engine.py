@@ -70,6 +70,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_destroy.restype = None
     lib.rs_engine_infer.argtypes = [vp, vp, i32, C.POINTER(RsDets)]
     lib.rs_engine_infer_device.argtypes = [vp, vp, i32]
+    lib.rs_engine_infer_phase.argtypes = [vp, vp, i32, i32]
     lib.rs_engine_sync.argtypes = [vp]
     lib.rs_engine_fetch.argtypes = [vp, i32, C.POINTER(RsDets)]
     lib.rs_engine_stream.argtypes = [vp]
@@ -268,6 +269,10 @@ class Engine:
         """Enqueue a forward on tiles already in device memory (no wait)."""
         _check(self.lib, self.lib.rs_engine_infer_device(self._h, C.c_void_p(tiles_dev_ptr), n), "rs_engine_infer_device")
 
+    def infer_phase(self, tiles_dev_ptr: int, n: int, phase: int) -> None:
+        """Enqueue one phase (0, 1, 2) of a forward; see ``LanePipeline`` and include/rs_engine.h."""
+        _check(self.lib, self.lib.rs_engine_infer_phase(self._h, C.c_void_p(tiles_dev_ptr), n, phase), "rs_engine_infer_phase")
+
     def sync(self) -> None:
         _check(self.lib, self.lib.rs_engine_sync(self._h), "rs_engine_sync")
 
@@ -348,6 +353,65 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+class LanePipeline:
+    """Two engines ("lanes") on one shared wide stream, fed alternately so that consecutive batches overlap:
+    the convolutions of both lanes stay serialised on the shared stream (two chip-filling kernels gain nothing
+    from running together), while each lane's latency-bound detection glue (RPN top-k/NMS/merge, box NMS/merge)
+    runs on its own side stream behind the other lane's convolutions.  Enqueue order for batch k on lane k mod 2:
+
+        phase0(k)   backbone, FPN, RPN heads  -> glue G1(k) on the side stream
+        phase2(k-1) mask head of the previous batch (hides G1(k))
+        phase1(k)   box head                  -> glue G2(k) on the side stream, hidden by phase0(k+1)
+
+    Results of batch k are complete once phase2(k) has run, i.e. after ``submit`` of batch k+1 or ``flush``.
+    The reference processes one tile at a time and has no counterpart ([EXT d2: engine/defaults.py])."""
+
+    def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], max_batch: int = 16,
+                 device: int = 0, lanes: int = 2):
+        if lanes not in (1, 2):
+            raise ValueError("lanes must be 1 or 2")
+        first = Engine(spec, weights, tile_shape, max_batch, device)
+        self.engines = [first] + [Engine(spec, weights, tile_shape, max_batch, device, stream=first.stream) for _ in range(lanes - 1)]
+        self.k = 0
+        self._pending: Optional[Tuple[int, int, int]] = None     # (lane, tiles ptr, n) whose phase 2 is still to be enqueued
+
+    def lane_of_next(self) -> Engine:
+        return self.engines[self.k % len(self.engines)]
+
+    def submit(self, tiles_dev_ptr: int, n: int) -> int:
+        """Enqueue one batch (tiles resident in the next lane's device memory); returns the lane index used."""
+        lane = self.k % len(self.engines)
+        e = self.engines[lane]
+        self.k += 1
+        if len(self.engines) == 1:
+            e.infer_device(tiles_dev_ptr, n)
+            return lane
+        e.infer_phase(tiles_dev_ptr, n, 0)
+        self._finish_pending()
+        e.infer_phase(tiles_dev_ptr, n, 1)
+        self._pending = (lane, tiles_dev_ptr, n)
+        return lane
+
+    def _finish_pending(self) -> None:
+        if self._pending is not None:
+            lane, ptr, n = self._pending
+            self.engines[lane].infer_phase(ptr, n, 2)
+            self._pending = None
+
+    def flush(self) -> None:
+        """Enqueue the outstanding mask-head phase; after this every submitted batch is fully enqueued."""
+        self._finish_pending()
+
+    def sync(self) -> None:
+        self.flush()
+        for e in self.engines:
+            e.sync()
+
+    def close(self) -> None:
+        for e in reversed(self.engines):     # lane 0 owns the shared stream: destroy it last
+            e.close()
 
 
 class Predictor:
