@@ -154,6 +154,17 @@ int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, co
                  int stride, int pad, int cout, int kpad, int out_halo, int relu, int out_f32, int deconv2x,
                  int variant, int use_glds, void* stream);
 
+/* Bottleneck output with a projection shortcut as ONE GEMM over two activation sources:
+ *   out = act( conv_khxkw(in; W[:, :kh*kw*cin]) + conv_1x1_stride2(in2; W[:, kh*kw*cin:]) + bias )
+ * i.e. BottleneckBlock.forward's `out = conv3(out); shortcut = self.shortcut(x); out += shortcut; relu`
+ * ([EXT d2: modeling/backbone/resnet.py BottleneckBlock.forward]) with both FrozenBN-folded convolutions'
+ * weights concatenated along K and their biases added.  in2: [n][h2+2*in2_halo][w2+2*in2_halo][cin2] fp16;
+ * output pixel (y, x) reads in2 pixel (y*stride2, x*stride2). */
+int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const float* bias, void* out,
+                      int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad,
+                      int h2, int w2, int cin2, int in2_halo, int stride2,
+                      int cout, int kpad, int out_halo, int relu, int variant, void* stream);
+
 /* Greedy NMS over `segments` independent lists of up to 1024 boxes in priority order
  * (torchvision.ops.nms semantics: IoU > thresh suppresses). keep: [segments][cap] 0/1. */
 int rs_op_nms(const float* boxes, const int32_t* counts, const uint8_t* valid, uint8_t* keep,

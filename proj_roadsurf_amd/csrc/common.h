@@ -69,6 +69,11 @@ struct ConvParams {
   const int* dot_cls;   // mode 2: [slots] predicted class
   const int* dot_slot;  // mode 2: [entries] entry -> slot
   float* dot_out;       // mode 2: [slots][2*Ho][2*Wo] logits (without bias), zeroed by the caller
+  // Second activation source appended along K (bottleneck conv3 + projection shortcut in ONE GEMM:
+  //   out = relu([W3 | Wsc] * [conv2 out ; block input(stride s)] + b3 + bsc)): after the KH*KW*Cin/64 steps of
+  // `in`, Cin2/64 more K steps read pixel (y*stride2, x*stride2) of `in2` (1x1 taps).  Weight row = [K of in | Cin2].
+  const half_t* in2;    // nullptr = single source
+  int in2_Hp, in2_Wp, in2_Cs, in2_off, stride2, Cin2;
   int persist;          // >0: persistent launch with this many workgroups per CU; -1: per-variant default; 0: one per tile
   int stages;           // LDS K-step buffers: 0/2 = double buffered, 1 = single (set by launch_conv for shallow K)
 };

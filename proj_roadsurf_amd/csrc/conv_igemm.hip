@@ -72,13 +72,8 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   int m0 = 0, n0 = 0;
   // XCD-aware tile order: positions q and q+8 share an XCD (L2); each XCD gets a contiguous run of logical
   // tiles, channel tiles fastest, so tiles that re-read one activation panel hit the same L2.
-  auto setup_tile = [&](int qq) {
-    const int qn = ntiles >> 3, r = ntiles & 7, x = qq & 7;
-    const int L = (x < r ? x * (qn + 1) : r * (qn + 1) + (x - r) * qn) + (qq >> 3);
-    const int tile_n = L % tiles_n;
-    const int tile_m = L / tiles_n;
-    m0 = tile_m * BM;
-    n0 = tile_n * BN;
+  // per-lane source pointers of the activation rows this lane stages; `second` selects ConvParams::in2
+  auto setup_acts = [&](bool second) {
 #pragma unroll
     for (int ps = 0; ps < PA; ++ps) {
       int m = m0 + ps * NW * 8 + wave * 8 + lrow;
@@ -87,11 +82,26 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       const int t = m / p.Wo;
       const int y = t % p.Ho;
       const int n = t / p.Ho;
-      const long long base =
-          ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x2 * p.stride + p.in_off) * p.in_Cs;
       // LDS slot lchk of row r holds data chunk (lchk ^ (r & 7)); r & 7 == lrow here.
-      aptr[ps] = p.in + base + (SMALLC ? 0 : ((lchk ^ lrow) * 8));
+      if (second) {
+        const long long base =
+            ((long long)(n * p.in2_Hp + y * p.stride2 + p.in2_off) * p.in2_Wp + x2 * p.stride2 + p.in2_off) * p.in2_Cs;
+        aptr[ps] = p.in2 + base + (lchk ^ lrow) * 8;
+      } else {
+        const long long base =
+            ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x2 * p.stride + p.in_off) * p.in_Cs;
+        aptr[ps] = p.in + base + (SMALLC ? 0 : ((lchk ^ lrow) * 8));
+      }
     }
+  };
+  auto setup_tile = [&](int qq) {
+    const int qn = ntiles >> 3, r = ntiles & 7, x = qq & 7;
+    const int L = (x < r ? x * (qn + 1) : r * (qn + 1) + (x - r) * qn) + (qq >> 3);
+    const int tile_n = L % tiles_n;
+    const int tile_m = L / tiles_n;
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
+    setup_acts(false);
 #pragma unroll
     for (int ps = 0; ps < PW; ++ps) {
       const int row = ps * NW * 8 + wave * 8 + lrow;
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     }
   };
 
-  const int nk = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> 6));
+  const int nk = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> 6) + (p.in2 ? (p.Cin2 >> 6) : 0));
   const int nst = p.stages == 1 ? 1 : 2;   // LDS K-step buffers: 1 = shallow-K layers (more workgroups per CU)
   int* koff_s = (int*)(smem + nst * T::STAGE);
   if constexpr (SMALLC) {
@@ -163,6 +173,13 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   // taps-outer order and stays L2-resident (256-ch 3x3 @200x200: 85 KB instead of 338 KB per tile, 32 tiles
   // per XCD against 4 MB of L2).  The weight row is addressed by (tap, slice), so its memory layout is unchanged.
   auto next_off = [&]() {
+    if (c0 >= p.Cin) {               // second source (1x1 taps): only reached when p.in2 is set (nk counts its steps)
+      if (c0 == p.Cin) setup_acts(true);     // the first source's pointers are dead from here on: reuse the registers
+      const int off = c0 - p.Cin;
+      w_koff = p.KH * p.KW * p.Cin + off;
+      c0 += 64;
+      return off;
+    }
     const int off = (kh * p.in_Wp + kw) * p.in_Cs + c0;
     w_koff = (kh * p.KW + kw) * p.Cin + c0;
     if (++kw == p.KW) {
@@ -447,15 +464,20 @@ thread_local int g_last_conv_variant = -2;
 
 // variant: 0 = 128x128, 1 = 256x64, 2 = 256x16 (small heads), 3 = 256x128, 4 = 256x256, -1 = choose
 int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, int use_glds) {
-  if (use_glds < 0) { g_last_conv_variant = -1; return launch_conv_f32(p_in, stream); }   // fp32 validation mode (ref_f32.hip)
+  if (use_glds < 0) {                   // fp32 validation mode (ref_f32.hip)
+    RS_CHECK(!p_in.in2, RS_ERR_UNSUPPORTED, "conv: the fp32 validation kernel has no second K source");
+    g_last_conv_variant = -1;
+    return launch_conv_f32(p_in, stream);
+  }
   ConvParams p = p_in;
+  const int nk2 = p.in2 ? (p.Cin2 >> 6) : 0;   // K steps of the second source
   {
     // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second
     // LDS buffer; a single buffer halves the LDS footprint so 4 workgroups fit per CU and their
     // loads/epilogues overlap each other instead.
     static int nk_single = -1;
     if (nk_single < 0) { const char* e = getenv("RS_CONV_SINGLE_STAGE_NK"); nk_single = e ? atoi(e) : 4; }
-    const int nk = p.Cin < 64 ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6);
+    const int nk = p.Cin < 64 ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6) + nk2;
     // RS_CONV_PERSIST: 0 = one workgroup per tile everywhere (single LDS buffer for shallow K);
     // (default 0: measured, the persistent form is correct but not faster -- 0.221 vs 0.225 ms on res2 conv3, slower on
     //  conv1 -- these layers sit at ~3.3 TB/s either way) 1 = shallow-K layers run persistent + double buffered so that the next tile's operands load
@@ -476,7 +498,11 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     RS_CHECK((p.Cin == 8 || p.Cin == 4) && p.koff != nullptr, RS_ERR_ARG, "conv: small-Cin path needs Cin 4 or 8 and a koff table");
   } else {
     RS_CHECK(p.Cin % 64 == 0, RS_ERR_ARG, "conv: Cin %d not a multiple of 64", p.Cin);
-    RS_CHECK(p.KH * p.KW * p.Cin <= p.Kpad, RS_ERR_ARG, "conv: K exceeds Kpad");
+    RS_CHECK(p.KH * p.KW * p.Cin + nk2 * 64 <= p.Kpad, RS_ERR_ARG, "conv: K exceeds Kpad");
+  }
+  if (p.in2) {
+    RS_CHECK(!smallc && p.mode == 0 && p.Cin2 % 64 == 0 && p.Cin2 > 0 && p.stride2 >= 1, RS_ERR_ARG, "conv: bad second K source (Cin2 %d)", p.Cin2);
+    RS_CHECK(force_variant != 6 && force_variant != 11, RS_ERR_UNSUPPORTED, "conv: variants 6/11 have no second K source");
   }
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   int v = force_variant;
@@ -494,7 +520,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     // first-round rule (128x128 / 256x64 only).
     static int tuned = -1;
     if (tuned < 0) { const char* e = getenv("RS_CONV_TUNED"); tuned = e ? atoi(e) : 1; }
-    const int nk = smallc ? 0 : p.KH * p.KW * (p.Cin >> 6);
+    const int nk = smallc ? 0 : p.KH * p.KW * (p.Cin >> 6) + nk2;
     const long long tiles0 = (long long)cdiv(p.M, 128) * (rows / 128 > 0 ? rows / 128 : 1);
     const long long tiles4 = (long long)cdiv(p.M, 256) * (rows / 256 > 0 ? rows / 256 : 1);
     if (rows <= 16) v = 2;
@@ -503,7 +529,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     else if (rows % 256 == 0 && nk >= 8 && tiles4 >= 240) {                 // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
       static int stag = -1;
       if (stag < 0) { const char* e = getenv("RS_CONV_STAGGER"); stag = e ? atoi(e) : 0; }
-      if (stag && use_glds > 0) { g_last_conv_variant = 11; return launch_conv_stag(p, stream); }
+      if (stag && use_glds > 0 && !p.in2) { g_last_conv_variant = 11; return launch_conv_stag(p, stream); }
       v = 4;
     }
     else if (rows % 256 == 0 && nk <= 4 && p.M >= 100000) v = 10;           // HBM-bound 1x1 expansions on big maps: 64x256, rows read once

@@ -187,11 +187,12 @@ struct rs_engine {
   int build();
   int add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k, int stride,
                int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile = 1,
-               const int* m_count = nullptr);
+               const int* m_count = nullptr, const Act* in2 = nullptr, int stride2 = 1);
   int run(const uint8_t* tiles, int n, int phase = -1);
   int run_stages(int n, bool record, int phase = -1);
   int assign_phases();
   int use_graph = 0;
+  int fuse_shortcut = 1;
   long long forward_index = 0;
   std::set<int> warmed;
   std::map<int, hipGraphExec_t> graphs;
@@ -237,7 +238,7 @@ int rs_engine::parse_blob(const void* data, size_t nbytes) {
 // `m_count` = optional device-side count of units actually present.
 int rs_engine::add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k,
                         int stride, int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile,
-                        const int* m_count) {
+                        const int* m_count, const Act* in2, int stride2) {
   const BlobEntry* w = findw(wname);
   const BlobEntry* b = find(wname + ".b");
   RS_CHECK(w && b, RS_ERR_BLOB, "weights for %s missing from blob", wname.c_str());
@@ -255,6 +256,11 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
   p.out_Hp = out.Hp(); p.out_Wp = out.Wp(); p.out_Cs = out.C; p.out_pad = out.pad;
   if (up) { p.up_Hp = up->Hp(); p.up_Wp = up->Wp(); p.up_Cs = up->C; p.up_pad = up->pad; }
   p.relu = relu ? 1 : 0;
+  if (in2) {   // second K source: 1x1 taps at stride2 (projection shortcut folded into conv3)
+    RS_CHECK((out.H - 1) * stride2 < in2->H && (out.W - 1) * stride2 < in2->W && in2->C % 64 == 0, RS_ERR_ARG, "%s: second source geometry", name.c_str());
+    p.in2 = in2->p; p.in2_Hp = in2->Hp(); p.in2_Wp = in2->Wp(); p.in2_Cs = in2->C; p.in2_off = in2->pad;
+    p.stride2 = stride2; p.Cin2 = in2->C;
+  }
   RS_CHECK(in.pad >= pad, RS_ERR_ARG, "%s: input halo %d < conv pad %d", name.c_str(), in.pad, pad);
   RS_CHECK((int)w->dims[0] >= out.C, RS_ERR_BLOB, "%s: weight rows %lld < Cout %d", name.c_str(), (long long)w->dims[0], out.C);
   RS_CHECK((out.H - 1) * stride + k - 2 * pad <= in.H + (stride - 1), RS_ERR_ARG, "%s: geometry", name.c_str());
@@ -284,8 +290,9 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
   p.m_mul = out.H * out.W;
   Stage st;
   st.name = name;
-  st.flops_per_image = 2.0 * m_per_image * (double)k * k * cin_real * out.C;
-  st.bytes_per_image = 2.0 * ((double)in.H * in.W * in.C * units_per_tile + (double)m_per_image * out.C * (1 + (res ? 1 : 0)));
+  st.flops_per_image = 2.0 * m_per_image * ((double)k * k * cin_real + (in2 ? in2->C : 0)) * out.C;
+  st.bytes_per_image = 2.0 * ((double)in.H * in.W * in.C * units_per_tile + (double)m_per_image * out.C * (1 + (res ? 1 : 0)) +
+                              (in2 ? (double)m_per_image * in2->C : 0.0));
   const int glds = use_glds;
   st.fn = [p, m_per_image, glds](int n, hipStream_t s) mutable {
     p.M = n * m_per_image;
@@ -388,14 +395,23 @@ int rs_engine::build() {
       if ((rc = new_act(&t2, nm + ".conv2", NB, oh, ow, bott, 1))) return rc;
       if ((rc = new_act(&out, bi == S.res_blocks[si] - 1 ? "res" + std::to_string(si + 2) : nm + ".out", NB, oh, ow, cout, 1))) return rc;
       const Act* resid = &cur;
-      if (cur.C != cout) {
+      // Projection shortcut: in the fp16 path it is folded into conv3 as a second K source (one GEMM over
+      // [conv2 out ; block input], no shortcut tensor written or re-read); the fp32 validation path and
+      // RS_FUSE_SHORTCUT=0 keep the reference's two-convolution form.
+      const bool proj = cur.C != cout;
+      const bool fuse_sc = proj && !f32 && fuse_shortcut && s3 == 1 && cur.C % 64 == 0 && findw(wn + ".conv3sc") != nullptr;
+      if (proj && !fuse_sc) {
         if ((rc = new_act(&sc, nm + ".shortcut", NB, oh, ow, cout, 1))) return rc;
         if ((rc = add_conv(nm + ".shortcut", wn + ".shortcut", cur, sc, 1, stride, 0, false, nullptr, nullptr, cur.C))) return rc;
         resid = &sc;
       }
       if ((rc = add_conv(nm + ".conv1", wn + ".conv1", cur, t1, 1, s1, 0, true, nullptr, nullptr, cur.C))) return rc;
       if ((rc = add_conv(nm + ".conv2", wn + ".conv2", t1, t2, 3, s3, 1, true, nullptr, nullptr, bott))) return rc;
-      if ((rc = add_conv(nm + ".conv3", wn + ".conv3", t2, out, 1, 1, 0, true, resid, nullptr, bott))) return rc;
+      if (fuse_sc) {
+        if ((rc = add_conv(nm + ".conv3", wn + ".conv3sc", t2, out, 1, 1, 0, true, nullptr, nullptr, bott, 1, nullptr, &cur, stride))) return rc;
+      } else {
+        if ((rc = add_conv(nm + ".conv3", wn + ".conv3", t2, out, 1, 1, 0, true, resid, nullptr, bott))) return rc;
+      }
       cur = out;
       ch = oh; cw = ow;
     }
@@ -927,6 +943,8 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   e->use_glds = g ? atoi(g) : 1;
   e->f32 = spec->precision == 1;
   if (e->f32) e->use_glds = -1;
+  const char* fs = getenv("RS_FUSE_SHORTCUT");
+  e->fuse_shortcut = fs ? atoi(fs) : 1;
   const char* gg = getenv("RS_USE_GRAPH");
   e->use_graph = gg ? atoi(gg) : 0;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
@@ -1096,9 +1114,10 @@ int rs_engine_net_shape(rs_engine* e, int* rh, int* rw, int* ph, int* pw) {
 }
 
 // ------------------------------------------------------------------------- stand-alone operators
-int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual, const void* upsample_add,
-                 int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
-                 int out_halo, int relu, int out_f32, int deconv2x, int variant, int use_glds, void* stream) {
+static int op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual, const void* upsample_add,
+                     int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
+                     int out_halo, int relu, int out_f32, int deconv2x, int variant, int use_glds, void* stream,
+                     const void* in2, int h2, int w2, int cin2, int in2_halo, int stride2) {
   RS_CHECK(in && w && bias && out, RS_ERR_ARG, "null argument");
   RS_CHECK(in_halo >= pad, RS_ERR_ARG, "input halo %d < pad %d", in_halo, pad);
   const int ho = (hi + 2 * pad - kh) / stride + 1, wo = (wi + 2 * pad - kw) / stride + 1;
@@ -1113,6 +1132,11 @@ int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, co
   p.out_Hp = oh + 2 * out_halo; p.out_Wp = ow + 2 * out_halo; p.out_Cs = cout; p.out_pad = out_halo;
   if (upsample_add) { p.up_Hp = ho / 2 + 2 * out_halo; p.up_Wp = wo / 2 + 2 * out_halo; p.up_Cs = cout; p.up_pad = out_halo; }
   p.relu = relu; p.mode = deconv2x ? 1 : 0; p.out_f32 = out_f32;
+  if (in2) {
+    RS_CHECK(stride2 >= 1 && (ho - 1) * stride2 < h2 && (wo - 1) * stride2 < w2, RS_ERR_ARG, "second source geometry");
+    p.in2 = (const half_t*)in2; p.in2_Hp = h2 + 2 * in2_halo; p.in2_Wp = w2 + 2 * in2_halo; p.in2_Cs = cin2;
+    p.in2_off = in2_halo; p.stride2 = stride2; p.Cin2 = cin2;
+  }
   int* koff_dev = nullptr;
   if (cin < 64) {
     RS_CHECK(cin == 8, RS_ERR_UNSUPPORTED, "small-Cin path needs cin == 8");
@@ -1128,6 +1152,22 @@ int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, co
     hipFree(koff_dev);
   }
   return rc;
+}
+
+int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual, const void* upsample_add,
+                 int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
+                 int out_halo, int relu, int out_f32, int deconv2x, int variant, int use_glds, void* stream) {
+  return op_conv2d(in, w, bias, out, residual, upsample_add, n, hi, wi, cin, in_halo, kh, kw, stride, pad, cout, kpad, out_halo,
+                   relu, out_f32, deconv2x, variant, use_glds, stream, nullptr, 0, 0, 0, 0, 1);
+}
+
+int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const float* bias, void* out,
+                      int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad,
+                      int h2, int w2, int cin2, int in2_halo, int stride2,
+                      int cout, int kpad, int out_halo, int relu, int variant, void* stream) {
+  RS_CHECK(in2, RS_ERR_ARG, "null argument");
+  return op_conv2d(in, w, bias, out, nullptr, nullptr, n, hi, wi, cin, in_halo, kh, kw, stride, pad, cout, kpad, out_halo,
+                   relu, 0, 0, variant, 1, stream, in2, h2, w2, cin2, in2_halo, stride2);
 }
 
 int rs_op_nms(const float* boxes, const int32_t* counts, const uint8_t* valid, uint8_t* keep, int segments, int cap,

@@ -210,6 +210,17 @@ def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], w_dtype=np.float1
         else:
             T[name + ".w"] = _ohwi(w, cin, w_dtype)
         T[name + ".b"] = b.astype(np.float32)
+    # first block of every res stage: conv3 and the projection shortcut as one GEMM over K = [conv2 out | block input]
+    # (fp16 path only; [EXT d2: modeling/backbone/resnet.py BottleneckBlock.forward] adds the two conv outputs)
+    if w_dtype == np.float16:
+        for name in [n for n in list(T) if n.endswith(".shortcut.w")]:
+            blk = name[: -len(".shortcut.w")]
+            w3, _ = _fold_bn(W, blk + ".conv3", spec.bn_eps)
+            wsc, _ = _fold_bn(W, blk + ".shortcut", spec.bn_eps)
+            if w3.shape[1] % 64 or wsc.shape[1] % 64:
+                continue
+            T[blk + ".conv3sc.w"] = np.concatenate([_ohwi(w3, w3.shape[1], w_dtype), _ohwi(wsc, wsc.shape[1], w_dtype)], 1)
+            T[blk + ".conv3sc.b"] = (T[blk + ".conv3.b"] + T[blk + ".shortcut.b"]).astype(np.float32)
     # RPN heads fused into one 1x1 conv: rows [0,A) objectness, [A,5A) deltas (a*4+d), padded to 16
     p = "proposal_generator.rpn_head."
     w = np.concatenate([W[p + "objectness_logits.weight"], W[p + "anchor_deltas.weight"]], 0).astype(np.float32)

@@ -200,6 +200,46 @@ def test_fc_gemm(gpu_required):
     _check_close(got, ref, tol=3e-3)
 
 
+@pytest.mark.parametrize("cin,cin2,cout,stride2,hw,variant", [
+    (64, 64, 256, 1, (37, 41), -1),      # res2.0: conv3 64->256 + shortcut 64->256
+    (64, 64, 256, 1, (37, 41), 0),
+    (128, 256, 512, 2, (26, 30), -1),    # res3.0: conv3 128->512 + stride-2 shortcut 256->512
+    (128, 256, 512, 2, (26, 30), 7),
+    (128, 256, 512, 2, (26, 30), 10),
+    (256, 512, 1024, 2, (19, 17), 4),    # res4.0 on the 256x256 tile
+])
+def test_bottleneck_out_dual_source(gpu_required, cin, cin2, cout, stride2, hw, variant):
+    """conv3 + projection shortcut as one GEMM over two K sources (rs_op_conv2d_dual) == relu(conv1x1(a) +
+    conv1x1_stride(b) + bias) in torch fp32."""
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(20 + cin)
+    h, w = hw
+    n = 3
+    a = _r16(torch.randn(n, cin, h, w, generator=g))
+    b = _r16(torch.randn(n, cin2, h * stride2, w * stride2, generator=g))
+    w3 = _r16(torch.randn(cout, cin, 1, 1, generator=g) * 0.08)
+    wsc = _r16(torch.randn(cout, cin2, 1, 1, generator=g) * 0.05)
+    bias = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(a, w3) + F.conv2d(b, wsc, stride=stride2) + bias.view(1, -1, 1, 1))
+    ad = _halo(a.permute(0, 2, 3, 1).half().contiguous(), 1).to(dev)
+    bd = _halo(b.permute(0, 2, 3, 1).half().contiguous(), 1).to(dev)
+    wcat = np.concatenate([_ohwi(w3.numpy(), cin), _ohwi(wsc.numpy(), cin2)], 1)
+    wd = torch.from_numpy(wcat).to(dev)
+    bsd = bias.to(dev)
+    od = torch.zeros((n, h + 2, w + 2, cout), dtype=torch.float16, device=dev)
+    torch.cuda.synchronize()
+    rc = lib.rs_op_conv2d_dual(C.c_void_p(ad.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_void_p(bsd.data_ptr()),
+                               C.c_void_p(od.data_ptr()), n, h, w, cin, 1, 1, 1, 1, 0, h * stride2, w * stride2, cin2, 1, stride2,
+                               cout, wcat.shape[1], 1, 1, variant, None)
+    _check(lib, rc, "rs_op_conv2d_dual")
+    torch.cuda.synchronize()
+    o = od.cpu().float()
+    inner = o[:, 1:-1, 1:-1]
+    assert float(o.abs().sum()) == pytest.approx(float(inner.abs().sum()), rel=1e-6), "kernel wrote into the halo"
+    _check_close(inner.permute(0, 3, 1, 2), ref)
+
+
 def test_rejects_bad_shapes(gpu_required):
     lib = load_library()
     rc = lib.rs_op_conv2d(C.c_void_p(1), C.c_void_p(1), C.c_void_p(1), C.c_void_p(1), None, None,
