@@ -167,11 +167,14 @@ def main():
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")     # written by tools/pmc_summary.py from two --pmc passes
         if os.path.exists(pmc) and B == 16 and T == 512:
-            want = dom.split(">")[0].replace("conv_igemm_kernel<", "").replace(",", ", ")      # "2, 4, 4, 8"
+            sym = dom.split(" ")[0]                                   # "conv_deep_kernel" or "conv_igemm_kernel<2,4,4,8>"
+            want = sym.replace("conv_igemm_kernel<", "").replace(">", "").replace(",", ", ")
             for k in json.load(open(pmc)):
-                if f"conv_igemm_kernel<{want}, false, true>" in k["kernel"]:
+                hit = (f"conv_igemm_kernel<{want}, false, true" in k["kernel"]) if sym.startswith("conv_igemm") else (sym in k["kernel"])
+                if hit:
                     traffic = k["hbm_bytes_per_launch_corrected"]
                     traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, (2*FETCH+WRITE)*1024 per launch"
+                    break
         roofline = {"bound": "mfma", "kernel": dom + " (fp16 MFMA 16x16x32, fp32 accumulate)",
                     "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src,

@@ -106,3 +106,4 @@ int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, in
 int launch_conv_f32(const ConvParams& p, hipStream_t stream);
 int launch_conv_pipe(const ConvParams& p, hipStream_t stream);
 int launch_conv_stag(const ConvParams& p, hipStream_t stream);
+int launch_conv_deep(const ConvParams& p, hipStream_t stream);

@@ -1,0 +1,292 @@
+// 256x256 implicit-GEMM conv with a DEEPER ACTIVATION PREFETCH, for the deep-K layers (3x3 256->256 of
+// FPN/RPN/mask head, fc1/fc2, res4/res5 conv2).
+//
+// Same math, operand roles (weights = MFMA A operand, activations = B operand, v_mfma_f32_16x16x32_f16),
+// LDS-DMA staging, 128-byte XOR-swizzled LDS rows, lockstep schedule and epilogue as the 256x256 variant of
+// conv_igemm.hip.  What changes is the LDS budget: that kernel double-buffers both operands (2 x 64 KB), so
+// every operand byte has ONE K step (~1 us of MFMA work) to arrive, and with one resident workgroup per CU
+// nothing else runs while it waits (rocprofv3: MFMA busy 45-49 %, L2 hit ~70 % -> a third of the activation
+// rows come from HBM/MALL with more latency than that).  Here the 160 KB are split by operand:
+//
+//      activations   3 stages x 32 KB   -> issued TWO K steps ahead
+//      weights       2 stages x 32 KB   -> issued one step ahead (the 1.2 MB filter stays L2-resident)
+//
+// Issue order is always weights then activations, so the wait that publishes a step is `s_waitcnt vmcnt(4)`:
+// everything but the 4 youngest LDS-DMA pieces (the activations two steps ahead) has landed; raw s_barrier.
+// The fragment reads are software-pipelined over half K steps against the MFMAs (see the main loop).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, NT = 512, MI = 4, NJ = 8, WCH = 4;
+constexpr int ASTAGE = BM * 128, WSTAGE = BN * 128;       // 32 KB each
+constexpr int W_BASE = 3 * ASTAGE;
+constexpr int LDS_BYTES = 3 * ASTAGE + 2 * WSTAGE;        // 160 KB
+
+__device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int DBG>
+__global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wpx = wave / WCH, wch = wave % WCH;
+
+  int M = p.M;
+  if (p.m_count) {
+    long long mc = (long long)(*p.m_count) * p.m_mul;
+    if (mc < M) M = (int)mc;
+  }
+  const int tiles_n = p.Cout / BN;
+  const int ntiles = tiles_n * ((M + BM - 1) / BM);
+  const int q = blockIdx.x;
+  if (q >= ntiles) return;
+  int m0, n0;
+  {
+    const int qn = ntiles >> 3, r = ntiles & 7, x = q & 7;      // XCD-aware order, see conv_igemm.hip
+    const int L = (x < r ? x * (qn + 1) : r * (qn + 1) + (x - r) * qn) + (q >> 3);
+    n0 = (L % tiles_n) * BN;
+    m0 = (L / tiles_n) * BM;
+  }
+
+  // ---- staging pointers (identical to conv_igemm<2,4,4,8>): 4 passes of 64 rows for each operand
+  const int lrow = lane >> 3, lchk = lane & 7;
+  const half_t* aptr[4];
+  const half_t* wptr[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    int m = m0 + ps * 64 + wave * 8 + lrow;
+    if (m >= M) m = M - 1;
+    const int x = m % p.Wo;
+    const int t = m / p.Wo;
+    const int y = t % p.Ho;
+    const int n = t / p.Ho;
+    const long long base =
+        ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x * p.stride + p.in_off) * p.in_Cs;
+    aptr[ps] = p.in + base + (lchk ^ lrow) * 8;
+    const int row = ps * 64 + wave * 8 + lrow;
+    const int key = (row & 3) | (((row >> 4) & 1) << 2);
+    wptr[ps] = p.w + (long long)(n0 + row) * p.Kpad + (lchk ^ key) * 8;
+  }
+  const int nk = p.KH * p.KW * (p.Cin >> 6);
+
+  // two independent walkers over the K steps (64-channel slice outer, taps inner -- conv_igemm.hip): the
+  // activation walker runs one step ahead of the weight walker
+  int akh = 0, akw = 0, ac0 = 0, an = 0;      // an = index of the next activation step to issue
+  auto stage_a = [&]() {
+    const int off = (akh * p.in_Wp + akw) * p.in_Cs + ac0;
+    if (++akw == p.KW) { akw = 0; if (++akh == p.KH) { akh = 0; ac0 += 64; } }
+    char* abase = smem + (an % 3) * ASTAGE;
+    ++an;
+    if (DBG & 1) return;   // ceiling experiment: no global traffic
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) glds16(aptr[ps] + off, abase + (ps * 64 + wave * 8) * 128);
+  };
+  int wkh = 0, wkw = 0, wc0 = 0, wn = 0;
+  auto stage_w = [&]() {
+    const int koff = (wkh * p.KW + wkw) * p.Cin + wc0;
+    if (++wkw == p.KW) { wkw = 0; if (++wkh == p.KH) { wkh = 0; wc0 += 64; } }
+    char* wbase = smem + W_BASE + (wn & 1) * WSTAGE;
+    ++wn;
+    if (DBG & 1) return;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) glds16(wptr[ps] + koff, wbase + (ps * 64 + wave * 8) * 128);
+  };
+
+  const int fi = lane & 15, fq = lane >> 4, fkey = lane & 7;
+  int w_off[MI], x_off[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) w_off[i] = W_BASE + (wch * 64 + (fi >> 2) * 16 + i * 4 + (fi & 3)) * 128;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) x_off[j] = (wpx * 128 + j * 16 + fi) * 128;
+  const int c0_off = (fq ^ fkey) * 16, c1_off = ((4 + fq) ^ fkey) * 16;
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Software pipeline over half K steps.  F0 / F1 hold the fragments of the first / second 32-deep half of a
+  // step.  While the MFMAs of one half run, the reads of the next half are in flight; the workgroup barrier that
+  // publishes step t+1 sits in the MIDDLE of step t (after the first half's MFMAs), so the reads of
+  // step t+1's first half overlap the MFMAs of step t's second half:
+  //
+  //   reads F1(t) | MFMA F0(t) | wait own pieces of t+1, barrier | issue w(t+2), acts(t+3) | reads F0(t+1) | MFMA F1(t)
+  //
+  // At the barrier every wave has finished reading step t's buffers (lgkmcnt(0)), so they are refilled there.
+  // The fragment reads are inline asm: hipcc's own waitcnt insertion drains lgkmcnt(0) before the first MFMA of a
+  // half step even though only the OLDER twelve reads feed it, which serialises the LDS phase against the matrix
+  // phase again.  With asm reads the compiler sees no pending LDS operation; the counted waits below are the only
+  // ones, fenced with sched_barrier on both sides (MFMAs are register-only and would otherwise move across them).
+  half8 wf0[MI], xf0[NJ], wf1[MI], xf1[NJ];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned wrow = (unsigned)(W_BASE + (wch * 64 + (fi >> 2) * 16 + (fi & 3)) * 128);
+  const unsigned xrow = (unsigned)((wpx * 128 + fi) * 128);
+  const unsigned wa0 = lds0 + wrow + c0_off, wa1 = lds0 + wrow + c1_off;
+  const unsigned xa0 = lds0 + xrow + c0_off, xa1 = lds0 + xrow + c1_off;
+#define RS_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define RS_READS(wf, xf, wa, xa)                                                        \
+  RS_DSR(wf[0], wa, 0); RS_DSR(wf[1], wa, 512); RS_DSR(wf[2], wa, 1024); RS_DSR(wf[3], wa, 1536);   \
+  RS_DSR(xf[0], xa, 0); RS_DSR(xf[1], xa, 2048); RS_DSR(xf[2], xa, 4096); RS_DSR(xf[3], xa, 6144);  \
+  RS_DSR(xf[4], xa, 8192); RS_DSR(xf[5], xa, 10240); RS_DSR(xf[6], xa, 12288); RS_DSR(xf[7], xa, 14336);
+  auto reads0 = [&](int ab, int wb) {
+    const unsigned wa = wa0 + ((DBG & 2) ? 0 : wb) * WSTAGE, xa = xa0 + ((DBG & 2) ? 0 : ab) * ASTAGE;
+    RS_READS(wf0, xf0, wa, xa)
+  };
+  auto reads1 = [&](int ab, int wb) {
+    const unsigned wa = wa1 + ((DBG & 2) ? 0 : wb) * WSTAGE, xa = xa1 + ((DBG & 2) ? 0 : ab) * ASTAGE;
+    RS_READS(wf1, xf1, wa, xa)
+  };
+  // prologue: w(0), acts(0), acts(1); publish step 0; then w(1), acts(2) and the first fragments
+  stage_w();
+  stage_a();
+  if (nk > 1) stage_a();
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if (nk > 1) stage_w();
+  if (nk > 2) stage_a();
+  reads0(0, 0);
+  int abuf = 0;                                  // t % 3
+  for (int t = 0; t < nk; ++t) {
+    __builtin_amdgcn_sched_barrier(0);
+    reads1(abuf, t & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");          // F0 (the 12 older reads) has landed; F1 stays in flight
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int anext = abuf == 2 ? 0 : abuf + 1;
+    if (t + 1 < nk) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // F1 landed = my reads of step t's buffers are done
+      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my pieces of step t+1 (all but acts(t+2))
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < nk) stage_w();                 // w(t+2)    -> weight buffer of step t
+      if (t + 3 < nk) stage_a();                 // acts(t+3) -> activation buffer of step t
+      reads0(anext, (t + 1) & 1);
+    }
+    else {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // last step: F1 has landed
+    }
+    abuf = anext;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+  }
+
+  // ---- epilogue (as conv_igemm.hip, mode 0): lane holds channels crow .. crow+15 of pixel (j, fi)
+  const int crow = n0 + wch * 64 + fq * 16;
+  float bias[16];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
+    bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int m = m0 + wpx * 128 + j * 16 + fi;
+    if (m >= M) continue;
+    const int x = m % p.Wo;
+    const int t = m / p.Wo;
+    const int y = t % p.Ho;
+    const int n = t / p.Ho;
+    const long long opix = (long long)(n * p.out_Hp + y + p.out_pad) * p.out_Wp + x + p.out_pad;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+    if (p.res) {
+      const half_t* rp = p.res + opix * p.out_Cs + crow;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const half4 h = *(const half4*)(rp + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+      }
+    }
+    if (p.up) {
+      const long long upix = (long long)(n * p.up_Hp + (y >> 1) + p.up_pad) * p.up_Wp + (x >> 1) + p.up_pad;
+      const half_t* up = p.up + upix * p.up_Cs + crow;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const half4 h = *(const half4*)(up + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+      }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    if (p.out_f32) {
+      float* op = (float*)p.out + opix * p.out_Cs + crow;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) *(f32x4*)(op + i * 4) = f32x4{v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+    } else {
+      half_t* op = (half_t*)p.out + opix * p.out_Cs + crow;
+#pragma unroll
+      for (int i = 0; i < MI; i += 2) {
+        half8 h;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float f = v[i * 4 + r];
+          f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+          h[r] = (half_t)f;
+        }
+        *(half8*)(op + i * 4) = h;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Requirements: mode 0, single K source, Cin % 64 == 0, Cout % 256 == 0.
+int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
+  RS_CHECK(p.mode == 0 && !p.in2 && p.Cin % 64 == 0 && p.Cout % BN == 0 && p.M > 0, RS_ERR_ARG,
+           "conv_deep: unsupported shape (mode %d, Cin %d, Cout %d)", p.mode, p.Cin, p.Cout);
+  static bool done = false;
+  if (!done) {
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+#ifdef RS_DEEP_CEILING
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+#endif
+    done = true;
+  }
+  // Ceiling experiments (built only with -DRS_DEEP_CEILING; results are WRONG by construction): DBG bit 0 = no global
+  // traffic, bit 1 = every step reads LDS stage 0.  Measured round 1, fpn_output2 (755 GFLOP): full kernel 0.644 ms,
+  // without global traffic 0.534 ms -> the LDS+MFMA+epilogue schedule alone caps this kernel at ~1.41 PFLOP/s.
+#ifdef RS_DEEP_CEILING
+  static const int dbg = [] { const char* e = getenv("RS_DEEP_DBG"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int dbg = 0;
+#endif
+  const long long nblk = (long long)(p.Cout / BN) * cdiv(p.M, BM);
+  RS_CHECK(nblk < (1ll << 31), RS_ERR_ARG, "conv_deep: grid too large");
+#ifdef RS_DEEP_CEILING
+  if (dbg == 1) { hipLaunchKernelGGL(conv_deep_kernel<1>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
+  if (dbg == 3) { hipLaunchKernelGGL(conv_deep_kernel<3>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
+#endif
+  (void)dbg;
+  hipLaunchKernelGGL(conv_deep_kernel<0>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}

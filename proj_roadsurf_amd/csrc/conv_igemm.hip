@@ -514,6 +514,11 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     g_last_conv_variant = 11;
     return launch_conv_stag(p, stream);
   }
+  if (v == 12) {                        // 256x256 with 3 activation stages / 2 weight stages (conv_deep.hip)
+    RS_CHECK(!p.in2, RS_ERR_UNSUPPORTED, "conv: variant 12 has no second K source");
+    g_last_conv_variant = 12;
+    return launch_conv_deep(p, stream);
+  }
   if (v < 0) {
     // Tile choice from the offline sweep over every layer shape of the batch-16 forward
     // (tools/ubench/tune_conv.py, profiles/r01/conv_tile_sweep.txt).  RS_CONV_TUNED=0 restores the
@@ -530,6 +535,9 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
       static int stag = -1;
       if (stag < 0) { const char* e = getenv("RS_CONV_STAGGER"); stag = e ? atoi(e) : 0; }
       if (stag && use_glds > 0 && !p.in2) { g_last_conv_variant = 11; return launch_conv_stag(p, stream); }
+      static int deep = -1;
+      if (deep < 0) { const char* e = getenv("RS_CONV_DEEP"); deep = e ? atoi(e) : 1; }
+      if (deep && use_glds > 0 && !p.in2) { g_last_conv_variant = 12; return launch_conv_deep(p, stream); }
       v = 4;
     }
     else if (rows % 256 == 0 && nk <= 4 && p.M >= 100000) v = 10;           // HBM-bound 1x1 expansions on big maps: 64x256, rows read once

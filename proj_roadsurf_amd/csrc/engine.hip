@@ -1073,9 +1073,10 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
                                 "conv_igemm_kernel<4,2,4,4> 256x128", "conv_igemm_kernel<2,4,4,8> 256x256", "conv_igemm_kernel<4,1,4,4,smallC> 256x64 stem",
                                 "conv_pipe_kernel 256x256 (4-stage LDS ring, register-double-buffered fragments)",
                                 "conv_igemm_kernel<2,2,4,2> 64x128", "conv_igemm_kernel<4,1,4,2> 128x64", "conv_igemm_kernel<2,2,4,1> 32x128",
-                                "conv_igemm_kernel<2,4,4,2> 64x256", "conv_stag_kernel 256x256 (two wave groups one phase apart)"};
+                                "conv_igemm_kernel<2,4,4,2> 64x256", "conv_stag_kernel 256x256 (two wave groups one phase apart)",
+                                "conv_deep_kernel 256x256 (3 activation + 2 weight LDS stages)"};
   const int v = e->stages[i].variant;
-  const char* s = v == -1 ? "conv_f32_kernel" : (v >= 0 && v <= 11 ? names[v] : "");
+  const char* s = v == -1 ? "conv_f32_kernel" : (v >= 0 && v <= 12 ? names[v] : "");
   strncpy(name_out, s, 95);
   name_out[95] = 0;
   return RS_OK;

@@ -13,46 +13,65 @@
 #include "common.h"
 
 __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)p.N * p.new_h * p.new_w;
-  if (gid >= total) return;
-  const int X = (int)(gid % p.new_w);
-  const long long t = gid / p.new_w;
-  const int Y = (int)(t % p.new_h);
-  const int n = (int)(t / p.new_h);
+  // block = 64 output columns x 4 rows of one tile (no integer divisions)
+  const int X = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.z;
+  if (X >= p.new_w || Y >= p.new_h) return;
   int ymin = Y, ny = 1, xmin = X, nx = 1;
   if (p.need_v) { ymin = p.vb[Y * 2]; ny = p.vb[Y * 2 + 1]; }
   if (p.need_h) { xmin = p.hb[X * 2]; nx = p.hb[X * 2 + 1]; }
   const uint8_t* img = p.tiles + (long long)n * p.H * p.W * p.C;
+  const int C = p.C;
+  // all channels of a source pixel are adjacent bytes: walk the taps once and carry one accumulator per channel
+  // (same integer arithmetic per channel as Pillow's ImagingResampleHorizontal_8bpc / Vertical_8bpc).
+  int vacc[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+  int val[4] = {0, 0, 0, 0};
+  const int* hk = p.hk + (long long)X * p.ksh;
+  const int* vk = p.vk + (long long)Y * p.ksv;
+  for (int ty = 0; ty < ny; ++ty) {
+    const uint8_t* row = img + ((long long)(ymin + ty) * p.W) * C;
+    int h[4] = {0, 0, 0, 0};
+    if (p.need_h) {
+      int ss[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+      for (int tx = 0; tx < nx; ++tx) {
+        const uint8_t* px = row + (xmin + tx) * C;
+        const int k = hk[tx];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) ss[c] += (int)px[c] * k;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const int v = ss[c] >> 22; h[c] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    } else {
+      const uint8_t* px = row + X * C;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (c < C) h[c] = px[c];
+    }
+    if (p.need_v) {
+      const int k = vk[ty];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vacc[c] += h[c] * k;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) val[c] = h[c];
+    }
+  }
   half4 o;
   float of[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) { o[c] = (half_t)0.f; of[c] = 0.f; }
-  for (int c = 0; c < p.C; ++c) {
-    const int cs = p.flip ? (p.C - 1 - c) : c;
-    int vacc = 1 << 21;
-    int val = 0;
-    for (int ty = 0; ty < ny; ++ty) {
-      const uint8_t* row = img + ((long long)(ymin + ty) * p.W) * p.C + cs;
-      int h;
-      if (p.need_h) {
-        int ss = 1 << 21;
-        for (int tx = 0; tx < nx; ++tx) ss += (int)row[(xmin + tx) * p.C] * p.hk[X * p.ksh + tx];
-        h = ss >> 22;
-        h = h < 0 ? 0 : (h > 255 ? 255 : h);
-      } else {
-        h = row[X * p.C];
-      }
-      if (p.need_v) vacc += h * p.vk[Y * p.ksv + ty];
-      else val = h;
+  for (int c = 0; c < 4; ++c) {
+    o[c] = (half_t)0.f;
+    of[c] = 0.f;
+    if (c < C) {
+      const int cs = p.flip ? (C - 1 - c) : c;      // model channel c reads source channel cs
+      int v = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (q == cs) v = p.need_v ? (vacc[q] >> 22) : val[q];
+      if (p.need_v) v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      const float f = ((float)v - p.mean[c]) / p.stdv[c];
+      o[c] = (half_t)f;
+      of[c] = f;
     }
-    if (p.need_v) {
-      val = vacc >> 22;
-      val = val < 0 ? 0 : (val > 255 ? 255 : val);
-    }
-    const float f = ((float)val - p.mean[c]) / p.stdv[c];
-    o[c] = (half_t)f;
-    of[c] = f;
   }
   const long long oidx = (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 4;
   if (p.out_f32) {
@@ -63,8 +82,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) 
 }
 
 int launch_preprocess(const PreprocParams& p, hipStream_t s) {
-  const long long total = (long long)p.N * p.new_h * p.new_w;
-  hipLaunchKernelGGL(preprocess_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(preprocess_kernel, dim3(cdiv(p.new_w, 64), cdiv(p.new_h, 4), p.N), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

@@ -99,7 +99,7 @@ def test_conv3x3_256(gpu_required, glds, variant):
     _check_close(got, ref)
 
 
-@pytest.mark.parametrize("variant", [4, 6, 11])
+@pytest.mark.parametrize("variant", [4, 6, 11, 12])
 def test_conv3x3_256_big_tiles(gpu_required, variant):
     """256x256 workgroup tile (variant 4, production for deep-K layers) and the experimental software-pipelined
     form (variant 6): ragged M (not a multiple of 256), residual + ReLU epilogue."""
