@@ -194,6 +194,23 @@ int rs_abi_version(void);
  * 256-byte aligned.  Entries "<layer>.w" (fp16 [Cout_pad][Kpad], FrozenBN folded) and
  * "<layer>.b" (fp32) for every conv/linear layer, detectron2 layer names. */
 
+/* ------------------------------------------------------------------ detections -> polygons (host code)
+ * What the object-detector's detectron2dets_to_features does per instance after the predictor returns
+ * ([EXT od: helpers/detectron2.py]; R:config/config_obj_detec.yaml:87-89): rasterio.features.shapes on the
+ * instance mask (4-connected regions, rings along pixel edges, holes) and Ramer-Douglas-Peucker (epsilon in
+ * pixels; <= 0 disables).  masks = rs_dets.masks layout, [n][h][(w+7)/8] bit-packed LSB first.  Instances are
+ * spread over `threads` host threads (0 = all cores).  The result is a flat ragged structure:
+ *   inst_poly_count[n]      polygons of every instance
+ *   poly_ring_count[np]     rings of every polygon (exterior first, then holes)
+ *   ring_len[nr]            vertices of every ring (closed: first == last)
+ *   xy[2*nv]                pixel-corner coordinates (x = column, y = row), float64
+ * Python restatement with identical vertex output: proj_roadsurf_amd/vectorize.py. */
+typedef struct rs_vec_result rs_vec_result;
+rs_vec_result* rs_vectorize_masks(const uint8_t* masks, int n, int h, int w, double rdp_epsilon, int threads);
+void rs_vec_counts(const rs_vec_result* r, int64_t* n_instances, int64_t* n_polygons, int64_t* n_rings, int64_t* n_vertices);
+int rs_vec_copy(const rs_vec_result* r, int32_t* inst_poly_count, int32_t* poly_ring_count, int32_t* ring_len, double* xy);
+void rs_vec_free(rs_vec_result* r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_resize_shape.argtypes = [i32, i32, i32, i32, i32p, i32p]
     lib.rs_resize_shape.restype = None
     lib.rs_resize_coeffs.argtypes = [i32, i32, i32p, i32p]
+    i64p, f64p = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+    lib.rs_vectorize_masks.argtypes = [vp, i32, i32, i32, C.c_double, i32]
+    lib.rs_vectorize_masks.restype = vp
+    lib.rs_vec_counts.argtypes = [vp, i64p, i64p, i64p, i64p]
+    lib.rs_vec_counts.restype = None
+    lib.rs_vec_copy.argtypes = [vp, i32p, i32p, i32p, f64p]
+    lib.rs_vec_free.argtypes = [vp]
+    lib.rs_vec_free.restype = None
     lib.rs_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
     lib.rs_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
     if path is None:

@@ -9,7 +9,7 @@ import pytest
 from scipy import ndimage
 
 from proj_roadsurf_amd.gpkg import read_gpkg, write_gpkg
-from proj_roadsurf_amd.vectorize import instances_to_features, mask_to_polygons, rdp, ring_area
+from proj_roadsurf_amd.vectorize import instances_to_features, mask_to_polygons, rdp, ring_area, vectorize_masks_native
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -71,6 +71,71 @@ class _Inst:
 
     def has(self, k):
         return True
+
+
+def _native_lib():
+    from proj_roadsurf_amd.engine import LIB_PATH
+    if not os.path.exists(LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def _restated(masks, eps):
+    out = []
+    for m in masks:
+        polys = []
+        for poly in mask_to_polygons(m):
+            rings = []
+            for r in poly:
+                rr = rdp(r, eps) if eps > 0 else list(r)
+                if len(rr) < 4:
+                    rr = list(r)
+                rings.append([(float(x), float(y)) for x, y in rr])
+            polys.append(rings)
+        out.append(polys)
+    return out
+
+
+@pytest.mark.parametrize("shape,eps", [((64, 64), 0.0), ((64, 64), 0.75), ((50, 77), 0.75), ((128, 100), 2.0)])
+def test_native_vectorizer_equals_restatement_vertex_for_vertex(shape, eps):
+    """rs_vectorize_masks (C++, multi-threaded, on the engine's bit-packed masks) == mask_to_polygons + rdp of this
+    module: same polygons, same ring order, same start vertices, identical float64 coordinates.  Cases: smooth
+    blobs, salt-and-pepper noise (many holes and diagonal contacts), empty and full masks, widths that are not a
+    multiple of 8."""
+    _native_lib()
+    h, w = shape
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    masks = []
+    for i in range(6):                                    # smooth blobs with holes
+        f = ndimage.gaussian_filter(rng.random((h, w)), 2.5 + i)
+        masks.append(f > np.quantile(f, 0.55))
+    for dens in (0.3, 0.5, 0.7):                          # noise: diagonal touches, 1-pixel holes/islands
+        masks.append(rng.random((h, w)) < dens)
+    chk = (np.add.outer(np.arange(h), np.arange(w)) % 2).astype(bool)
+    masks += [chk, ~chk, np.zeros((h, w), bool), np.ones((h, w), bool)]
+    ring = np.zeros((h, w), bool); ring[5:40, 5:45] = True; ring[10:30, 10:40] = False; ring[15:25, 15:35] = True
+    masks.append(ring)                                    # island inside a hole
+    masks = np.stack(masks)
+    packed = np.packbits(masks, axis=2, bitorder="little")
+    want = _restated(masks, eps)
+    for threads in (1, 4):
+        got = vectorize_masks_native(packed, h, w, eps, threads)
+        assert len(got) == len(want)
+        for gi, wi in zip(got, want):
+            assert gi == wi
+
+
+def test_native_vectorizer_in_features_path():
+    _native_lib()
+    from proj_roadsurf_amd.engine import Instances
+    rng = np.random.default_rng(5)
+    h, w, n = 96, 120, 7
+    masks = np.stack([ndimage.gaussian_filter(rng.random((h, w)), 4) > 0.5 for _ in range(n)])
+    inst = Instances((h, w), rng.random((n, 4)).astype(np.float32), rng.random(n).astype(np.float32), np.arange(n) % 2,
+                     np.packbits(masks, axis=2, bitorder="little"), None)
+    a = instances_to_features(inst, "t.tif", (0.0, 0.0, 120.0, 96.0), True, 0.75, native=True)
+    b = instances_to_features(inst, "t.tif", (0.0, 0.0, 120.0, 96.0), True, 0.75, native=False)
+    assert a == b and len(a) >= n
 
 
 def test_features_georeference_and_gpkg_roundtrip(tmp_path):
