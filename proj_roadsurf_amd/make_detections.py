@@ -85,6 +85,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--batch", type=int, default=16, help="tiles per engine call")
     ap.add_argument("--synthetic-weights", action="store_true",
                     help="use seeded synthetic weights instead of model_weights.pth_file (demo / smoke tests)")
+    ap.add_argument("--host-workers", type=int, default=4, help="threads for tile decode / vectorisation around the GPU call")
+    ap.add_argument("--vector-threads", type=int, default=4, help="threads inside one rs_vectorize_masks call")
     ap.add_argument("--max-tiles", type=int, default=0, help="debug: only the first N tiles of every dataset")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s", stream=sys.stderr)
@@ -126,14 +128,20 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     from .engine import Predictor      # fails loudly without librs_engine.so / a HIP device
     predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank)
 
-    def predict_batch(entries: Sequence[dict]) -> List[List[dict]]:
-        ims = [read_tile(e["file_name"]) for e in entries]
-        outs = predictor.predict_batch(ims)
+    # decode (PIL), GPU forward and vectorisation (C++, rs_vectorize_masks) overlap across batches (shard.run_sharded)
+    def prepare(entries: Sequence[dict]) -> List[Any]:
+        return [read_tile(e["file_name"]) for e in entries]
+
+    def predict_batch(ims: Sequence[Any]) -> List[Any]:
+        return predictor.predict_batch(ims)
+
+    def finish(entries: Sequence[dict], outs: List[Any]) -> List[List[dict]]:
         res = []
         for e, o in zip(entries, outs):
             ext, _ = tile_extent(meta, e["file_name"])
             res.append(instances_to_features(o["instances"], os.path.basename(e["file_name"]), ext,
-                                             bool(rdp_cfg.get("enabled", False)), float(rdp_cfg.get("epsilon", 0.75))))
+                                             bool(rdp_cfg.get("enabled", False)), float(rdp_cfg.get("epsilon", 0.75)),
+                                             threads=args.vector_threads))
         return res
 
     for dataset, d in coco.items():
@@ -141,7 +149,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         if args.max_tiles:
             images = images[: args.max_tiles]
         t0 = time.time()
-        per_tile = run_sharded(images, predict_batch, args.batch, rank, world)
+        per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
+                               workers=args.host_workers)
         if rank != 0:
             continue
         feats = [f for tile in per_tile for f in tile]
@@ -153,7 +162,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         base = f"{dataset}_detections_at_{thr_tag(thr)}_threshold"
         n = write_gpkg(base + ".gpkg", feats, table=base, epsg=epsg)
         with open(base + ".geojson", "w") as f:
-            json.dump({"type": "FeatureCollection", "features": feats}, f)
+            f.write(json.dumps({"type": "FeatureCollection", "features": feats}))   # dumps() = C encoder; dump() streams through the slow Python one
         dt = time.time() - t0
         log.info("%s: %d tiles -> %d features in %.1f s (%.1f tiles/s) -> %s.gpkg", dataset, len(images), n, dt,
                  len(images) / max(dt, 1e-9), base)

@@ -21,13 +21,38 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def run_sharded(items: Sequence[Any], predict_batch: Callable[[Sequence[Any]], List[Any]], batch: int,
-                rank: int = 0, world: int = 1, gather: bool = True) -> Optional[List[Any]]:
+                rank: int = 0, world: int = 1, gather: bool = True,
+                prepare: Optional[Callable[[Sequence[Any]], Any]] = None,
+                finish: Optional[Callable[[Sequence[Any], Any], List[Any]]] = None, workers: int = 4) -> Optional[List[Any]]:
     """Run ``predict_batch`` over this rank's block in batches of ``batch``; with ``gather`` the
-    per-item results of all ranks are returned on rank 0 in the original item order (None elsewhere)."""
+    per-item results of all ranks are returned on rank 0 in the original item order (None elsewhere).
+
+    Three-stage form (``prepare`` and/or ``finish`` given): ``prepare(batch_items)`` (tile decode) and
+    ``finish(batch_items, raw)`` (vectorisation) run on a small thread pool while the calling thread keeps the GPU
+    busy with ``predict_batch(prepared)``: batch k+1 is being decoded and batch k-1 vectorised while batch k is on
+    the device.  The reference does all three serially per tile ([EXT od] make_detections.py)."""
     lo, hi = shard_range(len(items), rank, world)
     mine: List[Any] = []
-    for i in range(lo, hi, batch):
-        mine.extend(predict_batch(items[i:min(i + batch, hi)]))
+    starts = list(range(lo, hi, batch))
+    if prepare is None and finish is None:
+        for i in starts:
+            mine.extend(predict_batch(items[i:min(i + batch, hi)]))
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        prep = prepare or (lambda b: b)
+        fin = finish or (lambda b, raw: raw)
+        chunks = [items[i:min(i + batch, hi)] for i in starts]
+        with ThreadPoolExecutor(max_workers=max(2, workers)) as pool:
+            ahead = [pool.submit(prep, c) for c in chunks[:2]]           # decode runs two batches ahead
+            done = []
+            for k, c in enumerate(chunks):
+                prepared = ahead[k].result()
+                if k + 2 < len(chunks):
+                    ahead.append(pool.submit(prep, chunks[k + 2]))
+                raw = predict_batch(prepared)
+                done.append(pool.submit(fin, c, raw))
+            for f in done:
+                mine.extend(f.result())
     if len(mine) != hi - lo:
         raise RuntimeError(f"predict_batch returned {len(mine)} results for {hi - lo} items")
     if world == 1 or not gather:

@@ -78,3 +78,34 @@ def test_run_sharded_single_process():
     assert [o["sum"] for o in out] == [i * 12 for i in range(5)]
     with pytest.raises(RuntimeError):
         run_sharded(tiles, lambda b: [], batch=2)
+
+
+def test_run_sharded_three_stage_pipeline_keeps_order_and_overlaps():
+    """prepare / predict / finish: results come back in item order, every stage sees every batch exactly once, and
+    prepare of batch k+1 has started before predict of batch k returns."""
+    import threading, time
+    items = list(range(23))
+    log, lock = [], threading.Lock()
+
+    def prepare(b):
+        with lock:
+            log.append(("prep", b[0]))
+        time.sleep(0.01)
+        return [x * 10 for x in b]
+
+    def predict(p):
+        with lock:
+            log.append(("gpu", p[0] // 10))
+        time.sleep(0.02)
+        return [x + 1 for x in p]
+
+    def finish(b, raw):
+        with lock:
+            log.append(("fin", b[0]))
+        return [(x, r) for x, r in zip(b, raw)]
+
+    out = run_sharded(items, predict, batch=4, prepare=prepare, finish=finish, workers=3)
+    assert out == [(x, x * 10 + 1) for x in items]
+    for tag in ("prep", "gpu", "fin"):
+        assert sorted(v for t, v in log if t == tag) == [0, 4, 8, 12, 16, 20]
+    assert log.index(("prep", 4)) < log.index(("gpu", 4)) and log.index(("prep", 8)) < log.index(("fin", 4)) + 3

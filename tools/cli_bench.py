@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the drop-in CLI (tile files -> GeoPackage) on synthetic data: N 512x512x3 TIFF tiles on disk,
+seeded synthetic weights, the reference's own YAML (R:config/detectron2_config_3bands.yaml defaults via EngineSpec).
+Measures what a user of make_detections.py sees: decode + H2D + forward + D2H + vectorise + write.
+
+    python tools/cli_bench.py [--tiles 256] [--batch 16] [--host-workers 4] [--vector-threads 4]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--host-workers", type=int, default=4)
+    ap.add_argument("--vector-threads", type=int, default=4)
+    args = ap.parse_args()
+    import yaml
+    from PIL import Image
+    from proj_roadsurf_amd import make_detections
+    from tests.util import synthetic_tiles
+
+    with tempfile.TemporaryDirectory() as td:
+        wd = os.path.join(td, "obj_detector")
+        os.makedirs(os.path.join(wd, "oth-images"))
+        base = synthetic_tiles(16, 512, 512, 3, seed=1234)
+        images, meta = [], {}
+        for i in range(args.tiles):
+            fn = f"oth-images/18_{1000 + i}_2000.tif"
+            Image.fromarray(base[i % 16][:, :, ::-1]).save(os.path.join(wd, fn))
+            images.append({"id": i, "file_name": fn, "width": 512, "height": 512})
+            meta[fn] = {"extent": [100.0 * i, 0.0, 100.0 * i + 104.6, 104.6], "crs": "EPSG:3857"}
+        cats = [{"id": 1, "name": "artificial"}, {"id": 2, "name": "natural"}]
+        json.dump({"images": images, "annotations": [], "categories": cats}, open(os.path.join(wd, "COCO_oth.json"), "w"))
+        json.dump(meta, open(os.path.join(wd, "img_metadata.json"), "w"))
+        yaml.safe_dump({"INPUT": {"FORMAT": "RGB"}}, open(os.path.join(td, "d2.yaml"), "w"))     # everything else: reference defaults
+        cfg = {"make_detections.py": {"working_directory": wd, "log_subfolder": "logs", "image_metadata_json": "img_metadata.json",
+                                      "COCO_files": {"oth": "COCO_oth.json"}, "detectron2_config_file": os.path.join(td, "d2.yaml"),
+                                      "model_weights": {"pth_file": "logs/model_0005999.pth"},
+                                      "rdp_simplification": {"enabled": True, "epsilon": 0.75}, "score_lower_threshold": 0.05}}
+        yaml.safe_dump(cfg, open(os.path.join(td, "config.yaml"), "w"))
+        cwd = os.getcwd()
+        t0 = time.time()
+        rc = make_detections.main([os.path.join(td, "config.yaml"), "--synthetic-weights", "--batch", str(args.batch),
+                                   "--host-workers", str(args.host_workers), "--vector-threads", str(args.vector_threads)])
+        dt = time.time() - t0
+        os.chdir(cwd)
+        size = os.path.getsize(os.path.join(wd, "oth_detections_at_0dot05_threshold.gpkg"))
+    print(json.dumps({"cli_tiles": args.tiles, "seconds_total_incl_engine_build": dt, "rc": rc, "gpkg_bytes": size}))
+
+
+if __name__ == "__main__":
+    main()
