@@ -134,6 +134,30 @@ def test_roi_align_constant_and_linear_field():
     assert float(out.abs().max()) == 0.0
 
 
+def test_roi_align_detectron2_published_vector():
+    """Known-answer vector of detectron2's own test-suite (tests/layers/test_roi_align.py::test_forward_output, as
+    published with v0.6; detectron2 itself is not present here): 5x5 arange map, box (1,1,3,3), 4x4 output,
+    sampling_ratio 0, aligned=True."""
+    feat = torch.arange(25, dtype=torch.float32).view(1, 5, 5)
+    out = O.roi_align_one(feat, torch.tensor([1.0, 1.0, 3.0, 3.0]), 4, 1.0)
+    want = np.array([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]], np.float32)
+    assert np.array_equal(out[0].numpy(), want)
+
+
+def test_anchor_generator_detectron2_published_vector():
+    """detectron2 tests/modeling/test_anchor_generator.py::test_default_anchor_generator (v0.6): sizes (32, 64),
+    ratios (0.25, 1, 4), stride 4, a 1x2 feature map, offset 0 -- and ::test_default_anchor_generator_centered
+    (offset 0.5 shifts everything by +2)."""
+    want = np.array([[-32, -8, 32, 8], [-16, -16, 16, 16], [-8, -32, 8, 32], [-64, -16, 64, 16], [-32, -32, 32, 32], [-16, -64, 16, 64],
+                     [-28, -8, 36, 8], [-12, -16, 20, 16], [-4, -32, 12, 32], [-60, -16, 68, 16], [-28, -32, 36, 32], [-12, -64, 20, 64]],
+                    np.float32)
+    spec = EngineSpec(anchor_sizes=((32.0, 64.0),) * 5, anchor_aspect_ratios=(0.25, 1.0, 4.0))
+    assert spec.fpn_strides[0] == 4
+    assert np.array_equal(O.grid_anchors(spec, 0, 1, 2).numpy(), want)
+    centred = EngineSpec(anchor_sizes=((32.0, 64.0),) * 5, anchor_aspect_ratios=(0.25, 1.0, 4.0), anchor_offset=0.5)
+    assert np.array_equal(O.grid_anchors(centred, 0, 1, 2).numpy(), want + 2.0)
+
+
 def test_paste_masks_full_box():
     # a box covering the whole canvas with a constant 0.7 mask pastes to all-True; 0.3 to all-False
     m = torch.full((1, 1, 28, 28), 0.7)
