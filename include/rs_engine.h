@@ -165,6 +165,15 @@ int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const floa
                       int h2, int w2, int cin2, int in2_halo, int stride2,
                       int cout, int kpad, int out_halo, int relu, int variant, void* stream);
 
+/* Training path: weight gradient of rs_op_conv2d's convolution (conv_wgrad.hip),
+ *   grad[co][(kh,kw,ci)] = scale[co] * sum_{n,y,x} dy[n][y][x][co] * in[n][y*stride+kh-pad][x*stride+kw-pad][ci]
+ * -- what autograd computes for Conv2d.weight / Linear.weight ([EXT d2: layers/wrappers.py Conv2d]; with FrozenBN the
+ * trainable tensor is the unfolded weight, hence the optional per-channel `scale`).  dy: [n][ho+2*dy_halo][wo+2*dy_halo][cout]
+ * fp16 with a zero halo; grad: fp32 [cout][kpad] in the forward weight layout.  splits <= 0: chosen by the library. */
+int rs_op_conv2d_wgrad(const void* dy, const void* in, float* grad, const float* scale, int n, int hi, int wi, int cin,
+                       int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits,
+                       void* stream);
+
 /* Greedy NMS over `segments` independent lists of up to 1024 boxes in priority order
  * (torchvision.ops.nms semantics: IoU > thresh suppresses). keep: [segments][cap] 0/1. */
 int rs_op_nms(const float* boxes, const int32_t* counts, const uint8_t* valid, uint8_t* keep,

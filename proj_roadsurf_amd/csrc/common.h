@@ -81,6 +81,24 @@ struct ConvParams {
 int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant /* -1 auto */, int use_glds);
 extern thread_local int g_last_conv_variant;
 
+// ------------------------------------------------------------------ training: weight gradient (conv_wgrad.hip)
+struct WgradParams {
+  const half_t* dy;     // gradient of the layer output, [N][Ho+2*dy_pad][Wo+2*dy_pad][dy_Cs] fp16, zero halo
+  const half_t* x;      // layer input as the forward saw it (zero halo)
+  float* partial;       // [splits][Cout][Kpad] fp32 scratch
+  float* grad;          // [Cout][Kpad] fp32, K = (kh,kw,cin) with cin fastest (the forward weight layout)
+  const half_t* zeros;  // >= Cout zero halfs: source of the dY rows past M (so the tail contributes nothing)
+  const float* scale;   // optional [Cout]: FrozenBN scale folded into the forward weight (grad is w.r.t. the unfolded one)
+  int M, Ho, Wo;
+  int dy_Hp, dy_Wp, dy_Cs, dy_pad;
+  int in_Hp, in_Wp, in_Cs, in_off;   // as ConvParams
+  int stride, KH, KW, Cin, Cout, Kpad;
+  int splits;           // pixel-range splits (gridDim.z); wgrad_splits() proposes one
+  int accumulate;       // 1: grad += result
+};
+int wgrad_splits(const WgradParams& p);
+int launch_conv_wgrad(const WgradParams& p, hipStream_t stream);
+
 // ------------------------------------------------------------------ tile ingest / pooling
 struct PreprocParams {
   const uint8_t* tiles;   // [N][H][W][C] uint8, channel order as cv2.imread (BGR)

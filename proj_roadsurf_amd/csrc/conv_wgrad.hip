@@ -1,0 +1,226 @@
+// Weight gradient of a convolution / linear layer for gfx950 (MI355X): fp16 operands, fp32 accumulate on MFMA.
+//
+// Training path: what autograd reaches through cuDNN's backward-filter / cuBLAS for
+// every trainable Conv2d / Linear of the detectron2 model ([EXT d2: layers/wrappers.py Conv2d; modeling/backbone/
+// {resnet,fpn}.py; modeling/proposal_generator/rpn.py; modeling/roi_heads/{box_head,fast_rcnn,mask_head}.py];
+// trainable set fixed by FREEZE_AT 2, R:config/detectron2_config_3bands.yaml:58).
+//
+//   dW[co][(kh,kw,ci)] = sum over output pixels m = (n,y,x) of  dY[m][co] * X[n][y*s+kh-pad][x*s+kw-pad][ci]
+//
+// As a GEMM the reduction runs over PIXELS, and both operands are stored pixel-major (NHWC): every MFMA operand
+// is "k-strided" in memory.  The tiles are therefore staged row-major ([pixel][64 channels], 128-byte rows, LDS-DMA
+// exactly like the forward kernel's activation tile, zero halo = no bounds checks) and read back TRANSPOSED with
+// ds_read_b64_tr_b16: a 16-lane group reads a 4-pixel x 16-channel block and each lane receives the 4 pixels of
+// its channel, two reads = the 8 consecutive k of a v_mfma_f32_16x16x32_f16 operand.
+//   * swizzle: LDS slot s of row r holds source chunk s ^ key(r), key(r) = ((r>>1)&1)<<1 | ((r>>3)&1)<<2 -- the 8 rows
+//     a 32-lane half touches in one transposed read ({0..3, 8..11} or {4..7, 12..15} of a 16-row group) land on 8
+//     disjoint 8-bank spans (checked by simulation, tools/ubench/lds_tr_banks.py).
+//   * workgroup tile: 128 output channels x 128 K columns (= two (tap, 64-channel slice) pairs), 4 waves 2x2, wave
+//     tile 64x64; K step = 64 pixels, double buffered.
+//   * the pixel range is split over gridDim.z; every split writes its own fp32 partial tile and wgrad_reduce_kernel
+//     adds the partials in a fixed order (bitwise reproducible; no float atomics), applies the per-output-channel
+//     FrozenBN scale (the trainable tensor is the UNFOLDED weight) and accumulates into the gradient.
+//   * rows of dY beyond M read a zero row (WgradParams::zeros), so the tail contributes nothing.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BK = 64, NT = 256;   // 128 channels x 128 K columns per workgroup
+constexpr int SUB = BK * 128;                 // one [64 px][64 ch] sub-tile: 8 KB
+constexpr int STAGE = 4 * SUB;                // dY lo, dY hi, X half 0, X half 1
+constexpr int LDS_BYTES = 2 * STAGE;          // 64 KB
+
+__device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int row_key(int r) { return (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;      // wave tile: channels wr*64.., K columns wc*64..
+
+  const int co0 = blockIdx.x * BM;
+  // K columns of this workgroup: two 64-wide halves, each one (tap, channel slice)
+  const int slices = p.Cin >> 6;                // 64-channel slices per tap
+  int x_off[2], k_col[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int u = blockIdx.y * 2 + h;                 // (tap, slice) unit index, tap-major
+    const int units = p.KH * p.KW * slices;
+    if (u >= units) u = units - 1;              // odd unit count: the second half repeats the last unit (not stored)
+    const int tap = u / slices, sl = u - tap * slices;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    x_off[h] = (kh * p.in_Wp + kw) * p.in_Cs + sl * 64;
+    k_col[h] = tap * p.Cin + sl * 64;
+  }
+  const bool second_valid = (blockIdx.y * 2 + 1) < p.KH * p.KW * slices;
+
+  // pixel range of this split (multiples of BK)
+  const int steps_total = (p.M + BK - 1) / BK;
+  const int per = (steps_total + gridDim.z - 1) / gridDim.z;
+  const int s0 = blockIdx.z * per;
+  int s1 = s0 + per;
+  if (s1 > steps_total) s1 = steps_total;
+
+  // ---- staging: a sub-tile is 8 pieces of 8 rows; wave w stages pieces 2w, 2w+1 of each of the 4 sub-tiles
+  const int lrow = lane >> 3, lchk = lane & 7;
+  auto stage = [&](int buf, int step) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const int piece = wave * 2 + pc;
+      const int r = piece * 8 + lrow;                          // row inside the 64-pixel K step
+      const int m = step * BK + r;
+      const int src_chunk = (lchk ^ row_key(r)) * 8;
+      const half_t *gy, *gx;
+      if (m < p.M) {
+        const int x = m % p.Wo;
+        const int t = m / p.Wo;
+        const int y = t % p.Ho;
+        const int n = t / p.Ho;
+        gy = p.dy + ((long long)(n * p.dy_Hp + y + p.dy_pad) * p.dy_Wp + x + p.dy_pad) * p.dy_Cs + co0 + src_chunk;
+        gx = p.x + ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x * p.stride + p.in_off) * p.in_Cs + src_chunk;
+      } else {
+        gy = p.zeros + co0 + src_chunk;                        // zero row: the tail contributes nothing
+        gx = p.x + src_chunk;                                  // any valid address; multiplied by zero
+      }
+      char* dst = base + piece * 1024;
+      glds16(gy, dst);
+      glds16(gy + 64, dst + SUB);
+      glds16(gx + (m < p.M ? x_off[0] : 0), dst + 2 * SUB);
+      glds16(gx + (m < p.M ? x_off[1] : 0), dst + 3 * SUB);
+    }
+  };
+
+  // ---- transposed fragment reads
+  // lane l: group g = l>>4 supplies k rows 8g..8g+7 of a 32-pixel MFMA step; inside the group q = (l&15)>>2 is the
+  // row of the 4-row block, pp = l&3 the 4-element column piece.  Block columns = 16 channels = chunks 2cb, 2cb+1.
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // byte offset (inside a sub-tile) of this lane's address for channel block cb, MFMA step ks (0/1), half hh (0/1)
+  auto tr_addr = [&](int cb, int ks, int hh) {
+    const int r = ks * 32 + g * 8 + hh * 4 + q;
+    const int c = 2 * cb + (pp >> 1);
+    return (unsigned)(r * 128 + ((c ^ row_key(r)) << 4) + 8 * (pp & 1));
+  };
+  unsigned a_addr[4][2][2], b_addr[4][2][2];     // [block][ks][hh]; wave's dY sub-tile = wr, X sub-tile = 2 + wc
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        a_addr[i][ks][hh] = lds0 + wr * SUB + tr_addr(i, ks, hh);
+        b_addr[i][ks][hh] = lds0 + (2 + wc) * SUB + tr_addr(i, ks, hh);
+      }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define RS_TR(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
+  if (s0 < s1) {
+    stage(0, s0);
+    for (int s = s0; s < s1; ++s) {
+      const int buf = (s - s0) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 1 < s1) stage(buf ^ 1, s + 1);
+      const unsigned bo = (unsigned)(buf * STAGE);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half4v a_lo[4], a_hi[4], b_lo[4], b_hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          RS_TR(a_lo[i], a_addr[i][ks][0] + bo);
+          RS_TR(a_hi[i], a_addr[i][ks][1] + bo);
+          RS_TR(b_lo[i], b_addr[i][ks][0] + bo);
+          RS_TR(b_hi[i], b_addr[i][ks][1] + bo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        half8 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i] = __builtin_shufflevector(a_lo[i], a_hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+          bf[i] = __builtin_shufflevector(b_lo[i], b_hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+#undef RS_TR
+
+  // ---- store the partial tile: D[row = 4*(lane>>4) + e][col = lane&15] of block (i, j)
+  if (wc == 1 && !second_valid) return;
+  float* out = p.partial + (long long)blockIdx.z * p.Cout * p.Kpad;
+  const int kc = k_col[wc];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = co0 + wr * 64 + i * 16 + (lane >> 4) * 4 + e;
+      if (co >= p.Cout) continue;
+      float* row = out + (long long)co * p.Kpad + kc + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) row[j * 16] = acc[i][j][e];
+    }
+  }
+}
+
+// grad[co][k] (+)= scale[co] * sum_z partial[z][co][k], z in ascending order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int splits, long long n_el, int Kpad,
+                                                           const float* scale, float* grad, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_el) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += partial[(long long)z * n_el + i];
+  if (scale) s *= scale[i / Kpad];
+  grad[i] = accumulate ? grad[i] + s : s;
+}
+
+}  // namespace
+
+int wgrad_splits(const WgradParams& p) {
+  const long long out_tiles = (long long)cdiv(p.Cout, BM) * cdiv(p.KH * p.KW * (p.Cin >> 6), 2);
+  const int steps = cdiv(p.M, BK);
+  long long s = cdiv(1024, out_tiles);          // aim at ~4 workgroups per CU
+  if (s > steps / 4) s = steps / 4;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+int launch_conv_wgrad(const WgradParams& p, hipStream_t stream) {
+  RS_CHECK(p.dy && p.x && p.partial && p.grad && p.zeros, RS_ERR_ARG, "wgrad: null pointer");
+  RS_CHECK(p.M > 0 && p.Cin % 64 == 0 && p.Cout % 64 == 0 && p.dy_Cs % 8 == 0, RS_ERR_ARG, "wgrad: Cin %d / Cout %d must be multiples of 64", p.Cin, p.Cout);
+  RS_CHECK(p.KH * p.KW * p.Cin <= p.Kpad && p.splits >= 1, RS_ERR_ARG, "wgrad: K exceeds Kpad");
+  RS_CHECK(p.Cout % BM == 0, RS_ERR_UNSUPPORTED, "wgrad: Cout %d not a multiple of %d", p.Cout, BM);
+  static bool done = false;
+  if (!done) {
+    RS_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    done = true;
+  }
+  const int units = p.KH * p.KW * (p.Cin >> 6);
+  dim3 grid(p.Cout / BM, cdiv(units, 2), p.splits);
+  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(NT), LDS_BYTES, stream, p);
+  RS_HIP(hipGetLastError());
+  const long long n_el = (long long)p.Cout * p.Kpad;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n_el, 256)), dim3(256), 0, stream, p.partial, p.splits, n_el, p.Kpad,
+                     p.scale, p.grad, p.accumulate);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}

@@ -1171,6 +1171,33 @@ int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const floa
                    relu, 0, 0, variant, 1, stream, in2, h2, w2, cin2, in2_halo, stride2);
 }
 
+int rs_op_conv2d_wgrad(const void* dy, const void* x, float* grad, const float* scale, int n, int hi, int wi, int cin, int in_halo,
+                       int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits, void* stream) {
+  RS_CHECK(dy && x && grad, RS_ERR_ARG, "null argument");
+  RS_CHECK(in_halo >= pad, RS_ERR_ARG, "input halo %d < pad %d", in_halo, pad);
+  const int ho = (hi + 2 * pad - kh) / stride + 1, wo = (wi + 2 * pad - kw) / stride + 1;
+  WgradParams p;
+  memset(&p, 0, sizeof p);
+  p.dy = (const half_t*)dy; p.x = (const half_t*)x; p.grad = grad; p.scale = scale;
+  p.M = n * ho * wo; p.Ho = ho; p.Wo = wo;
+  p.dy_Hp = ho + 2 * dy_halo; p.dy_Wp = wo + 2 * dy_halo; p.dy_Cs = cout; p.dy_pad = dy_halo;
+  p.in_Hp = hi + 2 * in_halo; p.in_Wp = wi + 2 * in_halo; p.in_Cs = cin; p.in_off = in_halo - pad;
+  p.stride = stride; p.KH = kh; p.KW = kw; p.Cin = cin; p.Cout = cout; p.Kpad = kpad;
+  p.splits = splits > 0 ? splits : wgrad_splits(p);
+  hipStream_t s = (hipStream_t)stream;
+  void *partial = nullptr, *zeros = nullptr;
+  RS_HIP(hipMalloc(&partial, (size_t)p.splits * cout * kpad * 4));
+  RS_HIP(hipMalloc(&zeros, (size_t)cout * 2 + 256));
+  RS_HIP(hipMemsetAsync(zeros, 0, (size_t)cout * 2 + 256, s));
+  RS_HIP(hipMemsetAsync(partial, 0, (size_t)p.splits * cout * kpad * 4, s));   // K padding columns stay zero
+  p.partial = (float*)partial; p.zeros = (const half_t*)zeros;
+  int rc = launch_conv_wgrad(p, s);
+  hipStreamSynchronize(s);
+  hipFree(partial);
+  hipFree(zeros);
+  return rc;
+}
+
 int rs_op_nms(const float* boxes, const int32_t* counts, const uint8_t* valid, uint8_t* keep, int segments, int cap,
               float thresh, void* stream) {
   RS_CHECK(boxes && counts && keep && segments > 0, RS_ERR_ARG, "bad argument");

@@ -1,0 +1,90 @@
+"""GPU parity of the training-path operators, through the C ABI, against torch autograd
+(fp32) on the same fp16-representable operands.  rs_op_conv2d_wgrad accumulates fp16 products in fp32 on MFMA over
+up to ~1e5 pixels; tolerance: max|err| <= 2e-3 * max|ref| (+ fp32 summation-order noise)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from proj_roadsurf_amd.engine import load_library, _check
+
+pytestmark = pytest.mark.gpu
+
+
+def _halo(x_nhwc: torch.Tensor, pad: int) -> torch.Tensor:
+    n, h, w, c = x_nhwc.shape
+    out = torch.zeros((n, h + 2 * pad, w + 2 * pad, c), dtype=x_nhwc.dtype)
+    out[:, pad:pad + h, pad:pad + w] = x_nhwc
+    return out
+
+
+def _r16(t):
+    return t.half().float()
+
+
+def run_wgrad(x, dy, k, stride, pad, scale=None, splits=0, in_halo=None, dy_halo=1):
+    """x (N,Cin,H,W), dy (N,Cout,Ho,Wo) fp32 fp16-representable -> dW (Cout,Cin,k,k) fp32 from the GPU."""
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    n, cin, hi, wi = x.shape
+    cout = dy.shape[1]
+    in_halo = pad if in_halo is None else in_halo
+    xd = _halo(x.permute(0, 2, 3, 1).half().contiguous(), in_halo).to(dev)
+    dyd = _halo(dy.permute(0, 2, 3, 1).half().contiguous(), dy_halo).to(dev)
+    kpad = (k * k * cin + 63) // 64 * 64
+    gd = torch.full((cout, kpad), float("nan"), dtype=torch.float32, device=dev)
+    sd = scale.to(dev) if scale is not None else None
+    torch.cuda.synchronize()
+    rc = lib.rs_op_conv2d_wgrad(C.c_void_p(dyd.data_ptr()), C.c_void_p(xd.data_ptr()), C.c_void_p(gd.data_ptr()),
+                                C.c_void_p(sd.data_ptr()) if sd is not None else None,
+                                n, hi, wi, cin, in_halo, k, k, stride, pad, cout, kpad, dy_halo, splits, None)
+    _check(lib, rc, "rs_op_conv2d_wgrad")
+    torch.cuda.synchronize()
+    g = gd.cpu()[:, : k * k * cin].reshape(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
+    return g
+
+
+def ref_wgrad(x, dy, k, stride, pad):
+    w = torch.zeros(dy.shape[1], x.shape[1], k, k, requires_grad=True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    assert y.shape == dy.shape, (y.shape, dy.shape)
+    y.backward(dy)
+    return w.grad.detach()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw,n,splits", [
+    (256, 256, 3, 1, (25, 27), 2, 0),      # FPN output / RPN / mask-head 3x3
+    (256, 256, 3, 1, (25, 27), 2, 1),      # single split: every pixel through one workgroup column
+    (64, 128, 1, 1, (19, 23), 3, 0),       # 1x1, one K unit (second half of the workgroup tile unused)
+    (256, 128, 1, 2, (26, 30), 2, 0),      # strided 1x1 (res3.0.conv1 shape)
+    (128, 128, 3, 1, (14, 14), 5, 3),      # ragged pixel count vs the 64-pixel K step
+    (512, 256, 1, 1, (13, 13), 2, 0),      # FPN lateral
+])
+def test_conv_wgrad_matches_autograd(gpu_required, cin, cout, k, stride, hw, n, splits):
+    g = torch.Generator().manual_seed(cin + cout + k)
+    h, w = hw
+    pad = k // 2
+    x = _r16(torch.randn(n, cin, h, w, generator=g))
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = _r16(torch.randn(n, cout, ho, wo, generator=g) * 0.1)
+    ref = ref_wgrad(x, dy, k, stride, pad)
+    got = run_wgrad(x, dy, k, stride, pad, splits=splits, in_halo=max(pad, 1))
+    err = float((got - ref).abs().max())
+    assert err <= 2e-3 * max(1.0, float(ref.abs().max())), f"max err {err}, ref max {float(ref.abs().max())}"
+
+
+def test_conv_wgrad_scale_and_fc_shape(gpu_required):
+    """Linear layer as a 1x1 conv over an (M x 1) image, FrozenBN-style per-channel scale applied to the gradient."""
+    g = torch.Generator().manual_seed(3)
+    m, kin, nout = 333, 1024, 256
+    a = _r16(torch.randn(m, kin, generator=g))
+    dy = _r16(torch.randn(m, nout, generator=g) * 0.05)
+    scale = torch.rand(nout, generator=g) + 0.5
+    ref = (dy.t() @ a) * scale[:, None]
+    x4 = a.t().reshape(1, kin, m, 1)
+    dy4 = dy.t().reshape(1, nout, m, 1)
+    got = run_wgrad(x4, dy4, 1, 1, 0, scale=scale, in_halo=0, dy_halo=0)[:, :, 0, 0]
+    err = float((got - ref).abs().max())
+    assert err <= 2e-3 * max(1.0, float(ref.abs().max())), err
