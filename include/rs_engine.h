@@ -165,6 +165,17 @@ int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const floa
                       int h2, int w2, int cin2, int in2_halo, int stride2,
                       int cout, int kpad, int out_halo, int relu, int variant, void* stream);
 
+/* Training path: input gradient of rs_op_conv2d's convolution, with the backward epilogue fused:
+ *   dx = relu'(mask) * ( conv_transpose(dy, W) + res + res32 + sum2x2(down) )
+ * dy: [n][ho+2h][wo+2h][cout] fp16; w_t: the transposed, tap-flipped weight [cin][(kh-1-i, kw-1-j, co)] fp16 (kpad columns);
+ * dx/res/mask: [n][hi+2h][wi+2h][cin] fp16, res32 the same geometry in fp32, down: [n][2hi+2h][2wi+2h][cin] fp16 (all
+ * optional except dx).  stride 1, or stride s with a 1x1 kernel (STRIDE_IN_1X1, R:config/detectron2_config_3bands.yaml:111):
+ * then dx is only written at every s-th pixel and the caller provides zeros elsewhere.  What autograd reaches through
+ * cuDNN backward-data + the ReLU / add / nearest-upsample backward nodes ([EXT d2: modeling/backbone/{resnet,fpn}.py]). */
+int rs_op_conv2d_dgrad(const void* dy, const void* w_t, void* dx, const void* res, const float* res32, const void* mask,
+                       const void* down, int n, int hi, int wi, int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                       int pad, int kpad, int halo, int variant, void* stream);
+
 /* Training path: weight gradient of rs_op_conv2d's convolution (conv_wgrad.hip),
  *   grad[co][(kh,kw,ci)] = scale[co] * sum_{n,y,x} dy[n][y][x][co] * in[n][y*stride+kh-pad][x*stride+kw-pad][ci]
  * -- what autograd computes for Conv2d.weight / Linear.weight ([EXT d2: layers/wrappers.py Conv2d]; with FrozenBN the

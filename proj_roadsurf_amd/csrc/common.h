@@ -74,6 +74,15 @@ struct ConvParams {
   // `in`, Cin2/64 more K steps read pixel (y*stride2, x*stride2) of `in2` (1x1 taps).  Weight row = [K of in | Cin2].
   const half_t* in2;    // nullptr = single source
   int in2_Hp, in2_Wp, in2_Cs, in2_off, stride2, Cin2;
+  // ---- training-path epilogue options (input-gradient convolutions, conv_igemm.hip only) ----
+  const half_t* down;   // finer map (2Ho x 2Wo, out channel count) whose 2x2 sums are added: backward of the FPN top-down
+                        // nearest upsample; geometry down_Hp/down_Wp/down_Cs/down_pad
+  int down_Hp, down_Wp, down_Cs, down_pad;
+  const float* res32;   // fp32 addend with the OUTPUT's geometry (RoIAlign-backward scatter target), nullptr = none
+  const half_t* mask;   // ReLU backward: output is zeroed where mask (output geometry, the saved forward activation) <= 0;
+                        // applied after bias/res/up/down/res32, before `relu`
+  int out_stride;       // 0/1 = dense; s > 1: output pixel (y, x) is stored at (y*s, x*s) of the out/res/res32/mask maps
+                        // (input gradient of a stride-s 1x1 convolution; the other positions are the caller's zeros)
   int persist;          // >0: persistent launch with this many workgroups per CU; -1: per-variant default; 0: one per tile
   int stages;           // LDS K-step buffers: 0/2 = double buffered, 1 = single (set by launch_conv for shallow K)
 };

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       const int n = t / p.Ho;
       int oy = y, ox = x;
       if (p.mode != 0) { oy = 2 * y + (g >> 1); ox = 2 * x + (g & 1); }
+      else if (p.out_stride > 1) { oy = y * p.out_stride; ox = x * p.out_stride; }
       const long long opix = (long long)(n * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad;
       float v[4 * MI];
 #pragma unroll
@@ -325,6 +326,37 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
           const half4 h = *(const half4*)(up + i * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+        }
+      }
+      if (p.down) {      // backward of the nearest 2x upsample: add the 2x2 block of the finer gradient map
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          const long long dpix = (long long)(n * p.down_Hp + 2 * y + (dd >> 1) + p.down_pad) * p.down_Wp + 2 * x + (dd & 1) + p.down_pad;
+          const half_t* dp = p.down + dpix * p.down_Cs + cb;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const half4 h = *(const half4*)(dp + i * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+          }
+        }
+      }
+      if (p.res32) {
+        const float* rp = p.res32 + opix * p.out_Cs + cb;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const f32x4 h = *(const f32x4*)(rp + i * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] += h[r];
+        }
+      }
+      if (p.mask) {      // ReLU backward
+        const half_t* mp = p.mask + opix * p.out_Cs + cb;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const half4 h = *(const half4*)(mp + i * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] = (float)h[r] > 0.f ? v[i * 4 + r] : 0.f;
         }
       }
       if (p.relu) {
@@ -466,11 +498,13 @@ thread_local int g_last_conv_variant = -2;
 int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, int use_glds) {
   if (use_glds < 0) {                   // fp32 validation mode (ref_f32.hip)
     RS_CHECK(!p_in.in2, RS_ERR_UNSUPPORTED, "conv: the fp32 validation kernel has no second K source");
+    RS_CHECK(!(p_in.down || p_in.res32 || p_in.mask || p_in.out_stride > 1), RS_ERR_UNSUPPORTED, "conv: the fp32 validation kernel has no training epilogue options");
     g_last_conv_variant = -1;
     return launch_conv_f32(p_in, stream);
   }
   ConvParams p = p_in;
   const int nk2 = p.in2 ? (p.Cin2 >> 6) : 0;   // K steps of the second source
+  const bool train_opts = p.down || p.res32 || p.mask || p.out_stride > 1;   // only conv_igemm_kernel implements these
   {
     // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second
     // LDS buffer; a single buffer halves the LDS footprint so 4 workgroups fit per CU and their
@@ -514,6 +548,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     g_last_conv_variant = 11;
     return launch_conv_stag(p, stream);
   }
+  RS_CHECK(!(train_opts && (v == 6 || v == 11 || v == 12 || p.mode != 0)), RS_ERR_UNSUPPORTED, "conv: training epilogue options need a conv_igemm variant, mode 0");
   if (v == 12) {                        // 256x256 with 3 activation stages / 2 weight stages (conv_deep.hip)
     RS_CHECK(!p.in2, RS_ERR_UNSUPPORTED, "conv: variant 12 has no second K source");
     g_last_conv_variant = 12;
@@ -534,10 +569,10 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     else if (rows % 256 == 0 && nk >= 8 && tiles4 >= 240) {                 // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
       static int stag = -1;
       if (stag < 0) { const char* e = getenv("RS_CONV_STAGGER"); stag = e ? atoi(e) : 0; }
-      if (stag && use_glds > 0 && !p.in2) { g_last_conv_variant = 11; return launch_conv_stag(p, stream); }
+      if (stag && use_glds > 0 && !p.in2 && !train_opts) { g_last_conv_variant = 11; return launch_conv_stag(p, stream); }
       static int deep = -1;
       if (deep < 0) { const char* e = getenv("RS_CONV_DEEP"); deep = e ? atoi(e) : 1; }
-      if (deep && use_glds > 0 && !p.in2) { g_last_conv_variant = 12; return launch_conv_deep(p, stream); }
+      if (deep && use_glds > 0 && !p.in2 && !train_opts) { g_last_conv_variant = 12; return launch_conv_deep(p, stream); }
       v = 4;
     }
     else if (rows % 256 == 0 && nk <= 4 && p.M >= 100000) v = 10;           // HBM-bound 1x1 expansions on big maps: 64x256, rows read once

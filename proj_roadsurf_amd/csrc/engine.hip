@@ -1171,6 +1171,36 @@ int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const floa
                    relu, 0, 0, variant, 1, stream, in2, h2, w2, cin2, in2_halo, stride2);
 }
 
+int rs_op_conv2d_dgrad(const void* dy, const void* w_t, void* dx, const void* res, const float* res32, const void* mask,
+                       const void* down, int n, int hi, int wi, int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                       int pad, int kpad, int halo, int variant, void* stream) {
+  RS_CHECK(dy && w_t && dx, RS_ERR_ARG, "null argument");
+  RS_CHECK(stride == 1 || (kh == 1 && kw == 1), RS_ERR_UNSUPPORTED, "dgrad: stride %d needs a 1x1 kernel (STRIDE_IN_1X1)", stride);
+  RS_CHECK(halo >= kh - 1 - pad && halo >= 0 && kh == kw, RS_ERR_ARG, "dgrad: halo %d too small", halo);
+  // the input gradient of conv(x, W, stride 1, pad) is conv(dy, W^T flipped, stride 1, pad' = k-1-pad); of a stride-s 1x1
+  // convolution it is the 1x1 convolution of dy stored at every s-th pixel of dx
+  ConvParams p;
+  memset(&p, 0, sizeof p);
+  const int pad_t = kh - 1 - pad;
+  const int oh = stride == 1 ? ho + 2 * pad_t - kh + 1 : ho, ow = stride == 1 ? wo + 2 * pad_t - kw + 1 : wo;
+  RS_CHECK(stride == 1 ? (oh == hi && ow == wi) : ((ho - 1) * stride < hi && (wo - 1) * stride < wi), RS_ERR_ARG, "dgrad: geometry");
+  void* zero_bias = nullptr;
+  RS_HIP(hipMalloc(&zero_bias, (size_t)cin * 4 + 256));
+  RS_HIP(hipMemsetAsync(zero_bias, 0, (size_t)cin * 4 + 256, (hipStream_t)stream));
+  p.in = (const half_t*)dy; p.w = (const half_t*)w_t; p.bias = (const float*)zero_bias; p.out = dx;
+  p.res = (const half_t*)res; p.res32 = res32; p.mask = (const half_t*)mask; p.down = (const half_t*)down;
+  p.M = n * oh * ow; p.Ho = oh; p.Wo = ow;
+  p.in_Hp = ho + 2 * halo; p.in_Wp = wo + 2 * halo; p.in_Cs = cout; p.in_off = halo - pad_t;
+  p.stride = 1; p.KH = kh; p.KW = kw; p.Cin = cout; p.Kpad = kpad; p.Cout = cin;
+  p.out_Hp = hi + 2 * halo; p.out_Wp = wi + 2 * halo; p.out_Cs = cin; p.out_pad = halo;
+  p.out_stride = stride;
+  if (down) { p.down_Hp = 2 * hi + 2 * halo; p.down_Wp = 2 * wi + 2 * halo; p.down_Cs = cin; p.down_pad = halo; }
+  int rc = launch_conv(p, (hipStream_t)stream, variant, 1);
+  hipStreamSynchronize((hipStream_t)stream);
+  hipFree(zero_bias);
+  return rc;
+}
+
 int rs_op_conv2d_wgrad(const void* dy, const void* x, float* grad, const float* scale, int n, int hi, int wi, int cin, int in_halo,
                        int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits, void* stream) {
   RS_CHECK(dy && x && grad, RS_ERR_ARG, "null argument");

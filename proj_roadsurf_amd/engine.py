@@ -85,6 +85,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_net_shape.argtypes = [vp, i32p, i32p, i32p, i32p]
     lib.rs_op_conv2d.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 17 + [vp]
     lib.rs_op_conv2d_dual.argtypes = [vp, vp, vp, vp, vp] + [i32] * 19 + [vp]
+    lib.rs_op_conv2d_dgrad.argtypes = [vp] * 7 + [i32] * 14 + [vp]
     lib.rs_op_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i32] * 13 + [vp]
     lib.rs_op_nms.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp]
     lib.rs_op_roi_align.argtypes = [C.POINTER(vp), i32p, i32p, f32p, i32, vp, i32, i32, i32, i32, vp, vp, vp]

@@ -88,3 +88,92 @@ def test_conv_wgrad_scale_and_fc_shape(gpu_required):
     got = run_wgrad(x4, dy4, 1, 1, 0, scale=scale, in_halo=0, dy_halo=0)[:, :, 0, 0]
     err = float((got - ref).abs().max())
     assert err <= 2e-3 * max(1.0, float(ref.abs().max())), err
+
+
+def _wt_flipped(w):
+    """(Cout,Cin,k,k) -> transposed, tap-flipped GEMM weight [Cin][(k-1-i, k-1-j, co)] fp16, K padded to 64."""
+    cout, cin, k, _ = w.shape
+    t = w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, k * k * cout)      # [ci][(i', j', co)]
+    kpad = (t.shape[1] + 63) // 64 * 64
+    out = torch.zeros(cin, kpad)
+    out[:, : t.shape[1]] = t
+    return out.half().contiguous(), kpad
+
+
+def run_dgrad(dy, w, hi, wi, stride, pad, res=None, res32=None, mask=None, down=None, variant=-1):
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    n, cout, ho, wo = dy.shape
+    cin, k = w.shape[1], w.shape[2]
+    halo = 1
+    dyd = _halo(dy.permute(0, 2, 3, 1).half().contiguous(), halo).to(dev)
+    wt, kpad = _wt_flipped(w)
+    wtd = wt.to(dev)
+    dxd = torch.zeros((n, hi + 2, wi + 2, cin), dtype=torch.float16, device=dev)
+
+    def nhwc(t, dt):
+        return _halo(t.permute(0, 2, 3, 1).to(dt).contiguous(), halo).to(dev) if t is not None else None
+    rd, r32d, md, dd = nhwc(res, torch.float16), nhwc(res32, torch.float32), nhwc(mask, torch.float16), nhwc(down, torch.float16)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    torch.cuda.synchronize()
+    rc = lib.rs_op_conv2d_dgrad(ptr(dyd), ptr(wtd), ptr(dxd), ptr(rd), ptr(r32d), ptr(md), ptr(dd), n, hi, wi, cin, ho, wo, cout,
+                                k, k, stride, pad, kpad, halo, variant, None)
+    _check(lib, rc, "rs_op_conv2d_dgrad")
+    torch.cuda.synchronize()
+    o = dxd.cpu().float()
+    inner = o[:, 1:-1, 1:-1]
+    assert float(o.abs().sum()) == pytest.approx(float(inner.abs().sum()), rel=1e-6), "kernel wrote into the halo"
+    return inner.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw,variant", [
+    (256, 256, 3, 1, (25, 27), -1),     # 3x3 (FPN output, RPN conv, mask fcn, bottleneck conv2)
+    (256, 256, 3, 1, (25, 27), 4),      # 256x256 tile of conv_igemm (conv_deep has no training epilogue)
+    (512, 128, 1, 1, (26, 30), -1),     # bottleneck conv1
+    (128, 512, 1, 1, (26, 30), -1),     # bottleneck conv3
+    (512, 256, 1, 2, (26, 30), -1),     # stride-2 1x1 (res4.0.conv1 / shortcut): scattered store
+])
+def test_conv_dgrad_with_fused_backward_epilogue(gpu_required, cin, cout, k, stride, hw, variant):
+    """dx = relu'(y_prev) * (conv_transpose(dy) + identity-path gradient + fp32 RoIAlign scatter), vs autograd of
+    relu(x) -> conv (+ the two extra consumers of x)."""
+    g = torch.Generator().manual_seed(cin * 3 + cout + k + stride)
+    hi, wi = hw
+    n = 2
+    pad = k // 2
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    w = _r16(torch.randn(cout, cin, k, k, generator=g) * 0.05)
+    dy = _r16(torch.randn(n, cout, ho, wo, generator=g))
+    pre = torch.randn(n, cin, hi, wi, generator=g)                     # pre-activation of the previous layer
+    y_prev = _r16(F.relu(pre))                                         # its saved (post-ReLU) output = the mask
+    res = _r16(torch.randn(n, cin, hi, wi, generator=g))               # gradient arriving over the identity shortcut
+    res32 = torch.randn(n, cin, hi, wi, generator=g)                   # fp32 scatter target (RoIAlign backward)
+    if stride > 1:                                                      # strided store: the caller owns the other positions
+        keep = torch.zeros(1, 1, hi, wi)
+        keep[:, :, ::stride, ::stride] = 1
+        res, res32 = res * keep, res32 * keep
+    # autograd reference: x = relu(pre); L = <conv(x), dy> + <x, res> + <x, res32>
+    pre_r = pre.clone().requires_grad_(True)
+    x = F.relu(pre_r)
+    L = (F.conv2d(x, w, stride=stride, padding=pad) * dy).sum() + (x * res).sum() + (x * res32).sum()
+    L.backward()
+    ref = pre_r.grad * (y_prev > 0)          # fp16 rounding can flush a tiny positive activation to 0: use the stored mask
+    got = run_dgrad(dy, w, hi, wi, stride, pad, res=res, res32=res32, mask=y_prev, variant=variant)
+    if stride > 1:
+        assert float((got * (1 - keep)).abs().max()) == 0.0
+    err = float((got - ref).abs().max())
+    assert err <= 3e-3 * max(1.0, float(ref.abs().max())), f"max err {err}, ref max {float(ref.abs().max())}"
+
+
+def test_conv_dgrad_fpn_topdown_backward(gpu_required):
+    """d(inner_l) = conv_transpose3x3(dP_l) + 2x2-sum of d(inner_{l-1}): backward of `lateral + nearest-upsample(top)`."""
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w = 2, 256, 13, 15
+    wt = _r16(torch.randn(c, c, 3, 3, generator=g) * 0.03)
+    dP = _r16(torch.randn(n, c, h, w, generator=g))
+    d_finer = _r16(torch.randn(n, c, 2 * h, 2 * w, generator=g))
+    inner = torch.randn(n, c, h, w, generator=g).requires_grad_(True)
+    L = (F.conv2d(inner, wt, padding=1) * dP).sum() + (F.interpolate(inner, scale_factor=2.0, mode="nearest") * d_finer).sum()
+    L.backward()
+    got = run_dgrad(dP, wt, h, w, 1, 1, down=d_finer)
+    err = float((got - inner.grad).abs().max())
+    assert err <= 3e-3 * max(1.0, float(inner.grad.abs().max())), err
