@@ -197,6 +197,13 @@ int rs_op_roi_align(const void* const feats[4], const int32_t heights[4], const 
                     const float scales[4], int nlevels, const float* rois, int n_rois, int rois_per_image,
                     int P, int out_halo, void* out, int32_t* levels_out, void* stream);
 
+/* Training path: adjoint of rs_op_roi_align.  dout: gradient of the pooled output, same layout as `out` above;
+ * dfeats[l]: fp32 gradient maps with the geometry of feats[l] ([N][H_l+2][W_l+2][256]), accumulated into with float atomics
+ * (torchvision's roi_align_backward_kernel does the same: [EXT tv: csrc/ops/cuda/roi_align_kernel.cu]). */
+int rs_op_roi_align_bwd(float* const dfeats[4], const int32_t heights[4], const int32_t widths[4], const float scales[4],
+                        int nlevels, const float* rois, int n_rois, int rois_per_image, int P, int out_halo, const void* dout,
+                        void* stream);
+
 /* -------- host-only helpers (no GPU needed) -------- */
 /* detectron2 ResizeShortestEdge.get_output_shape. */
 void rs_resize_shape(int h, int w, int short_edge, int max_size, int* new_h, int* new_w);

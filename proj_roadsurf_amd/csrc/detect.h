@@ -60,6 +60,9 @@ struct RoiAlignParams {
   int P, out_pad;
   int* out_level;           // optional [entry]
   int f32;                  // fp32 validation mode: features and output are float
+  // backward (roi_align_bwd_kernel): `out` holds the incoming gradient [entry][P+2*out_pad]^2[256] fp16 and the
+  // gradient of the feature maps is accumulated (float atomics) into dfeat[level], fp32, same geometry as feat[level]
+  float* dfeat[4];
 };
 
 struct BoxCandParams {
@@ -117,6 +120,7 @@ int launch_rpn_select(const RpnParams& p, hipStream_t s);
 int launch_nms(const NmsParams& p, int segments, hipStream_t s);
 int launch_rpn_merge(const RpnMergeParams& p, int N, hipStream_t s);
 int launch_roi_align(const RoiAlignParams& p, hipStream_t s);
+int launch_roi_align_bwd(const RoiAlignParams& p, hipStream_t s);
 int launch_box_candidates(const BoxCandParams& p, int N, hipStream_t s);
 int launch_det_merge(const DetMergeParams& p, int N, hipStream_t s);
 int launch_det_compact(const int* det_count, int N, int D, int* slot_list, int* total, hipStream_t s);

@@ -723,6 +723,130 @@ __global__ __launch_bounds__(256) void roi_align_win_kernel(const RoiAlignParams
 }
 
 // ---------------------------------------------------------------------------------------------
+// ROIAlign backward (training path): the adjoint of roi_align_win_kernel.  For every bin the
+// incoming gradient g[ph][pw][c]/count is spread over the bin's cell window with the same separable weights,
+//   dF[y][x][c] += wy[ph][y] * wx[pw][x] * g[ph][pw][c] / count,
+// with float atomics into the fp32 gradient maps (as torchvision's roi_align_backward_kernel does with atomicAdd:
+// [EXT tv: csrc/ops/cuda/roi_align_kernel.cu]; summation order, hence the last bits, vary from run to run there too).
+// Same level assignment, tables, half-wave-per-bin / 8-channels-per-lane layout as the forward kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams p) {
+  __shared__ float s_w[2][RS_ROI_PMAX][RS_ROI_WMAX];
+  __shared__ int s_base[2][RS_ROI_PMAX], s_len[2][RS_ROI_PMAX];
+  const int entry = blockIdx.x;
+  const int tid = threadIdx.x;
+  int n_entries = p.S;
+  if (p.n_entries) { const int c = *p.n_entries; n_entries = c < n_entries ? c : n_entries; }
+  if (entry >= n_entries) return;
+  const int slot = p.slot_list ? p.slot_list[entry] : entry;
+  const int n = slot / p.slots_per_image;
+  const int P = p.P, PP = P + 2 * p.out_pad;
+  const half_t* gout = p.out + (long long)entry * PP * PP * 256;
+  const int hw = tid >> 5, l32 = tid & 31;
+  if (p.per_image_count && (slot - n * p.slots_per_image) >= p.per_image_count[n]) return;
+  const float* r = p.rois + (long long)slot * 4;
+  const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+  const float area = (x2 - x1) * (y2 - y1);
+  const float v = sqrtf(area) / 224.0f + 1e-8f;
+  int lvl = v >= 2.0f ? 3 : (v >= 1.0f ? 2 : (v >= 0.5f ? 1 : 0));
+  if (lvl > p.nlevels - 1) lvl = p.nlevels - 1;
+  const int H = p.H[lvl], W = p.W[lvl];
+  const float sc = p.scale[lvl];
+  float* dfeat = p.dfeat[lvl] + ((long long)n * (H + 2) * (W + 2) + (W + 2) + 1) * 256 + l32 * 8;   // cell (0,0)
+  const float roi_start_w = x1 * sc - 0.5f;
+  const float roi_start_h = y1 * sc - 0.5f;
+  const float roi_w = (x2 * sc - 0.5f) - roi_start_w;
+  const float roi_h = (y2 * sc - 0.5f) - roi_start_h;
+  const float bin_h = roi_h / (float)P;
+  const float bin_w = roi_w / (float)P;
+  int gh = (int)ceilf(roi_h / (float)P);
+  int gw = (int)ceilf(roi_w / (float)P);
+  if (gh < 0) gh = 0;
+  if (gw < 0) gw = 0;
+  const float count = (float)((gh * gw) > 1 ? (gh * gw) : 1);
+  if ((tid < P) || (tid >= 32 && tid < 32 + P)) {
+    const int ax = tid >= 32 ? 1 : 0;
+    const int b = ax ? tid - 32 : tid;
+    const int g = ax ? gw : gh;
+    const int size = ax ? W : H;
+    const float start = ax ? roi_start_w : roi_start_h;
+    const float bin = ax ? bin_w : bin_h;
+    float* w = s_w[ax][b];
+    for (int j = 0; j < RS_ROI_WMAX; ++j) w[j] = 0.f;
+    int base = 0, len = 0;
+    bool have = false, overflow = false;
+    for (int i = 0; i < g; ++i) {
+      float c = start + (float)b * bin + ((float)i + 0.5f) * bin / (float)g;
+      if (c < -1.0f || c > (float)size) continue;
+      if (c <= 0.f) c = 0.f;
+      int lo = (int)c, hi;
+      if (lo >= size - 1) { hi = lo = size - 1; c = (float)lo; } else { hi = lo + 1; }
+      const float l = c - (float)lo, h = 1.f - l;
+      if (!have) { base = lo; have = true; }
+      if (hi - base >= RS_ROI_WMAX) { overflow = true; break; }
+      w[lo - base] += h;
+      w[hi - base] += l;
+      len = hi - base + 1;
+    }
+    s_base[ax][b] = base;
+    s_len[ax][b] = overflow ? -1 : len;
+  }
+  __syncthreads();
+  for (int b0 = 0; b0 < P * P; b0 += 8) {
+    const int b = b0 + hw;
+    if (b >= P * P) break;
+    const int ph = b / P, pw = b - ph * P;
+    const half8 gv = *(const half8*)(gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8);
+    float gsc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) gsc[c] = (float)gv[c] / count;
+    const int ny = s_len[0][ph], nx = s_len[1][pw];
+    if (ny >= 0 && nx >= 0) {
+      float* f0 = dfeat + ((long long)s_base[0][ph] * (W + 2) + s_base[1][pw]) * 256;
+      for (int j = 0; j < ny; ++j) {
+        const float wj = s_w[0][ph][j];
+        if (wj == 0.f) continue;
+        for (int i = 0; i < nx; ++i) {
+          const float wgt = wj * s_w[1][pw][i];
+          if (wgt == 0.f) continue;
+          float* d = f0 + ((long long)j * (W + 2) + i) * 256;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) atomicAdd(d + c, wgt * gsc[c]);
+        }
+      }
+    } else {
+      for (int iy = 0; iy < gh; ++iy) {
+        float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+        if (y < -1.0f || y > (float)H) continue;
+        if (y <= 0.f) y = 0.f;
+        int ylo = (int)y, yhi;
+        if (ylo >= H - 1) { yhi = ylo = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
+        const float ly = y - (float)ylo, hy = 1.f - ly;
+        for (int ix = 0; ix < gw; ++ix) {
+          float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+          if (x < -1.0f || x > (float)W) continue;
+          if (x <= 0.f) x = 0.f;
+          int xlo = (int)x, xhi;
+          if (xlo >= W - 1) { xhi = xlo = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
+          const float lx = x - (float)xlo, hx = 1.f - lx;
+          float* d1 = dfeat + ((long long)ylo * (W + 2) + xlo) * 256;
+          float* d2 = dfeat + ((long long)ylo * (W + 2) + xhi) * 256;
+          float* d3 = dfeat + ((long long)yhi * (W + 2) + xlo) * 256;
+          float* d4 = dfeat + ((long long)yhi * (W + 2) + xhi) * 256;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            atomicAdd(d1 + c, hy * hx * gsc[c]);
+            atomicAdd(d2 + c, hy * lx * gsc[c]);
+            atomicAdd(d3 + c, ly * hx * gsc[c]);
+            atomicAdd(d4 + c, ly * lx * gsc[c]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Box head: softmax + per-class decode + threshold + per-(image,class) sort
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void box_candidates_kernel(const BoxCandParams p) {
@@ -1010,6 +1134,15 @@ int launch_roi_align(const RoiAlignParams& p, hipStream_t s) {
   static const int use_win = [] { const char* g = getenv("RS_ROI_WINDOW"); return g ? atoi(g) : 1; }();
   if (!p.f32 && use_win && p.P <= RS_ROI_PMAX) hipLaunchKernelGGL(roi_align_win_kernel, dim3(p.S), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(roi_align_kernel, dim3(p.S), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_roi_align_bwd(const RoiAlignParams& p, hipStream_t s) {
+  RS_CHECK(p.C == 256 && !p.f32 && p.P <= RS_ROI_PMAX, RS_ERR_UNSUPPORTED, "roi_align backward: C must be 256, fp16, P <= %d", RS_ROI_PMAX);
+  RS_CHECK(p.S > 0, RS_ERR_ARG, "roi_align backward: S");
+  for (int l = 0; l < p.nlevels; ++l) RS_CHECK(p.dfeat[l] != nullptr, RS_ERR_ARG, "roi_align backward: null gradient map");
+  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(p.S), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

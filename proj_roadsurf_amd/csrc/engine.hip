@@ -1249,4 +1249,16 @@ int rs_op_roi_align(const void* const feats[4], const int32_t heights[4], const 
   return launch_roi_align(p, (hipStream_t)stream);
 }
 
+int rs_op_roi_align_bwd(float* const dfeats[4], const int32_t heights[4], const int32_t widths[4], const float scales[4],
+                        int nlevels, const float* rois, int n_rois, int rois_per_image, int P, int out_halo, const void* dout,
+                        void* stream) {
+  RS_CHECK(dfeats && rois && dout && nlevels >= 1 && nlevels <= 4 && n_rois > 0 && rois_per_image > 0, RS_ERR_ARG, "bad argument");
+  RoiAlignParams p;
+  memset(&p, 0, sizeof p);
+  for (int l = 0; l < nlevels; ++l) { p.dfeat[l] = dfeats[l]; p.H[l] = heights[l]; p.W[l] = widths[l]; p.scale[l] = scales[l]; }
+  p.nlevels = nlevels; p.C = 256; p.rois = rois; p.S = n_rois; p.slots_per_image = rois_per_image;
+  p.out = (half_t*)dout; p.P = P; p.out_pad = out_halo;
+  return launch_roi_align_bwd(p, (hipStream_t)stream);
+}
+
 }  // extern "C"

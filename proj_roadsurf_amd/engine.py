@@ -89,6 +89,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_op_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i32] * 13 + [vp]
     lib.rs_op_nms.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp]
     lib.rs_op_roi_align.argtypes = [C.POINTER(vp), i32p, i32p, f32p, i32, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.rs_op_roi_align_bwd.argtypes = [C.POINTER(vp), i32p, i32p, f32p, i32, vp, i32, i32, i32, i32, vp, vp]
     lib.rs_resize_shape.argtypes = [i32, i32, i32, i32, i32p, i32p]
     lib.rs_resize_shape.restype = None
     lib.rs_resize_coeffs.argtypes = [i32, i32, i32p, i32p]

@@ -177,3 +177,73 @@ def test_conv_dgrad_fpn_topdown_backward(gpu_required):
     got = run_dgrad(dP, wt, h, w, 1, 1, down=d_finer)
     err = float((got - inner.grad).abs().max())
     assert err <= 3e-3 * max(1.0, float(inner.grad.abs().max())), err
+
+
+@pytest.mark.parametrize("P", [7, 14])
+def test_roi_align_backward_is_the_adjoint_of_forward(gpu_required, P):
+    """RoIAlign is linear in the feature maps, so its backward is pinned by <roi_align(F), G> == <F, roi_align_bwd(G)>
+    for random F, G (forward kernel: parity-tested against the oracle in test_gpu_engine.py).  Boxes cover all four
+    FPN levels, image borders (clamped / skipped samples) and an elongated one (per-sample fallback path)."""
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(P)
+    n_img, rpi = 2, 12
+    sizes = [(48, 56), (24, 28), (12, 14), (6, 7)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    feats = [(torch.randn(n_img, h, w, 256, generator=g)).half() for h, w in sizes]
+    fd = [_halo(f, 1).to(dev) for f in feats]
+    W_img, H_img = 224.0, 192.0
+    cx = torch.rand(n_img * rpi, generator=g) * W_img
+    cy = torch.rand(n_img * rpi, generator=g) * H_img
+    side = torch.tensor([20.0, 60.0, 130.0, 250.0, 500.0, 33.0] * (n_img * rpi // 6))
+    bw, bh = side.clone(), side.clone()
+    bw[3], bh[3] = 900.0, 6.0                 # elongated: window larger than the LDS table
+    rois = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1).clamp(-20, 260).float().contiguous()
+    rd = rois.to(dev)
+    out = torch.zeros(n_img * rpi, P, P, 256, dtype=torch.float16, device=dev)
+    G = (torch.randn(n_img * rpi, P, P, 256, generator=g) * 0.5).half()
+    Gd = G.to(dev)
+    dfd = [torch.zeros(n_img, h + 2, w + 2, 256, dtype=torch.float32, device=dev) for h, w in sizes]
+    vp4 = C.c_void_p * 4
+    hs = (C.c_int32 * 4)(*[h for h, _ in sizes])
+    ws = (C.c_int32 * 4)(*[w for _, w in sizes])
+    sc = (C.c_float * 4)(*scales)
+    torch.cuda.synchronize()
+    _check(lib, lib.rs_op_roi_align(vp4(*[f.data_ptr() for f in fd]), hs, ws, sc, 4, C.c_void_p(rd.data_ptr()), n_img * rpi, rpi, P, 0,
+                                    C.c_void_p(out.data_ptr()), None, None), "rs_op_roi_align")
+    _check(lib, lib.rs_op_roi_align_bwd(vp4(*[f.data_ptr() for f in dfd]), hs, ws, sc, 4, C.c_void_p(rd.data_ptr()), n_img * rpi, rpi, P, 0,
+                                        C.c_void_p(Gd.data_ptr()), None), "rs_op_roi_align_bwd")
+    torch.cuda.synchronize()
+    lhs = float((out.double().cpu() * G.double()).sum())
+    rhs = 0.0
+    for f, d in zip(feats, dfd):
+        dd = d.cpu().double()
+        assert float(dd.abs().sum()) == pytest.approx(float(dd[:, 1:-1, 1:-1].abs().sum()), rel=1e-9), "gradient written into the halo"
+        rhs += float((f.double() * dd[:, 1:-1, 1:-1]).sum())
+    scale = float((out.double().cpu().abs() * G.double().abs()).sum())
+    # forward output is rounded to fp16 (rel 5e-4 per element): the two inner products agree to that
+    assert abs(lhs - rhs) <= 1e-3 * scale, (lhs, rhs, scale)
+    assert sum(float(d.abs().sum()) for d in dfd) > 0
+
+
+def test_deconv2x2_backward_through_conv_ops(gpu_required):
+    """ConvTranspose2d(k=2, s=2) of the mask head: its input gradient is a 2x2 stride-2 convolution of dY (forward
+    kernel, rs_op_conv2d) and its weight gradient is rs_op_conv2d_wgrad with the operands swapped (X as the 'output
+    gradient', dY as the strided 'input').  Both against autograd of F.conv_transpose2d."""
+    from tests.test_gpu_conv import run_conv
+    g = torch.Generator().manual_seed(21)
+    n, cin, cout, h, w = 5, 256, 256, 14, 14
+    wt = _r16(torch.randn(cin, cout, 2, 2, generator=g) * 0.05)            # ConvTranspose2d weight (Cin, Cout, 2, 2)
+    x = _r16(torch.randn(n, cin, h, w, generator=g))
+    dy = _r16(torch.randn(n, cout, 2 * h, 2 * w, generator=g) * 0.2)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    (F.conv_transpose2d(xr, wr, stride=2) * dy).sum().backward()
+    # dgrad: conv2d(dy, W as (out=Cin, in=Cout, 2, 2), stride 2)
+    got_dx = run_conv(dy, wt, torch.zeros(cin), stride=2, pad=0, in_halo=1, out_halo=1)
+    err = float((got_dx - xr.grad).abs().max())
+    assert err <= 3e-3 * max(1.0, float(xr.grad.abs().max())), err
+    # wgrad: dW[ci][co][dy][dx] = sum X[ci](y,x) * dY[co](2y+dy, 2x+dx)
+    got_dw = run_wgrad(dy, x, 2, 2, 0, in_halo=1, dy_halo=1)              # (cout'=Cin, cin'=Cout, 2, 2)
+    err = float((got_dw - wr.grad).abs().max())
+    assert err <= 3e-3 * max(1.0, float(wr.grad.abs().max())), err
