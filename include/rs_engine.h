@@ -204,6 +204,33 @@ int rs_op_roi_align_bwd(float* const dfeats[4], const int32_t heights[4], const 
                         int nlevels, const float* rois, int n_rois, int rois_per_image, int P, int out_halo, const void* dout,
                         void* stream);
 
+/* Training path, losses: each writes the gradient of the total loss w.r.t. its inputs (fp16, times loss_scale) and adds the
+ * loss values to loss_out (fp32, for logging).  Label assignment / sampling happen before (oracle/train_oracle.py restates
+ * them; their kernels are the next step).
+ *  rs_op_rpn_loss : RPN.losses for ONE feature level.  head/dhead: [n][hw][cs] ([0,A) logits, [A,5A) deltas); labels:
+ *                   [n][total_anchors] in {1,0,-1} after subsampling; anchors [total_anchors][4]; matched_gt
+ *                   [n][total_anchors][4]; this level's anchors start at level_off.  loss_out[0] += loss_rpn_cls,
+ *                   loss_out[1] += loss_rpn_loc, both / normalizer (= RPN.BATCH_SIZE_PER_IMAGE * n, R:223).
+ *  rs_op_box_loss : FastRCNNOutputLayers.losses.  pred/dpred [n_rois][cs] ([0,K] logits, K = background, then 4K deltas);
+ *                   gt_classes in {0..K, -1 = empty slot}; n_valid = number of sampled RoIs.  loss_out[0] += loss_cls,
+ *                   loss_out[1] += loss_box_reg.
+ *  rs_op_mask_loss: mask_rcnn_loss.  logits/dlogits [n_masks][side*side][cs], targets [n_masks][side*side] 0/1.
+ *  rs_op_sgd_momentum: one torch.optim.SGD step on a flat fp32 tensor (grad is divided by the loss scale first).
+ *  rs_op_fold_weights: fp32 master weight [cout][kpad] -> fp16 forward weight (same layout, optional per-channel scale
+ *                   folded) and its transposed, tap-flipped copy [cin][kpad_t] for rs_op_conv2d_dgrad (w_bwd may be NULL). */
+int rs_op_rpn_loss(const float* head, void* dhead, const int32_t* labels, const float* anchors, const float* matched_gt,
+                   float* loss_out, int n, int hw, int num_anchors, int cs, int level_off, int total_anchors, float normalizer,
+                   float loss_scale, void* stream);
+int rs_op_box_loss(const float* pred, void* dpred, const int32_t* gt_classes, const float* proposals, const float* gt_boxes,
+                   float* loss_out, int n_rois, int num_classes, int cs, float n_valid, const float reg_weights[4], float loss_scale,
+                   void* stream);
+int rs_op_mask_loss(const float* logits, void* dlogits, const uint8_t* targets, const int32_t* gt_classes, float* loss_out, int n_masks,
+                    int side, int cs, float loss_scale, void* stream);
+int rs_op_sgd_momentum(float* w, float* momentum_buf, const float* grad, int64_t n, float lr, float momentum, float weight_decay,
+                       float inv_loss_scale, int first_step, void* stream);
+int rs_op_fold_weights(const float* w32, const float* scale, void* w_fwd, void* w_bwd, int cout, int cin, int kh, int kw, int kpad,
+                       int kpad_t, void* stream);
+
 /* -------- host-only helpers (no GPU needed) -------- */
 /* detectron2 ResizeShortestEdge.get_output_shape. */
 void rs_resize_shape(int h, int w, int short_edge, int max_size, int* new_h, int* new_w);

@@ -14,6 +14,7 @@
 
 #include "../../include/rs_engine.h"
 #include "detect.h"
+#include "train.h"
 
 // ------------------------------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
@@ -1259,6 +1260,48 @@ int rs_op_roi_align_bwd(float* const dfeats[4], const int32_t heights[4], const 
   p.nlevels = nlevels; p.C = 256; p.rois = rois; p.S = n_rois; p.slots_per_image = rois_per_image;
   p.out = (half_t*)dout; p.P = P; p.out_pad = out_halo;
   return launch_roi_align_bwd(p, (hipStream_t)stream);
+}
+
+int rs_op_rpn_loss(const float* head, void* dhead, const int32_t* labels, const float* anchors, const float* matched_gt,
+                   float* loss_out, int n, int hw, int num_anchors, int cs, int level_off, int total_anchors, float normalizer,
+                   float loss_scale, void* stream) {
+  RpnLossParams p;
+  memset(&p, 0, sizeof p);
+  p.head = head; p.dhead = (half_t*)dhead; p.labels = labels; p.anchors = anchors; p.matched_gt = matched_gt; p.loss_out = loss_out;
+  p.A = num_anchors; p.cs = cs; p.HW = hw; p.n_anchors = hw * num_anchors; p.level_off = level_off; p.total_anchors = total_anchors;
+  p.normalizer = normalizer; p.loss_scale = loss_scale;
+  return launch_rpn_loss(p, n, (hipStream_t)stream);
+}
+
+int rs_op_box_loss(const float* pred, void* dpred, const int32_t* gt_classes, const float* proposals, const float* gt_boxes,
+                   float* loss_out, int n_rois, int num_classes, int cs, float n_valid, const float reg_weights[4], float loss_scale,
+                   void* stream) {
+  RS_CHECK(reg_weights, RS_ERR_ARG, "null argument");
+  BoxLossParams p;
+  memset(&p, 0, sizeof p);
+  p.pred = pred; p.dpred = (half_t*)dpred; p.gt_classes = gt_classes; p.proposals = proposals; p.gt_boxes = gt_boxes; p.loss_out = loss_out;
+  p.n_rois = n_rois; p.K = num_classes; p.cs = cs; p.n_valid = n_valid;
+  p.wx = reg_weights[0]; p.wy = reg_weights[1]; p.ww = reg_weights[2]; p.wh = reg_weights[3]; p.loss_scale = loss_scale;
+  return launch_box_loss(p, (hipStream_t)stream);
+}
+
+int rs_op_mask_loss(const float* logits, void* dlogits, const uint8_t* targets, const int32_t* gt_classes, float* loss_out, int n_masks,
+                    int side, int cs, float loss_scale, void* stream) {
+  MaskLossParams p;
+  memset(&p, 0, sizeof p);
+  p.logits = logits; p.dlogits = (half_t*)dlogits; p.targets = targets; p.gt_classes = gt_classes; p.loss_out = loss_out;
+  p.n_masks = n_masks; p.S = side; p.cs = cs; p.loss_scale = loss_scale;
+  return launch_mask_loss(p, (hipStream_t)stream);
+}
+
+int rs_op_sgd_momentum(float* w, float* momentum_buf, const float* grad, int64_t n, float lr, float momentum, float weight_decay,
+                       float inv_loss_scale, int first_step, void* stream) {
+  return launch_sgd_momentum(w, momentum_buf, grad, n, lr, momentum, weight_decay, inv_loss_scale, first_step, (hipStream_t)stream);
+}
+
+int rs_op_fold_weights(const float* w32, const float* scale, void* w_fwd, void* w_bwd, int cout, int cin, int kh, int kw, int kpad,
+                       int kpad_t, void* stream) {
+  return launch_fold_weights(w32, scale, (half_t*)w_fwd, (half_t*)w_bwd, cout, cin, kh, kw, kpad, kpad_t, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,43 @@
+// Training-path kernels (train_kernels.hip): parameter blocks and launchers.
+#pragma once
+#include "common.h"
+
+struct RpnLossParams {
+  const float* head;        // one level's fused RPN head output [N][HW][cs] fp32: [0,A) logits, [A,5A) deltas
+  half_t* dhead;            // gradient, same layout, fp16 (times loss_scale)
+  const int* labels;        // [N][total_anchors]: 1 positive, 0 negative, -1 not sampled (after subsampling)
+  const float* anchors;     // [total_anchors][4]
+  const float* matched_gt;  // [N][total_anchors][4]
+  float* loss_out;          // [2]: loss_rpn_cls, loss_rpn_loc (accumulated)
+  int A, cs, HW, n_anchors, level_off, total_anchors;
+  float normalizer;         // BATCH_SIZE_PER_IMAGE * N
+  float loss_scale;
+};
+struct BoxLossParams {
+  const float* pred;        // [n_rois][cs] fp32: [0,K] logits (K = background), then 4K deltas
+  half_t* dpred;            // gradient fp16 (times loss_scale)
+  const int* gt_classes;    // [n_rois]: class, K = background, -1 = empty slot (no loss)
+  const float* proposals;   // [n_rois][4]
+  const float* gt_boxes;    // [n_rois][4] matched gt box (used for foreground rows)
+  float* loss_out;          // [2]: loss_cls, loss_box_reg
+  int n_rois, K, cs;
+  float n_valid;            // number of sampled RoIs (gt_classes >= 0): the mean's denominator
+  float wx, wy, ww, wh;
+  float loss_scale;
+};
+struct MaskLossParams {
+  const float* logits;      // [n_masks][S*S][cs] fp32, channel = class
+  half_t* dlogits;          // gradient fp16 (times loss_scale)
+  const uint8_t* targets;   // [n_masks][S*S] 0/1
+  const int* gt_classes;    // [n_masks]
+  float* loss_out;          // [1]
+  int n_masks, S, cs;
+  float loss_scale;
+};
+int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s);
+int launch_box_loss(const BoxLossParams& p, hipStream_t s);
+int launch_mask_loss(const MaskLossParams& p, hipStream_t s);
+int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, float lr, float momentum, float weight_decay,
+                        float inv_loss_scale, int first_step, hipStream_t s);
+int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
+                        int KpadT, hipStream_t s);

@@ -1,0 +1,212 @@
+// Training-path element-wise / reduction kernels.  fp32 math in detectron2's
+// operation order, compiled with -ffp-contract=off like the detection glue.
+//
+//   rpn_loss_kernel        RPN.losses: BCE-with-logits on the sampled anchors + L1 (SMOOTH_L1_BETA 0.0, R:251) on the
+//                          positive anchors' deltas vs Box2BoxTransform.get_deltas(anchor, matched gt), both divided by
+//                          BATCH_SIZE_PER_IMAGE * N (R:223)  [EXT d2: modeling/proposal_generator/rpn.py losses,
+//                          modeling/box_regression.py get_deltas / _dense_box_regression_loss]
+//   box_loss_kernel        FastRCNNOutputLayers.losses: softmax cross-entropy (mean over all sampled RoIs) + L1 on the
+//                          gt class' deltas of foreground RoIs / number of sampled RoIs (weights (10,10,5,5), R:160-164,175)
+//                          [EXT d2: modeling/roi_heads/fast_rcnn.py]
+//   mask_loss_kernel       mask_rcnn_loss: BCE-with-logits of the gt class' 28x28 logits vs the rasterised gt mask, mean over
+//                          all foreground masks and pixels  [EXT d2: modeling/roi_heads/mask_head.py]
+//   sgd_momentum_kernel    torch.optim.SGD step: g += wd*w; buf = mu*buf + g; w -= lr*buf (MOMENTUM 0.9, WEIGHT_DECAY 1e-4,
+//                          no Nesterov, R:281-282,303)  [EXT d2: solver/build.py; torch/optim/sgd.py]
+//   fold_weights_kernel    fp32 master weight -> the two fp16 GEMM operands of the next step: the forward weight
+//                          [Cout][(kh,kw,ci)] with the FrozenBN scale folded in, and its transposed, tap-flipped copy
+//                          [Cin][(kh',kw',co)] for the input-gradient convolution
+// Each loss kernel writes the GRADIENT of the (weighted) total loss w.r.t. its logits/deltas, scaled by `loss_scale`
+// (fp16 loss scaling), and accumulates the loss value itself into an fp32 scalar for logging.
+#include "common.h"
+#include "train.h"
+
+namespace {
+
+__device__ __forceinline__ float bce_with_logits(float x, float t) {
+  // torch: max(x,0) - x*t + log1p(exp(-|x|))
+  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sgnf(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+
+__device__ __forceinline__ void get_deltas(const float s[4], const float t[4], float wx, float wy, float ww, float wh, float out[4]) {
+  const float sw = s[2] - s[0], sh = s[3] - s[1];
+  const float scx = s[0] + 0.5f * sw, scy = s[1] + 0.5f * sh;
+  const float tw = t[2] - t[0], th = t[3] - t[1];
+  const float tcx = t[0] + 0.5f * tw, tcy = t[1] + 0.5f * th;
+  out[0] = wx * (tcx - scx) / sw;
+  out[1] = wy * (tcy - scy) / sh;
+  out[2] = ww * logf(tw / sw);
+  out[3] = wh * logf(th / sh);
+}
+
+__device__ __forceinline__ void block_sum_to(float v, float* dst) {
+  // wave reduction, then one atomic per wave (loss logging only; gradients never go through atomics here)
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(dst, v);
+}
+
+// one thread per anchor of one level; head output rows are [pixel][cs] fp32: columns [0,A) logits, [A,5A) deltas (a*4+d)
+__global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;          // anchor index inside the level, order (y, x, a)
+  float lc = 0.f, ll = 0.f;
+  if (i < p.n_anchors) {
+    const int px = i / p.A, a = i - px * p.A;
+    const long long row = ((long long)n * p.HW + px) * p.cs;
+    const int label = p.labels[(long long)n * p.total_anchors + p.level_off + i];
+    half_t* g = p.dhead + row;
+    float gl = 0.f, gd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (label >= 0) {
+      const float x = p.head[row + a], t = (float)label;
+      lc = bce_with_logits(x, t) / p.normalizer;
+      gl = (sigmoidf(x) - t) / p.normalizer;
+      if (label == 1) {
+        const float* an = p.anchors + ((long long)p.level_off + i) * 4;
+        const float* gt = p.matched_gt + ((long long)n * p.total_anchors + p.level_off + i) * 4;
+        const float s[4] = {an[0], an[1], an[2], an[3]}, t4[4] = {gt[0], gt[1], gt[2], gt[3]};
+        float tgt[4];
+        get_deltas(s, t4, 1.f, 1.f, 1.f, 1.f, tgt);
+        for (int d = 0; d < 4; ++d) {
+          const float diff = p.head[row + p.A + a * 4 + d] - tgt[d];
+          ll += fabsf(diff) / p.normalizer;
+          gd[d] = sgnf(diff) / p.normalizer;
+        }
+      }
+    }
+    g[a] = (half_t)(gl * p.loss_scale);
+    for (int d = 0; d < 4; ++d) g[p.A + a * 4 + d] = (half_t)(gd[d] * p.loss_scale);
+    if (a == 0) for (int c = 5 * p.A; c < p.cs; ++c) g[c] = (half_t)0.f;      // padding columns of the fused head
+  }
+  block_sum_to(lc, p.loss_out);
+  block_sum_to(ll, p.loss_out + 1);
+}
+
+// one thread per sampled RoI; pred rows [roi][cs] fp32: [0,K] class logits (background = K), then 4K deltas
+__global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float lc = 0.f, ll = 0.f;
+  if (r < p.n_rois) {
+    const float* pr = p.pred + (long long)r * p.cs;
+    half_t* g = p.dpred + (long long)r * p.cs;
+    const int K = p.K;
+    const int cls = p.gt_classes[r];                       // 0..K-1 foreground, K background, -1 ignored slot
+    for (int c = 0; c < p.cs; ++c) g[c] = (half_t)0.f;
+    if (cls >= 0 && cls <= K) {                            // anything else (empty slot, corrupt label) contributes nothing
+      float mx = pr[0];
+      for (int c = 1; c <= K; ++c) mx = fmaxf(mx, pr[c]);
+      float sum = 0.f;
+      for (int c = 0; c <= K; ++c) sum += expf(pr[c] - mx);
+      const float lse = mx + logf(sum);
+      lc = (lse - pr[cls]) / p.n_valid;
+      for (int c = 0; c <= K; ++c) {
+        const float sm = expf(pr[c] - lse);
+        g[c] = (half_t)((sm - (c == cls ? 1.f : 0.f)) / p.n_valid * p.loss_scale);
+      }
+      if (cls < K) {
+        const float* pb = p.proposals + (long long)r * 4;
+        const float* gb = p.gt_boxes + (long long)r * 4;
+        const float s[4] = {pb[0], pb[1], pb[2], pb[3]}, t4[4] = {gb[0], gb[1], gb[2], gb[3]};
+        float tgt[4];
+        get_deltas(s, t4, p.wx, p.wy, p.ww, p.wh, tgt);
+        for (int d = 0; d < 4; ++d) {
+          const float diff = pr[K + 1 + cls * 4 + d] - tgt[d];
+          ll += fabsf(diff) / p.n_valid;
+          g[K + 1 + cls * 4 + d] = (half_t)(sgnf(diff) / p.n_valid * p.loss_scale);
+        }
+      }
+    }
+  }
+  block_sum_to(lc, p.loss_out);
+  block_sum_to(ll, p.loss_out + 1);
+}
+
+// one thread per (mask, pixel); logits [mask][S*S][cs] fp32 (channel = class), targets [mask][S*S] uint8
+__global__ __launch_bounds__(256) void mask_loss_kernel(const MaskLossParams p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  float l = 0.f;
+  const long long per = (long long)p.S * p.S;
+  if (i < (long long)p.n_masks * per) {
+    const int m = (int)(i / per);
+    const int cls = p.gt_classes[m];
+    half_t* g = p.dlogits + i * p.cs;
+    for (int c = 0; c < p.cs; ++c) g[c] = (half_t)0.f;
+    if (cls >= 0 && cls < p.cs) {
+      const float x = p.logits[i * p.cs + cls], t = (float)p.targets[i];
+      const float norm = (float)p.n_masks * (float)per;
+      l = bce_with_logits(x, t) / norm;
+      g[cls] = (half_t)((sigmoidf(x) - t) / norm * p.loss_scale);
+    }
+  }
+  block_sum_to(l, p.loss_out);
+}
+
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(float* w, float* buf, const float* grad, long long n, float lr, float momentum,
+                                                          float weight_decay, float inv_loss_scale, int first_step) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float g = grad[i] * inv_loss_scale;
+  g = g + weight_decay * w[i];
+  const float b = first_step ? g : momentum * buf[i] + g;       // torch: the buffer starts as a clone of the first gradient
+  buf[i] = b;
+  w[i] = w[i] - lr * b;
+}
+
+// w32: [Cout][Kpad] fp32 master, K = (kh,kw,ci); fwd: same layout fp16 with scale[co] folded; bwd: [Cin][KpadT] fp16,
+// column ((KH-1-kh)*KW + (KW-1-kw))*Cout + co
+__global__ __launch_bounds__(256) void fold_weights_kernel(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin,
+                                                          int KH, int KW, int Kpad, int KpadT) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n = (long long)Cout * KH * KW * Cin;
+  if (i >= n) return;
+  const int ci = (int)(i % Cin);
+  long long t = i / Cin;
+  const int kw = (int)(t % KW); t /= KW;
+  const int kh = (int)(t % KH);
+  const int co = (int)(t / KH);
+  float v = w32[(long long)co * Kpad + (kh * KW + kw) * Cin + ci] * (scale ? scale[co] : 1.f);
+  // keep the fp32 product as its own rounding step: hipcc otherwise selects v_fma_mixlo_f16 (product rounded ONCE, to
+  // fp16), which differs from the host fold (numpy: fp32 multiply, then astype(float16)) on fp32-rounding ties -- measured
+  // 5 of 73,728 weights one fp16 ulp apart
+  asm volatile("" : "+v"(v));
+  const half_t h = (half_t)v;
+  fwd[(long long)co * Kpad + (kh * KW + kw) * Cin + ci] = h;
+  if (bwd) bwd[(long long)ci * KpadT + ((KH - 1 - kh) * KW + (KW - 1 - kw)) * Cout + co] = h;
+}
+
+}  // namespace
+
+int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.head && p.dhead && p.labels && p.anchors && p.matched_gt && p.loss_out && p.n_anchors > 0 && p.cs >= 5 * p.A, RS_ERR_ARG, "rpn_loss: bad arguments");
+  hipLaunchKernelGGL(rpn_loss_kernel, dim3(cdiv(p.n_anchors, 256), N), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_box_loss(const BoxLossParams& p, hipStream_t s) {
+  RS_CHECK(p.pred && p.dpred && p.gt_classes && p.proposals && p.gt_boxes && p.loss_out && p.n_rois > 0 && p.cs >= 5 * p.K + 1 && p.n_valid > 0, RS_ERR_ARG, "box_loss: bad arguments");
+  hipLaunchKernelGGL(box_loss_kernel, dim3(cdiv(p.n_rois, 256)), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_mask_loss(const MaskLossParams& p, hipStream_t s) {
+  RS_CHECK(p.logits && p.dlogits && p.targets && p.gt_classes && p.loss_out && p.n_masks > 0 && p.S > 0, RS_ERR_ARG, "mask_loss: bad arguments");
+  hipLaunchKernelGGL(mask_loss_kernel, dim3((unsigned)cdiv((long long)p.n_masks * p.S * p.S, 256)), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, float lr, float momentum, float weight_decay,
+                        float inv_loss_scale, int first_step, hipStream_t s) {
+  RS_CHECK(w && buf && grad && n > 0, RS_ERR_ARG, "sgd: bad arguments");
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, w, buf, grad, n, lr, momentum, weight_decay,
+                     inv_loss_scale, first_step);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
+                        int KpadT, hipStream_t s) {
+  RS_CHECK(w32 && fwd && Cout > 0 && Cin > 0, RS_ERR_ARG, "fold: bad arguments");
+  const long long n = (long long)Cout * KH * KW * Cin;
+  hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, w32, scale, fwd, bwd, Cout, Cin, KH, KW, Kpad, KpadT);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}

@@ -247,3 +247,168 @@ def test_deconv2x2_backward_through_conv_ops(gpu_required):
     got_dw = run_wgrad(dy, x, 2, 2, 0, in_halo=1, dy_halo=1)              # (cout'=Cin, cin'=Cout, 2, 2)
     err = float((got_dw - wr.grad).abs().max())
     assert err <= 3e-3 * max(1.0, float(wr.grad.abs().max())), err
+
+
+def _dev(t):
+    return t.contiguous().to(torch.device("cuda:0"))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _get_deltas(src, tgt, w):
+    """Box2BoxTransform.get_deltas ([EXT d2: modeling/box_regression.py])."""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    scx, scy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    tw, th = tgt[:, 2] - tgt[:, 0], tgt[:, 3] - tgt[:, 1]
+    tcx, tcy = tgt[:, 0] + 0.5 * tw, tgt[:, 1] + 0.5 * th
+    return torch.stack([w[0] * (tcx - scx) / sw, w[1] * (tcy - scy) / sh, w[2] * torch.log(tw / sw), w[3] * torch.log(th / sh)], 1)
+
+
+def _rand_boxes(n, g, lo=0.0, hi=300.0):
+    xy = torch.rand(n, 2, generator=g) * (hi - lo) + lo
+    wh = torch.rand(n, 2, generator=g) * 80 + 4
+    return torch.cat([xy, xy + wh], 1)
+
+
+def test_rpn_loss_and_gradient(gpu_required):
+    """RPN.losses restated with torch autograd: BCE-with-logits (sum) over sampled anchors + L1 (SMOOTH_L1_BETA 0) over
+    positive anchors' deltas, both / (BATCH_SIZE_PER_IMAGE * N); two levels sharing one label/anchor table."""
+    lib = load_library()
+    g = torch.Generator().manual_seed(31)
+    N, A, cs = 2, 3, 16
+    hws = [35, 12]
+    total = sum(hw * A for hw in hws)
+    anchors = _rand_boxes(total, g)
+    matched = _rand_boxes(N * total, g).view(N, total, 4)
+    labels = torch.randint(-1, 2, (N, total), generator=g, dtype=torch.int32)
+    heads = [torch.randn(N, hw, cs, generator=g) for hw in hws]
+    normalizer = 256.0 * N
+    scale = 1024.0
+    # reference
+    hr = [h.clone().requires_grad_(True) for h in heads]
+    logits = torch.cat([h[:, :, :A].reshape(N, -1) for h in hr], 1)
+    deltas = torch.cat([h[:, :, A:5 * A].reshape(N, -1, 4) for h in hr], 1)
+    valid, pos = labels >= 0, labels == 1
+    l_cls = F.binary_cross_entropy_with_logits(logits[valid], labels[valid].float(), reduction="sum") / normalizer
+    tgt = torch.stack([_get_deltas(anchors, matched[i], (1, 1, 1, 1)) for i in range(N)])
+    l_loc = (deltas[pos] - tgt[pos]).abs().sum() / normalizer
+    (l_cls + l_loc).backward()
+    # engine
+    loss = _dev(torch.zeros(2))
+    ad, md, ld = _dev(anchors), _dev(matched), _dev(labels)
+    off = 0
+    for h, hgrad, hw in zip(heads, hr, hws):
+        hd = _dev(h)
+        dh = torch.full((N, hw, cs), float("nan"), dtype=torch.float16, device=hd.device)
+        _check(lib, lib.rs_op_rpn_loss(_ptr(hd), _ptr(dh), _ptr(ld), _ptr(ad), _ptr(md), _ptr(loss), N, hw, A, cs, off, total,
+                                       normalizer, scale, None), "rs_op_rpn_loss")
+        torch.cuda.synchronize()
+        got = dh.cpu().float() / scale
+        ref = hgrad.grad
+        assert float(got[:, :, 5 * A:].abs().max()) == 0.0                      # padding columns get zero gradient
+        assert float((got[:, :, :5 * A] - ref[:, :, :5 * A]).abs().max()) <= 2e-3 * float(ref.abs().max())
+        off += hw * A
+    lo = loss.cpu()
+    assert abs(float(lo[0]) - float(l_cls)) <= 1e-5 * max(1.0, float(l_cls)) and abs(float(lo[1]) - float(l_loc)) <= 1e-5 * max(1.0, float(l_loc))
+
+
+def test_box_loss_and_gradient(gpu_required):
+    """FastRCNNOutputLayers.losses: cross_entropy(mean) + class-specific L1 on foreground rows / number of sampled RoIs."""
+    lib = load_library()
+    g = torch.Generator().manual_seed(32)
+    R, K, cs = 700, 2, 16
+    pred = torch.randn(R, cs, generator=g)
+    cls = torch.randint(0, K + 1, (R,), generator=g, dtype=torch.int32)
+    cls[::50] = -1                                                   # empty slots of a fixed-capacity buffer
+    props, gts = _rand_boxes(R, g), _rand_boxes(R, g)
+    w = (10.0, 10.0, 5.0, 5.0)
+    valid = cls >= 0
+    n_valid = float(valid.sum())
+    pr = pred.clone().requires_grad_(True)
+    l_cls = F.cross_entropy(pr[valid][:, :K + 1], cls[valid].long(), reduction="mean")
+    fg = valid & (cls < K)
+    fg_idx = torch.nonzero(fg)[:, 0]
+    d = pr[:, K + 1:K + 1 + 4 * K].view(R, K, 4)[fg_idx, cls[fg_idx].long()]
+    l_reg = (d - _get_deltas(props[fg_idx], gts[fg_idx], w)).abs().sum() / n_valid
+    (l_cls + l_reg).backward()
+    loss = _dev(torch.zeros(2))
+    pd = _dev(pred)
+    dp = torch.full((R, cs), float("nan"), dtype=torch.float16, device=pd.device)
+    scale = 512.0
+    cd, prd, gd = _dev(cls), _dev(props), _dev(gts)            # keep the device buffers alive across the launch
+    _check(lib, lib.rs_op_box_loss(_ptr(pd), _ptr(dp), _ptr(cd), _ptr(prd), _ptr(gd), _ptr(loss), R, K, cs, n_valid,
+                                   (C.c_float * 4)(*w), scale, None), "rs_op_box_loss")
+    torch.cuda.synchronize()
+    got = dp.cpu().float() / scale
+    assert float((got - pr.grad).abs().max()) <= 2e-3 * float(pr.grad.abs().max())
+    lo = loss.cpu()
+    assert abs(float(lo[0]) - float(l_cls)) <= 1e-5 * float(l_cls) + 1e-6 and abs(float(lo[1]) - float(l_reg)) <= 1e-5 * float(l_reg) + 1e-6
+
+
+def test_mask_loss_and_gradient(gpu_required):
+    lib = load_library()
+    g = torch.Generator().manual_seed(33)
+    M, S, cs, K = 37, 28, 16, 2
+    logits = torch.randn(M, S * S, cs, generator=g) * 2
+    tgt = (torch.rand(M, S * S, generator=g) > 0.5).to(torch.uint8)
+    cls = torch.randint(0, K, (M,), generator=g, dtype=torch.int32)
+    lr = logits.clone().requires_grad_(True)
+    sel = lr[torch.arange(M), :, cls.long()]
+    l = F.binary_cross_entropy_with_logits(sel, tgt.float(), reduction="mean")
+    l.backward()
+    loss = _dev(torch.zeros(1))
+    ld = _dev(logits)
+    dl = torch.full((M, S * S, cs), float("nan"), dtype=torch.float16, device=ld.device)
+    scale = 4096.0
+    td, cd = _dev(tgt), _dev(cls)
+    _check(lib, lib.rs_op_mask_loss(_ptr(ld), _ptr(dl), _ptr(td), _ptr(cd), _ptr(loss), M, S, cs, scale, None), "rs_op_mask_loss")
+    torch.cuda.synchronize()
+    got = dl.cpu().float() / scale
+    assert float((got - lr.grad).abs().max()) <= 2e-3 * float(lr.grad.abs().max())
+    assert abs(float(loss.cpu()[0]) - float(l)) <= 1e-5 * float(l)
+
+
+def test_sgd_momentum_equals_torch_optim(gpu_required):
+    """Three steps of torch.optim.SGD(lr, momentum 0.9, weight_decay 1e-4) on a flat tensor, gradients carrying a loss scale."""
+    lib = load_library()
+    g = torch.Generator().manual_seed(34)
+    n = 10007
+    w0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * 0.01 for _ in range(3)]
+    wt = w0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([wt], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    wd, buf = _dev(w0), _dev(torch.zeros(n))
+    scale = 256.0
+    for i, gr in enumerate(grads):
+        wt.grad = gr.clone()
+        opt.step()
+        gd = _dev(gr * scale)
+        _check(lib, lib.rs_op_sgd_momentum(_ptr(wd), _ptr(buf), _ptr(gd), n, 0.01, 0.9, 1e-4, 1.0 / scale, int(i == 0), None), "sgd")
+        torch.cuda.synchronize()
+    assert float((wd.cpu() - wt.detach()).abs().max()) <= 1e-6
+
+
+def test_fold_weights_layouts(gpu_required):
+    """fp32 master [Cout][(kh,kw,ci)] -> fp16 forward weight with the FrozenBN scale folded and the transposed, tap-flipped
+    copy rs_op_conv2d_dgrad consumes."""
+    lib = load_library()
+    g = torch.Generator().manual_seed(35)
+    cout, cin, k = 128, 64, 3
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    scale = torch.rand(cout, generator=g) + 0.5
+    master = w.permute(0, 2, 3, 1).reshape(cout, k * k * cin).contiguous()
+    kpad, kpad_t = k * k * cin, k * k * cout
+    md = _dev(master)
+    fwd = torch.zeros(cout, kpad, dtype=torch.float16, device=md.device)
+    bwd = torch.zeros(cin, kpad_t, dtype=torch.float16, device=md.device)
+    sd = _dev(scale)
+    _check(lib, lib.rs_op_fold_weights(_ptr(md), _ptr(sd), _ptr(fwd), _ptr(bwd), cout, cin, k, k, kpad, kpad_t, None), "fold")
+    torch.cuda.synchronize()
+    folded = w * scale[:, None, None, None]
+    want_f = folded.permute(0, 2, 3, 1).reshape(cout, kpad).half()
+    want_b, _ = _wt_flipped(folded)
+    df = (fwd.cpu().float() - want_f.float()).abs()
+    db = (bwd.cpu().float() - want_b[:, :kpad_t].float()).abs()
+    assert float(df.max()) == 0.0 and float(db.max()) == 0.0, (float(df.max()), int((df > 0).sum()), float(db.max()), int((db > 0).sum()))
