@@ -218,6 +218,22 @@ int rs_op_roi_align_bwd(float* const dfeats[4], const int32_t heights[4], const 
  *  rs_op_sgd_momentum: one torch.optim.SGD step on a flat fp32 tensor (grad is divided by the loss scale first).
  *  rs_op_fold_weights: fp32 master weight [cout][kpad] -> fp16 forward weight (same layout, optional per-channel scale
  *                   folded) and its transposed, tap-flipped copy [cin][kpad_t] for rs_op_conv2d_dgrad (w_bwd may be NULL). */
+/* Training path, label assignment.
+ *  rs_op_match    : Matcher on pairwise IoU ([EXT d2: modeling/matcher.py, structures/boxes.py]).  boxes: [n_boxes][4] shared
+ *                   by all images (anchors) or [n_images][n_boxes][4] (per_image_boxes = 1, box_count[n] valid rows);
+ *                   gt [n_images][gt_cap][4] (gt_cap <= 256).  matched: index of the best gt (lowest index on ties);
+ *                   labels: lbl_lo / lbl_mid / lbl_hi for best IoU < t_lo / in [t_lo, t_hi) / >= t_hi (RPN: 0,-1,1 at
+ *                   0.3/0.7, R:237-243; ROI heads: 0,1,1 at 0.5/0.5, R:184-188); allow_low_quality: boxes whose IoU with a
+ *                   gt equals that gt's highest IoU become 1 (RPN only).
+ *  rs_op_subsample: subsample_labels ([EXT d2: modeling/sampling.py]).  Positives: label != -1 && != bg_label.  rpn_mode 1
+ *                   rewrites labels in place (1 / 0 / -1); otherwise `sampled` [n_images][num_samples] receives the sampled
+ *                   indices (positives first, ascending inside each group, -1 padded).  The random choice is a keyed hash of
+ *                   (seed, image, index): deterministic for a seed, a different uniform sample per seed. */
+int rs_op_match(const float* boxes, int per_image_boxes, const int32_t* box_count, const float* gt, const int32_t* gt_count,
+                int32_t* matched, int32_t* labels, float* best_iou, int n_images, int n_boxes, int gt_cap, float t_lo, float t_hi,
+                int lbl_lo, int lbl_mid, int lbl_hi, int allow_low_quality, void* stream);
+int rs_op_subsample(int32_t* labels, int32_t* sampled, int32_t* sampled_count, int n_images, int n, int num_samples,
+                    float positive_fraction, int bg_label, int rpn_mode, uint32_t seed, void* stream);
 int rs_op_rpn_loss(const float* head, void* dhead, const int32_t* labels, const float* anchors, const float* matched_gt,
                    float* loss_out, int n, int hw, int num_anchors, int cs, int level_off, int total_anchors, float normalizer,
                    float loss_scale, void* stream);

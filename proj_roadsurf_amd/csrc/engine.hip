@@ -1294,6 +1294,33 @@ int rs_op_mask_loss(const float* logits, void* dlogits, const uint8_t* targets, 
   return launch_mask_loss(p, (hipStream_t)stream);
 }
 
+int rs_op_match(const float* boxes, int per_image_boxes, const int32_t* box_count, const float* gt, const int32_t* gt_count,
+                int32_t* matched, int32_t* labels, float* best_iou, int n_images, int n_boxes, int gt_cap, float t_lo, float t_hi,
+                int lbl_lo, int lbl_mid, int lbl_hi, int allow_low_quality, void* stream) {
+  MatchParams p;
+  memset(&p, 0, sizeof p);
+  p.boxes = boxes; p.per_image_boxes = per_image_boxes; p.box_count = box_count; p.gt = gt; p.gt_count = gt_count;
+  p.matched = matched; p.labels = labels; p.best_iou = best_iou; p.n_boxes = n_boxes; p.gt_cap = gt_cap;
+  p.t_lo = t_lo; p.t_hi = t_hi; p.lbl_lo = lbl_lo; p.lbl_mid = lbl_mid; p.lbl_hi = lbl_hi;
+  void* scratch = nullptr;
+  if (allow_low_quality) {
+    RS_HIP(hipMalloc(&scratch, (size_t)n_images * gt_cap * 4));
+    p.gt_best = (unsigned int*)scratch;
+  }
+  int rc = launch_match(p, n_images, (hipStream_t)stream);
+  if (scratch) { hipStreamSynchronize((hipStream_t)stream); hipFree(scratch); }
+  return rc;
+}
+
+int rs_op_subsample(int32_t* labels, int32_t* sampled, int32_t* sampled_count, int n_images, int n, int num_samples,
+                    float positive_fraction, int bg_label, int rpn_mode, uint32_t seed, void* stream) {
+  SubsampleParams p;
+  memset(&p, 0, sizeof p);
+  p.labels = labels; p.sampled = sampled; p.sampled_count = sampled_count; p.n = n; p.num_samples = num_samples;
+  p.positive_fraction = positive_fraction; p.bg_label = bg_label; p.rpn_mode = rpn_mode; p.seed = seed;
+  return launch_subsample(p, n_images, (hipStream_t)stream);
+}
+
 int rs_op_sgd_momentum(float* w, float* momentum_buf, const float* grad, int64_t n, float lr, float momentum, float weight_decay,
                        float inv_loss_scale, int first_step, void* stream) {
   return launch_sgd_momentum(w, momentum_buf, grad, n, lr, momentum, weight_decay, inv_loss_scale, first_step, (hipStream_t)stream);

@@ -41,3 +41,29 @@ int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, fl
                         float inv_loss_scale, int first_step, hipStream_t s);
 int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
                         int KpadT, hipStream_t s);
+
+// ---- label assignment (Matcher + subsample_labels) ----
+struct MatchParams {
+  const float* boxes;       // [n_boxes][4] shared by all images (anchors), or [N][n_boxes][4] when per_image_boxes
+  const float* gt;          // [N][gt_cap][4]
+  const int* gt_count;      // [N]
+  int* matched;             // [N][n_boxes] index of the best gt (0 when the image has none)
+  int* labels;              // [N][n_boxes] label of the IoU band: lbl_lo (< t_lo), lbl_mid ([t_lo, t_hi)), lbl_hi (>= t_hi)
+  float* best_iou;          // [N][n_boxes] (optional)
+  unsigned int* gt_best;    // [N][gt_cap] scratch: bit pattern of every gt's highest IoU (zeroed by the launcher); null = no
+                            // low-quality matches
+  const int* box_count;     // optional [N]: boxes beyond it get label -1 (per-image proposal lists)
+  int n_boxes, gt_cap, per_image_boxes;
+  float t_lo, t_hi;
+  int lbl_lo, lbl_mid, lbl_hi;
+};
+struct SubsampleParams {
+  int* labels;              // [N][n] in: class / band label; out (rpn_mode): 1 sampled positive, 0 sampled negative, -1 rest
+  int* sampled;             // [N][num_samples] (roi mode): sampled indices, positives first, each group ascending; -1 padded
+  int* sampled_count;       // [N][2]: number of sampled positives, negatives
+  int n, num_samples, bg_label, rpn_mode;
+  float positive_fraction;
+  unsigned int seed;        // changes every iteration
+};
+int launch_match(const MatchParams& p, int N, hipStream_t s);
+int launch_subsample(const SubsampleParams& p, int N, hipStream_t s);

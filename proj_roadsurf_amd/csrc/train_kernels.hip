@@ -174,6 +174,182 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const float* w32, con
   if (bwd) bwd[(long long)ci * KpadT + ((KH - 1 - kh) * KW + (KW - 1 - kw)) * Cout + co] = h;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matcher ([EXT d2: modeling/matcher.py]) on pairwise_iou ([EXT d2: structures/boxes.py]): per box the best gt
+// (lowest index on ties) and the label of its IoU band; optionally "low-quality matches": every box whose IoU with
+// some gt EQUALS that gt's highest IoU over all boxes becomes positive (second kernel, same IoU arithmetic bit for bit).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float iou_d2(const float a[4], float area_a, const float b[4], float area_b) {
+  const float w = fminf(a[2], b[2]) - fmaxf(a[0], b[0]);
+  const float h = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
+  const float inter = fmaxf(w, 0.f) * fmaxf(h, 0.f);
+  return inter > 0.f ? inter / (area_a + area_b - inter) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void match_kernel(const MatchParams p) {
+  __shared__ float s_gt[256 * 4];
+  __shared__ float s_area[256];
+  const int n = blockIdx.y;
+  const int G = p.gt_count[n] < p.gt_cap ? p.gt_count[n] : p.gt_cap;
+  for (int i = threadIdx.x; i < G; i += 256) {
+    const float* g = p.gt + ((long long)n * p.gt_cap + i) * 4;
+    s_gt[i * 4] = g[0]; s_gt[i * 4 + 1] = g[1]; s_gt[i * 4 + 2] = g[2]; s_gt[i * 4 + 3] = g[3];
+    s_area[i] = (g[2] - g[0]) * (g[3] - g[1]);
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n_boxes) return;
+  const long long o = (long long)n * p.n_boxes + i;
+  if (p.box_count && i >= p.box_count[n]) { p.matched[o] = 0; p.labels[o] = -1; if (p.best_iou) p.best_iou[o] = 0.f; return; }
+  const float* bp = p.boxes + (p.per_image_boxes ? o : (long long)i) * 4;
+  const float b[4] = {bp[0], bp[1], bp[2], bp[3]};
+  const float area = (b[2] - b[0]) * (b[3] - b[1]);
+  float best = -1.f;
+  int arg = 0;
+  for (int g = 0; g < G; ++g) {
+    const float v = iou_d2(&s_gt[g * 4], s_area[g], b, area);
+    if (v > best) { best = v; arg = g; }
+    if (p.gt_best) atomicMax(p.gt_best + (long long)n * p.gt_cap + g, __float_as_uint(v));   // v >= 0: bit order == value order
+  }
+  int label = p.lbl_lo;
+  if (G > 0) label = best >= p.t_hi ? p.lbl_hi : (best >= p.t_lo ? p.lbl_mid : p.lbl_lo);
+  p.matched[o] = arg;
+  p.labels[o] = label;
+  if (p.best_iou) p.best_iou[o] = G > 0 ? best : 0.f;
+}
+
+__global__ __launch_bounds__(256) void match_lowq_kernel(const MatchParams p) {
+  __shared__ float s_gt[256 * 4];
+  __shared__ float s_area[256];
+  __shared__ float s_best[256];
+  const int n = blockIdx.y;
+  const int G = p.gt_count[n] < p.gt_cap ? p.gt_count[n] : p.gt_cap;
+  for (int i = threadIdx.x; i < G; i += 256) {
+    const float* g = p.gt + ((long long)n * p.gt_cap + i) * 4;
+    s_gt[i * 4] = g[0]; s_gt[i * 4 + 1] = g[1]; s_gt[i * 4 + 2] = g[2]; s_gt[i * 4 + 3] = g[3];
+    s_area[i] = (g[2] - g[0]) * (g[3] - g[1]);
+    s_best[i] = __uint_as_float(p.gt_best[(long long)n * p.gt_cap + i]);
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n_boxes) return;
+  const long long o = (long long)n * p.n_boxes + i;
+  if (p.box_count && i >= p.box_count[n]) return;
+  const float* bp = p.boxes + (p.per_image_boxes ? o : (long long)i) * 4;
+  const float b[4] = {bp[0], bp[1], bp[2], bp[3]};
+  const float area = (b[2] - b[0]) * (b[3] - b[1]);
+  bool hit = false;
+  for (int g = 0; g < G; ++g) hit = hit || (iou_d2(&s_gt[g * 4], s_area[g], b, area) == s_best[g]);
+  if (hit) p.labels[o] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// subsample_labels ([EXT d2: modeling/sampling.py]): up to floor(num_samples * positive_fraction) positives and the rest
+// negatives, uniformly at random.  Every candidate gets a 64-bit key (hash(seed, image, index) << 32 | index); the k
+// candidates with the SMALLEST keys are the sample (a random permutation's first k) -- found with an 8-pass radix
+// select, deterministic for a given seed.  One workgroup per image.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned long long sample_key(unsigned int seed, int n, int i) {
+  const unsigned int h = mix32(mix32(seed ^ (0x9e3779b9u * (unsigned)(n + 1))) + (unsigned)i * 0x85ebca6bu);
+  return ((unsigned long long)h << 32) | (unsigned int)i;
+}
+
+// smallest key such that exactly k candidates of `group` (positives or negatives) have key <= it; k >= 1
+__device__ unsigned long long kth_key(const int* labels, int n_el, int bg, bool want_pos, int k, unsigned int seed, int img, int* hist) {
+  unsigned long long prefix = 0ull;
+  int need = k;
+  for (int pass = 7; pass >= 0; --pass) {
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const int shift = pass * 8;
+    const unsigned long long hi_mask = pass == 7 ? 0ull : (~0ull << (shift + 8));
+    for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
+      const int l = labels[i];
+      const bool cand = want_pos ? (l != -1 && l != bg) : (l == bg);
+      if (!cand) continue;
+      const unsigned long long key = sample_key(seed, img, i);
+      if ((key & hi_mask) != (prefix & hi_mask)) continue;
+      atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    int acc = 0, digit = 0;
+    for (int b = 0; b < 256; ++b) {          // every thread walks the 256 bins: same result everywhere, no extra barrier
+      if (acc + hist[b] >= need) { digit = b; break; }
+      acc += hist[b];
+    }
+    need -= acc;
+    prefix |= (unsigned long long)digit << shift;
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(1024) void subsample_kernel(const SubsampleParams p) {
+  __shared__ int hist[256];
+  __shared__ int s_cnt[2];
+  __shared__ int s_out[2];
+  const int n = blockIdx.x;
+  int* labels = p.labels + (long long)n * p.n;
+  if (threadIdx.x < 2) { s_cnt[threadIdx.x] = 0; s_out[threadIdx.x] = 0; }
+  __syncthreads();
+  int cp = 0, cn = 0;
+  for (int i = threadIdx.x; i < p.n; i += blockDim.x) {
+    const int l = labels[i];
+    if (l == p.bg_label) ++cn; else if (l != -1) ++cp;
+  }
+  for (int o = 32; o > 0; o >>= 1) { cp += __shfl_xor(cp, o); cn += __shfl_xor(cn, o); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt[0], cp); atomicAdd(&s_cnt[1], cn); }
+  __syncthreads();
+  const int P = s_cnt[0], Q = s_cnt[1];
+  int num_pos = (int)((float)p.num_samples * p.positive_fraction);
+  if (num_pos > P) num_pos = P;
+  int num_neg = p.num_samples - num_pos;
+  if (num_neg > Q) num_neg = Q;
+  unsigned long long thr_pos = 0ull, thr_neg = 0ull;
+  if (num_pos > 0 && num_pos < P) thr_pos = kth_key(labels, p.n, p.bg_label, true, num_pos, p.seed, n, hist);
+  if (num_neg > 0 && num_neg < Q) thr_neg = kth_key(labels, p.n, p.bg_label, false, num_neg, p.seed, n, hist);
+  __syncthreads();
+  if (threadIdx.x == 0 && p.sampled_count) { p.sampled_count[n * 2] = num_pos; p.sampled_count[n * 2 + 1] = num_neg; }
+  if (p.sampled) for (int i = threadIdx.x; i < p.num_samples; i += blockDim.x) p.sampled[(long long)n * p.num_samples + i] = -1;
+  __syncthreads();
+  // selection pass; in roi mode the list positions come from an ordered scan (ascending index inside each group)
+  for (int base = 0; base < p.n; base += blockDim.x) {
+    const int i = base + threadIdx.x;
+    int sel = 0;       // 1 = sampled positive, 2 = sampled negative
+    if (i < p.n) {
+      const int l = labels[i];
+      if (l == p.bg_label) {
+        if (num_neg > 0 && (num_neg >= Q || sample_key(p.seed, n, i) <= thr_neg)) sel = 2;
+      } else if (l != -1) {
+        if (num_pos > 0 && (num_pos >= P || sample_key(p.seed, n, i) <= thr_pos)) sel = 1;
+      }
+      if (p.rpn_mode) labels[i] = sel == 1 ? 1 : (sel == 2 ? 0 : -1);
+    }
+    if (p.sampled) {
+      // wave-level ordered compaction, waves in order through s_out
+      for (int grp = 1; grp <= 2; ++grp) {
+        const unsigned long long bal = __ballot(sel == grp);
+        const int lane = threadIdx.x & 63;
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        const int wcount = __popcll(bal);
+        __shared__ int w_off[16];
+        if (lane == 0) w_off[threadIdx.x >> 6] = wcount;
+        __syncthreads();
+        int off = s_out[grp - 1];
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += w_off[w];
+        if (sel == grp) p.sampled[(long long)n * p.num_samples + (grp == 2 ? num_pos : 0) + off + before] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += w_off[w]; s_out[grp - 1] += t; }
+        __syncthreads();
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s) {
@@ -207,6 +383,22 @@ int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_
   RS_CHECK(w32 && fwd && Cout > 0 && Cin > 0, RS_ERR_ARG, "fold: bad arguments");
   const long long n = (long long)Cout * KH * KW * Cin;
   hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, w32, scale, fwd, bwd, Cout, Cin, KH, KW, Kpad, KpadT);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_match(const MatchParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.boxes && p.gt && p.gt_count && p.matched && p.labels && p.n_boxes > 0 && p.gt_cap >= 1 && p.gt_cap <= 256, RS_ERR_ARG,
+           "match: bad arguments (gt capacity %d, at most 256)", p.gt_cap);
+  if (p.gt_best) RS_HIP(hipMemsetAsync(p.gt_best, 0, (size_t)N * p.gt_cap * 4, s));
+  hipLaunchKernelGGL(match_kernel, dim3(cdiv(p.n_boxes, 256), N), dim3(256), 0, s, p);
+  if (p.gt_best) hipLaunchKernelGGL(match_lowq_kernel, dim3(cdiv(p.n_boxes, 256), N), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_subsample(const SubsampleParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.labels && p.n > 0 && p.num_samples > 0 && (p.rpn_mode || p.sampled), RS_ERR_ARG, "subsample: bad arguments");
+  hipLaunchKernelGGL(subsample_kernel, dim3(N), dim3(1024), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

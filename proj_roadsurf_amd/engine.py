@@ -91,6 +91,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_op_roi_align.argtypes = [C.POINTER(vp), i32p, i32p, f32p, i32, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.rs_op_roi_align_bwd.argtypes = [C.POINTER(vp), i32p, i32p, f32p, i32, vp, i32, i32, i32, i32, vp, vp]
     f32 = C.c_float
+    lib.rs_op_match.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, i32, i32, vp]
+    lib.rs_op_subsample.argtypes = [vp, vp, vp, i32, i32, i32, f32, i32, i32, C.c_uint32, vp]
     lib.rs_op_rpn_loss.argtypes = [vp] * 6 + [i32] * 6 + [f32, f32, vp]
     lib.rs_op_box_loss.argtypes = [vp] * 6 + [i32, i32, i32, f32, f32p, f32, vp]
     lib.rs_op_mask_loss.argtypes = [vp] * 5 + [i32, i32, i32, f32, vp]

@@ -2,6 +2,7 @@
 (fp32) on the same fp16-representable operands.  rs_op_conv2d_wgrad accumulates fp16 products in fp32 on MFMA over
 up to ~1e5 pixels; tolerance: max|err| <= 2e-3 * max|ref| (+ fp32 summation-order noise)."""
 import ctypes as C
+import math
 
 import numpy as np
 import pytest
@@ -412,3 +413,97 @@ def test_fold_weights_layouts(gpu_required):
     df = (fwd.cpu().float() - want_f.float()).abs()
     db = (bwd.cpu().float() - want_b[:, :kpad_t].float()).abs()
     assert float(df.max()) == 0.0 and float(db.max()) == 0.0, (float(df.max()), int((df > 0).sum()), float(db.max()), int((db > 0).sum()))
+
+
+def test_matcher_equals_oracle(gpu_required):
+    """rs_op_match vs oracle/train_oracle.py (Matcher on pairwise_iou): RPN form (0.3/0.7, labels 0/-1/1, low-quality
+    matches, anchors shared by the images) and ROI-heads form (0.5, per-image proposal lists with counts) -- exact."""
+    from oracle import train_oracle as T
+    from oracle import maskrcnn_oracle as O
+    from proj_roadsurf_amd.spec import EngineSpec
+    lib = load_library()
+    g = torch.Generator().manual_seed(41)
+    spec = EngineSpec()
+    anchors = torch.cat([O.grid_anchors(spec, l, hw, hw) for l, hw in enumerate([40, 20, 10, 5, 3])])
+    A = anchors.shape[0]
+    N, cap = 3, 16
+    gts = [_rand_boxes(k, g, 0, 120) for k in (5, 0, 11)]
+    gt = torch.zeros(N, cap, 4)
+    for i, b in enumerate(gts):
+        gt[i, : b.shape[0]] = b
+    cnt = torch.tensor([b.shape[0] for b in gts], dtype=torch.int32)
+    ad, gd, cd = _dev(anchors), _dev(gt), _dev(cnt)
+    m = torch.empty(N, A, dtype=torch.int32, device=ad.device)
+    l = torch.empty(N, A, dtype=torch.int32, device=ad.device)
+    _check(lib, lib.rs_op_match(_ptr(ad), 0, None, _ptr(gd), _ptr(cd), _ptr(m), _ptr(l), None, N, A, cap, 0.3, 0.7, 0, -1, 1, 1, None), "match")
+    torch.cuda.synchronize()
+    for i in range(N):
+        wm, wl = T.matcher(T.pairwise_iou(gts[i], anchors), [0.3, 0.7], [0, -1, 1], True)
+        assert torch.equal(l[i].cpu(), wl.to(torch.int32)), f"image {i}: labels"
+        assert torch.equal(m[i].cpu(), wm.to(torch.int32)), f"image {i}: matched gt"
+    assert int((l[0] == 1).sum()) >= 5                      # every gt has at least its low-quality match
+    # ROI heads: per-image proposals (+ appended gt), threshold 0.5, no low-quality matches
+    P = 300
+    props = torch.stack([torch.cat([_rand_boxes(P - gts[i].shape[0], g, 0, 120), gts[i]]) for i in range(N)])
+    pc = torch.tensor([P, P - 40, P], dtype=torch.int32)
+    pd, pcd = _dev(props), _dev(pc)
+    m2 = torch.empty(N, P, dtype=torch.int32, device=ad.device)
+    l2 = torch.empty(N, P, dtype=torch.int32, device=ad.device)
+    _check(lib, lib.rs_op_match(_ptr(pd), 1, _ptr(pcd), _ptr(gd), _ptr(cd), _ptr(m2), _ptr(l2), None, N, P, cap, 0.5, 0.5, 0, 1, 1, 0, None), "match")
+    torch.cuda.synchronize()
+    for i in range(N):
+        k = int(pc[i])
+        wm, wl = T.matcher(T.pairwise_iou(gts[i], props[i, :k]), [0.5], [0, 1], False)
+        assert torch.equal(l2[i, :k].cpu(), wl.to(torch.int32)) and torch.equal(m2[i, :k].cpu(), wm.to(torch.int32))
+        assert bool((l2[i, k:] == -1).all())
+
+
+def test_subsample_is_a_valid_uniform_sample(gpu_required):
+    """rs_op_subsample: quotas of subsample_labels (R:223,246 RPN; R:178,192 ROI heads), members drawn only from the right
+    group, deterministic per seed, different per seed, and every candidate equally likely (chi-square-ish bound)."""
+    lib = load_library()
+    g = torch.Generator().manual_seed(42)
+    N, n = 2, 20000
+    base = torch.zeros(N, n, dtype=torch.int32)
+    base[0, torch.randperm(n, generator=g)[:400]] = 1
+    base[0, torch.randperm(n, generator=g)[:3000]] = -1
+    base[1, torch.randperm(n, generator=g)[:30]] = 1              # fewer positives than the quota
+    dev = torch.device("cuda:0")
+    outs = []
+    for seed in (1, 1, 2):
+        lab = base.clone().to(dev)
+        cnt = torch.zeros(N, 2, dtype=torch.int32, device=dev)
+        _check(lib, lib.rs_op_subsample(_ptr(lab), None, _ptr(cnt), N, n, 256, 0.5, 0, 1, seed, None), "subsample")
+        torch.cuda.synchronize()
+        outs.append((lab.cpu(), cnt.cpu()))
+    (a, ca), (b, _), (c, _) = outs
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    for i, (want_pos, want_neg) in enumerate([(128, 128), (int((base[1] == 1).sum()), 256 - int((base[1] == 1).sum()))]):
+        assert int((a[i] == 1).sum()) == want_pos == int(ca[i, 0]) and int((a[i] == 0).sum()) == want_neg == int(ca[i, 1])
+        assert bool((base[i][a[i] == 1] == 1).all()) and bool((base[i][a[i] == 0] == 0).all())
+    # ROI mode: index list, foreground first, ascending inside each group; class labels (bg = 2)
+    n2 = 1100
+    cls = torch.full((1, n2), 2, dtype=torch.int32)
+    cls[0, torch.randperm(n2, generator=g)[:90]] = torch.randint(0, 2, (90,), generator=g, dtype=torch.int32)
+    cls[0, torch.randperm(n2, generator=g)[:50]] = -1
+    hits = torch.zeros(n2)
+    trials = 200
+    for seed in range(trials):
+        lab = cls.clone().to(dev)
+        samp = torch.empty(1, 512, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, 2, dtype=torch.int32, device=dev)
+        _check(lib, lib.rs_op_subsample(_ptr(lab), _ptr(samp), _ptr(cnt), 1, n2, 512, 0.25, 2, 0, 1000 + seed, None), "subsample")
+        torch.cuda.synchronize()
+        s_, c_ = samp.cpu()[0], cnt.cpu()[0]
+        nfg = int(((cls[0] != 2) & (cls[0] != -1)).sum())
+        npos, nneg = int(c_[0]), int(c_[1])
+        assert npos == min(nfg, 128) and nneg == min(int((cls[0] == 2).sum()), 512 - npos)
+        fg, bg = s_[:npos], s_[npos:npos + nneg]
+        assert bool((cls[0][fg.long()] < 2).all()) and bool((cls[0][fg.long()] >= 0).all()) and bool((cls[0][bg.long()] == 2).all())
+        assert bool((fg[1:] > fg[:-1]).all()) and bool((bg[1:] > bg[:-1]).all()) and bool((s_[npos + nneg:] == -1).all())
+        assert torch.equal(lab.cpu(), cls)                          # roi mode leaves the labels alone
+        hits[bg.long()] += 1
+    bgmask = cls[0] == 2
+    p_sel = (512 - min(nfg, 128)) / int(bgmask.sum())
+    z = (hits[bgmask] - trials * p_sel) / math.sqrt(trials * p_sel * (1 - p_sel))
+    assert float(z.abs().max()) < 5.0 and abs(float(z.mean())) < 0.2
