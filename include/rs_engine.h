@@ -247,6 +247,29 @@ int rs_op_sgd_momentum(float* w, float* momentum_buf, const float* grad, int64_t
 int rs_op_fold_weights(const float* w32, const float* scale, void* w_fwd, void* w_bwd, int cout, int cin, int kh, int kw, int kpad,
                        int kpad_t, void* stream);
 
+/* ------------------------------------------------------------------ training engine (in progress)
+ * Owns a forward engine (same blob, packed with train=True: fp32 master weights `<layer>.m32`, FrozenBN scales `<layer>.s`),
+ * one flat fp32 master / gradient / momentum buffer in the forward GEMM layout, a gradient buffer per activation, and the
+ * backward stage list.  Round 1 covers the trunk: rs_trainer_forward_trunk (preprocess .. FPN), rs_trainer_backward_trunk
+ * (FPN + res5..res3 from the gradients of p2..p6, tensors "d:p2".."d:p6"), rs_trainer_apply_sgd (torch.optim.SGD step on
+ * every trainable tensor + refold of the fp16 operands).  What detectron2 reaches through autograd + SimpleTrainer.run_step
+ * ([EXT d2: engine/train_loop.py]).  Tensors: "d:<forward tensor>" activation gradients (fp16, times loss_scale),
+ * "g:<layer>.w|.b" gradients and "m:<layer>.w|.b" master weights (fp32, forward layout). */
+typedef struct rs_trainer rs_trainer;
+int rs_trainer_create(const rs_spec* spec, const void* weights, size_t nbytes, int device_ordinal, int batch, int tile_h,
+                      int tile_w, int tile_c, float loss_scale, rs_trainer** out);
+void rs_trainer_destroy(rs_trainer* t);
+rs_engine* rs_trainer_engine(rs_trainer* t);
+int rs_trainer_forward_trunk(rs_trainer* t, const uint8_t* tiles_dev, int n);
+int rs_trainer_backward_trunk(rs_trainer* t, int n);
+int rs_trainer_apply_sgd(rs_trainer* t, float lr, float momentum, float weight_decay);
+int rs_trainer_sync(rs_trainer* t);
+int rs_trainer_tensor(rs_trainer* t, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo);
+int rs_trainer_tensor_count(rs_trainer* t);
+int rs_trainer_tensor_name(rs_trainer* t, int i, char* name_out);
+int64_t rs_trainer_param_count(rs_trainer* t);
+void* rs_trainer_grad_buffer(rs_trainer* t);
+
 /* -------- host-only helpers (no GPU needed) -------- */
 /* detectron2 ResizeShortestEdge.get_output_shape. */
 void rs_resize_shape(int h, int w, int short_edge, int max_size, int* new_h, int* new_w);

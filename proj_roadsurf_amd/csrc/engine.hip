@@ -18,6 +18,7 @@
 
 // ------------------------------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
+static bool g_trainer_unfused_shortcut = false;   // set by rs_trainer_create while it builds its forward engine
 void rs_set_error(const char* fmt, ...) {
   va_list a;
   va_start(a, fmt);
@@ -946,6 +947,7 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   if (e->f32) e->use_glds = -1;
   const char* fs = getenv("RS_FUSE_SHORTCUT");
   e->fuse_shortcut = fs ? atoi(fs) : 1;
+  if (g_trainer_unfused_shortcut) e->fuse_shortcut = 0;   // the training engine differentiates conv3 and the shortcut separately
   const char* gg = getenv("RS_USE_GRAPH");
   e->use_graph = gg ? atoi(gg) : 0;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
@@ -1328,7 +1330,9 @@ int rs_op_sgd_momentum(float* w, float* momentum_buf, const float* grad, int64_t
 
 int rs_op_fold_weights(const float* w32, const float* scale, void* w_fwd, void* w_bwd, int cout, int cin, int kh, int kw, int kpad,
                        int kpad_t, void* stream) {
-  return launch_fold_weights(w32, scale, (half_t*)w_fwd, (half_t*)w_bwd, cout, cin, kh, kw, kpad, kpad_t, (hipStream_t)stream);
+  return launch_fold_weights(w32, scale, (half_t*)w_fwd, (half_t*)w_bwd, cout, cin, kh, kw, kpad, cout, kpad_t, (hipStream_t)stream);
 }
 
 }  // extern "C"
+
+#include "train_engine.inc"

@@ -40,7 +40,9 @@ int launch_mask_loss(const MaskLossParams& p, hipStream_t s);
 int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, float lr, float momentum, float weight_decay,
                         float inv_loss_scale, int first_step, hipStream_t s);
 int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
-                        int KpadT, hipStream_t s);
+                        int kc, int KpadT, hipStream_t s);
+int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, hipStream_t s);
+int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s);
 
 // ---- label assignment (Matcher + subsample_labels) ----
 struct MatchParams {

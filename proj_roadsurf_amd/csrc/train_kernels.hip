@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* w, float* buf,
 }
 
 // w32: [Cout][Kpad] fp32 master, K = (kh,kw,ci); fwd: same layout fp16 with scale[co] folded; bwd: [Cin][KpadT] fp16,
-// column ((KH-1-kh)*KW + (KW-1-kw))*Cout + co
+// column ((KH-1-kh)*KW + (KW-1-kw))*kc + co (kc = Cout rounded up to the 64-channel K step; the padding columns stay zero)
 __global__ __launch_bounds__(256) void fold_weights_kernel(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin,
-                                                          int KH, int KW, int Kpad, int KpadT) {
+                                                          int KH, int KW, int Kpad, int kc, int KpadT) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n = (long long)Cout * KH * KW * Cin;
   if (i >= n) return;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const float* w32, con
   asm volatile("" : "+v"(v));
   const half_t h = (half_t)v;
   fwd[(long long)co * Kpad + (kh * KW + kw) * Cin + ci] = h;
-  if (bwd) bwd[(long long)ci * KpadT + ((KH - 1 - kh) * KW + (KW - 1 - kw)) * Cout + co] = h;
+  if (bwd) bwd[(long long)ci * KpadT + ((KH - 1 - kh) * KW + (KW - 1 - kw)) * kc + co] = h;   // kc >= Cout: channel stride per tap
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,6 +350,48 @@ __global__ __launch_bounds__(1024) void subsample_kernel(const SubsampleParams p
   }
 }
 
+// bias gradient: grad[c] = sum over rows of dy[row][c] (halo rows are zero, so the whole buffer can be summed).
+// One workgroup per 8 channels, fixed summation order (bitwise reproducible).
+__global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* grad) {
+  __shared__ float red[256][8];
+  const int c0 = blockIdx.x * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long r = threadIdx.x; r < rows; r += 256) {
+    const half8 v = *(const half8*)(dy + r * C + c0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[i];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[threadIdx.x][i] += red[threadIdx.x + s][i];
+    __syncthreads();
+  }
+  if (threadIdx.x < 8 && c0 + (int)threadIdx.x < cout) grad[c0 + threadIdx.x] = red[0][threadIdx.x];
+}
+
+// backward of LastLevelMaxPool (max_pool2d k=1 s=2): d_fine[2y][2x] += d_coarse[y][x]; both NHWC fp16 with halo 1
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const half_t* dc, half_t* df, int N, int Hf, int Wf, int Hc, int Wc, int C) {
+  const int cv = C >> 3;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Hc * Wc * cv;
+  if (gid >= total) return;
+  const int c8 = (int)(gid % cv);
+  long long t = gid / cv;
+  const int x = (int)(t % Wc); t /= Wc;
+  const int y = (int)(t % Hc);
+  const int n = (int)(t / Hc);
+  const half8 a = *(const half8*)(dc + (((long long)n * (Hc + 2) + y + 1) * (Wc + 2) + x + 1) * C + c8 * 8);
+  half_t* o = df + (((long long)n * (Hf + 2) + 2 * y + 1) * (Wf + 2) + 2 * x + 1) * C + c8 * 8;
+  half8 b = *(const half8*)o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b[i] = (half_t)((float)b[i] + (float)a[i]);
+  *(half8*)o = b;
+}
+
 }  // namespace
 
 int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s) {
@@ -379,10 +421,10 @@ int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, fl
   return RS_OK;
 }
 int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
-                        int KpadT, hipStream_t s) {
-  RS_CHECK(w32 && fwd && Cout > 0 && Cin > 0, RS_ERR_ARG, "fold: bad arguments");
+                        int kc, int KpadT, hipStream_t s) {
+  RS_CHECK(w32 && fwd && Cout > 0 && Cin > 0 && kc >= Cout && (!bwd || KH * KW * kc <= KpadT), RS_ERR_ARG, "fold: bad arguments");
   const long long n = (long long)Cout * KH * KW * Cin;
-  hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, w32, scale, fwd, bwd, Cout, Cin, KH, KW, Kpad, KpadT);
+  hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, w32, scale, fwd, bwd, Cout, Cin, KH, KW, Kpad, kc, KpadT);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
@@ -399,6 +441,20 @@ int launch_match(const MatchParams& p, int N, hipStream_t s) {
 int launch_subsample(const SubsampleParams& p, int N, hipStream_t s) {
   RS_CHECK(p.labels && p.n > 0 && p.num_samples > 0 && (p.rpn_mode || p.sampled), RS_ERR_ARG, "subsample: bad arguments");
   hipLaunchKernelGGL(subsample_kernel, dim3(N), dim3(1024), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, hipStream_t s) {
+  RS_CHECK(dy && grad && rows > 0 && C % 8 == 0 && cout > 0 && cout <= C, RS_ERR_ARG, "bias_grad: bad arguments");
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(cout, 8)), dim3(256), 0, s, dy, rows, C, cout, grad);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s) {
+  RS_CHECK(d_coarse && d_fine && C % 8 == 0 && 2 * (Hc - 1) < Hf && 2 * (Wc - 1) < Wf, RS_ERR_ARG, "subsample2_bwd: bad arguments");
+  const long long total = (long long)N * Hc * Wc * (C >> 3);
+  hipLaunchKernelGGL(subsample2_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, d_coarse, d_fine, N, Hf, Wf, Hc, Wc, C);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

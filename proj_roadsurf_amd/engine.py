@@ -466,3 +466,110 @@ class Predictor:
             out.extend({"instances": r} for r in res)
             i = j
         return out
+
+
+class Trainer:
+    """Training engine (include/rs_engine.h ``rs_trainer_*``; SURVEY.md §8a rows T1/T2, in progress): forward engine +
+    flat fp32 master / gradient / momentum buffers + backward stage list.  Round 1: trunk forward/backward and the SGD
+    step; losses, label assignment and RoI-head backward exist as operators (``rs_op_*``) and are wired in next."""
+
+    def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], batch: int = 2,
+                 device: int = 0, loss_scale: float = 1.0, lib_path: Optional[str] = None):
+        self.lib = lib = load_library(lib_path)
+        vp, i32 = C.c_void_p, C.c_int
+        lib.rs_trainer_create.argtypes = [C.POINTER(RsSpec), vp, C.c_size_t, i32, i32, i32, i32, i32, C.c_float, C.POINTER(vp)]
+        lib.rs_trainer_destroy.argtypes = [vp]
+        lib.rs_trainer_destroy.restype = None
+        lib.rs_trainer_engine.argtypes = [vp]
+        lib.rs_trainer_engine.restype = vp
+        lib.rs_trainer_forward_trunk.argtypes = [vp, vp, i32]
+        lib.rs_trainer_backward_trunk.argtypes = [vp, i32]
+        lib.rs_trainer_apply_sgd.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+        lib.rs_trainer_sync.argtypes = [vp]
+        lib.rs_trainer_tensor.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        lib.rs_trainer_tensor_count.argtypes = [vp]
+        lib.rs_trainer_tensor_name.argtypes = [vp, i32, C.c_char_p]
+        lib.rs_trainer_param_count.argtypes = [vp]
+        lib.rs_trainer_param_count.restype = C.c_int64
+        self.spec = spec
+        self.tile_h, self.tile_w, self.tile_c = (int(x) for x in tile_shape)
+        self.batch = int(batch)
+        blob = pack_weights(spec, weights, train=True)
+        rs = make_rs_spec(spec)
+        h = C.c_void_p()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _check(lib, lib.rs_trainer_create(C.byref(rs), buf, len(blob), device, self.batch, self.tile_h, self.tile_w, self.tile_c,
+                                          float(loss_scale), C.byref(h)), "rs_trainer_create")
+        self._h = h
+        self._eng = C.c_void_p(lib.rs_trainer_engine(h))
+
+    def _tensor_ptr(self, name: str, engine: bool = False):
+        p, dt, nd, halo = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        dims = (C.c_int64 * 5)()
+        if engine:
+            _check(self.lib, self.lib.rs_engine_tensor(self._eng, name.encode(), C.byref(p), C.byref(dt), C.byref(nd), dims, C.byref(halo)), f"tensor {name}")
+        else:
+            _check(self.lib, self.lib.rs_trainer_tensor(self._h, name.encode(), C.byref(p), C.byref(dt), C.byref(nd), dims, C.byref(halo)), f"tensor {name}")
+        return int(p.value), np.dtype(DT_NP[dt.value]), tuple(int(dims[i]) for i in range(nd.value)), halo.value
+
+    def tensor(self, name: str, engine: bool = False, strip_halo: bool = True) -> np.ndarray:
+        """Copy a trainer tensor ("d:<act>", "g:<layer>.w", "m:<layer>.w") or, with ``engine=True``, a forward tensor to the host."""
+        ptr, dt, shape, halo = self._tensor_ptr(name, engine)
+        a = np.empty(shape, dt)
+        _check(self.lib, self.lib.rs_memcpy_d2h(a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), a.nbytes), "rs_memcpy_d2h")
+        if strip_halo and halo:
+            a = a[:, halo:-halo, halo:-halo]
+        return a
+
+    def set_tensor(self, name: str, interior: np.ndarray) -> None:
+        """Write the interior of an activation-gradient tensor (the halo stays zero)."""
+        ptr, dt, shape, halo = self._tensor_ptr(name)
+        full = np.zeros(shape, dt)
+        n = interior.shape[0]
+        if halo:
+            full[:n, halo:-halo, halo:-halo] = interior.astype(dt)
+        else:
+            full[:n] = interior.astype(dt)
+        _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(ptr), full.ctypes.data_as(C.c_void_p), full.nbytes), "rs_memcpy_h2d")
+
+    def tensor_names(self) -> List[str]:
+        buf = C.create_string_buffer(96)
+        out = []
+        for i in range(self.lib.rs_trainer_tensor_count(self._h)):
+            self.lib.rs_trainer_tensor_name(self._h, i, buf)
+            out.append(buf.value.decode())
+        return out
+
+    def upload_tiles(self, tiles: np.ndarray) -> int:
+        tiles = np.ascontiguousarray(tiles)
+        assert tiles.dtype == np.uint8 and tiles.shape[1:] == (self.tile_h, self.tile_w, self.tile_c) and tiles.shape[0] <= self.batch
+        ptr, _, _, _ = self._tensor_ptr("tiles", engine=True)
+        _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(ptr), tiles.ctypes.data_as(C.c_void_p), tiles.nbytes), "rs_memcpy_h2d")
+        return ptr
+
+    def forward_trunk(self, tiles_ptr: int, n: int) -> None:
+        _check(self.lib, self.lib.rs_trainer_forward_trunk(self._h, C.c_void_p(tiles_ptr), n), "rs_trainer_forward_trunk")
+
+    def backward_trunk(self, n: int) -> None:
+        _check(self.lib, self.lib.rs_trainer_backward_trunk(self._h, n), "rs_trainer_backward_trunk")
+
+    def apply_sgd(self, lr: float, momentum: float = 0.9, weight_decay: float = 1e-4) -> None:
+        _check(self.lib, self.lib.rs_trainer_apply_sgd(self._h, lr, momentum, weight_decay), "rs_trainer_apply_sgd")
+
+    def sync(self) -> None:
+        _check(self.lib, self.lib.rs_trainer_sync(self._h), "rs_trainer_sync")
+
+    @property
+    def param_count(self) -> int:
+        return int(self.lib.rs_trainer_param_count(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.rs_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -193,14 +193,18 @@ def _pad_rows(w: np.ndarray, b: np.ndarray, mult: int) -> Tuple[np.ndarray, np.n
     return w2, b2
 
 
-def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], w_dtype=np.float16) -> Dict[str, np.ndarray]:
-    """Kernel-ready tensors keyed ``<layer>.w`` (fp16 [Cout_pad][Kpad]) / ``<layer>.b`` (fp32)."""
+def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], w_dtype=np.float16, fold_bn: bool = True) -> Dict[str, np.ndarray]:
+    """Kernel-ready tensors keyed ``<layer>.w`` (fp16 [Cout_pad][Kpad]) / ``<layer>.b`` (fp32).
+    ``fold_bn=False`` keeps the raw (unfolded) convolution weight in ``.w`` -- the layout of the training master
+    weights -- while ``.b`` is still the folded FrozenBN bias."""
     T: Dict[str, np.ndarray] = {}
     for name, cin, cout, k, has_norm in conv_layers(spec):
         if name.endswith("objectness_logits") or name.endswith("anchor_deltas"):
             continue
         if has_norm:
             w, b = _fold_bn(W, name, spec.bn_eps)
+            if not fold_bn:
+                w = W[name + ".weight"].astype(np.float32)
         else:
             w, b = W[name + ".weight"].astype(np.float32), W[name + ".bias"].astype(np.float32)
         if name.endswith("stem.conv1"):
@@ -281,8 +285,53 @@ def serialize(tensors: Dict[str, np.ndarray]) -> bytes:
     return bytes(buf)
 
 
-def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray]) -> bytes:
+def bn_scale(W: Dict[str, np.ndarray], name: str, eps: float) -> np.ndarray:
+    """FrozenBatchNorm2d scale = weight * rsqrt(running_var + eps) of layer ``name`` (fp32)."""
+    return (W[name + ".norm.weight"].astype(np.float32) / np.sqrt(W[name + ".norm.running_var"].astype(np.float32) + np.float32(eps))).astype(np.float32)
+
+
+def trainable_layers(spec: EngineSpec, freeze_at: int = 2) -> List[str]:
+    """Engine layer names that receive gradients (FREEZE_AT 2: stem and res2 frozen, R:58), fused heads included."""
+    L = []
+    for name, _, _, _, _ in conv_layers(spec):
+        if name.endswith("objectness_logits") or name.endswith("anchor_deltas"):
+            continue
+        if ".stem." in name and freeze_at >= 1:
+            continue
+        if ".res2." in name and freeze_at >= 2:
+            continue
+        L.append(name)
+    L += ["proposal_generator.rpn_head.heads", "roi_heads.box_head.fc1", "roi_heads.box_head.fc2", "roi_heads.box_predictor"]
+    if spec.mask_on:
+        L += ["roi_heads.mask_head.deconv", "roi_heads.mask_head.predictor16"]
+    return L
+
+
+def train_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], freeze_at: int = 2) -> Dict[str, np.ndarray]:
+    """Extra blob entries of the training engine: per trainable layer the fp32 master weight ``<layer>.m32`` in the
+    forward GEMM layout (UNFOLDED: FrozenBN has no parameters, the trainable tensor is the raw convolution weight) and,
+    for FrozenBN layers, the per-channel scale ``<layer>.s`` that the forward fold and the weight gradient apply."""
+    raw = engine_tensors(spec, W, w_dtype=np.float32, fold_bn=False)
+    T: Dict[str, np.ndarray] = {}
+    has_norm = {n: hn for n, _, _, _, hn in conv_layers(spec)}
+    for name in trainable_layers(spec, freeze_at):
+        if name == "roi_heads.mask_head.predictor16":
+            # the mask predictor as a 16-row GEMM operand (forward uses a VALU dot on the predicted class only; training
+            # needs all classes' logits and the layer's gradients): rows [0,K) = classes, padded to 16
+            pw = W["roi_heads.mask_head.predictor.weight"].astype(np.float32)[:, :, 0, 0]
+            wp, bp = _pad_rows(_ohwi(pw[:, :, None, None], pw.shape[1], np.float32), W["roi_heads.mask_head.predictor.bias"].astype(np.float32), 16)
+            T[name + ".m32"], T[name + ".w"], T[name + ".b"] = wp, wp.astype(np.float16), bp
+            continue
+        T[name + ".m32"] = raw[name + ".w"].astype(np.float32)
+        if has_norm.get(name, False):
+            T[name + ".s"] = bn_scale(W, name, spec.bn_eps)
+    return T
+
+
+def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False) -> bytes:
     T = engine_tensors(spec, W)
+    if train:
+        T.update(train_tensors(spec, W))
     if spec.precision == "fp32":
         # fp32 validation mode: same layout, GEMM weights additionally kept in fp32 ("<layer>.w32")
         T32 = engine_tensors(spec, W, w_dtype=np.float32)
