@@ -262,6 +262,13 @@ void rs_trainer_destroy(rs_trainer* t);
 rs_engine* rs_trainer_engine(rs_trainer* t);
 int rs_trainer_forward_trunk(rs_trainer* t, const uint8_t* tiles_dev, int n);
 int rs_trainer_backward_trunk(rs_trainer* t, int n);
+/* Ground truth of the batch (host pointers): boxes in network-input pixels [n][cap][4], classes [n][cap], counts [n]. */
+int rs_trainer_set_targets(rs_trainer* t, const float* gt_boxes, const int32_t* gt_classes, const int32_t* gt_count, int n, int cap);
+/* RPN of the training forward + RPN.losses + its backward: heads on the current FPN maps, anchor Matcher (0.3/0.7, low-quality
+ * matches) and subsample_labels (256 @ 0.5) keyed by `seed`, loss_rpn_cls / loss_rpn_loc into tensor "losses"[0..1], gradients of
+ * the shared head accumulated over the levels, d:p2..d:p6 overwritten with the head's input gradient.  external_labels = 1 keeps
+ * the caller's "rpn_labels" / "rpn_matched" (parity tests feed the oracle's sample). */
+int rs_trainer_rpn_step(rs_trainer* t, int n, uint32_t seed, int external_labels);
 int rs_trainer_apply_sgd(rs_trainer* t, float lr, float momentum, float weight_decay);
 int rs_trainer_sync(rs_trainer* t);
 int rs_trainer_tensor(rs_trainer* t, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo);

@@ -91,8 +91,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
         gx = p.x + src_chunk;                                  // any valid address; multiplied by zero
       }
       char* dst = base + piece * 1024;
-      glds16(gy, dst);
-      glds16(gy + 64, dst + SUB);
+      // channel chunks past the gradient buffer's row (narrow heads: 16 outputs stored 64 wide) read the zero row
+      const half_t* gy0 = (co0 + src_chunk < p.dy_Cs) ? gy : p.zeros + src_chunk;
+      const half_t* gy1 = (co0 + 64 + src_chunk < p.dy_Cs) ? gy + 64 : p.zeros + src_chunk;
+      glds16(gy0, dst);
+      glds16(gy1, dst + SUB);
       glds16(gx + (m < p.M ? x_off[0] : 0), dst + 2 * SUB);
       glds16(gx + (m < p.M ? x_off[1] : 0), dst + 3 * SUB);
     }
@@ -206,16 +209,15 @@ int wgrad_splits(const WgradParams& p) {
 
 int launch_conv_wgrad(const WgradParams& p, hipStream_t stream) {
   RS_CHECK(p.dy && p.x && p.partial && p.grad && p.zeros, RS_ERR_ARG, "wgrad: null pointer");
-  RS_CHECK(p.M > 0 && p.Cin % 64 == 0 && p.Cout % 64 == 0 && p.dy_Cs % 8 == 0, RS_ERR_ARG, "wgrad: Cin %d / Cout %d must be multiples of 64", p.Cin, p.Cout);
+  RS_CHECK(p.M > 0 && p.Cin % 64 == 0 && p.dy_Cs % 8 == 0 && p.Cout >= 1 && p.Cout <= p.dy_Cs, RS_ERR_ARG, "wgrad: Cin %d must be a multiple of 64, Cout %d <= gradient row width %d", p.Cin, p.Cout, p.dy_Cs);
   RS_CHECK(p.KH * p.KW * p.Cin <= p.Kpad && p.splits >= 1, RS_ERR_ARG, "wgrad: K exceeds Kpad");
-  RS_CHECK(p.Cout % BM == 0, RS_ERR_UNSUPPORTED, "wgrad: Cout %d not a multiple of %d", p.Cout, BM);
   static bool done = false;
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     done = true;
   }
   const int units = p.KH * p.KW * (p.Cin >> 6);
-  dim3 grid(p.Cout / BM, cdiv(units, 2), p.splits);
+  dim3 grid(cdiv(p.Cout, BM), cdiv(units, 2), p.splits);
   hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(NT), LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());
   const long long n_el = (long long)p.Cout * p.Kpad;

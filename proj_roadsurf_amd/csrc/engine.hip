@@ -454,7 +454,7 @@ int rs_engine::build() {
   for (int l = 0; l < L; ++l) {
     const std::string ln = std::to_string(l + 2);
     Act t;
-    if ((rc = new_act(&t, "rpn_conv" + ln, NB, P[l].H, P[l].W, 256, 0))) return rc;
+    if ((rc = new_act(&t, "rpn_conv" + ln, NB, P[l].H, P[l].W, 256, 1))) return rc;   // halo 1: its gradient is the input of a 3x3 (training)
     if ((rc = add_conv("rpn.conv" + ln, "proposal_generator.rpn_head.conv", P[l], t, 3, 1, 1, true, nullptr, nullptr, 256))) return rc;
     float* ho = nullptr;
     if ((rc = alloc((void**)&ho, (size_t)NB * P[l].H * P[l].W * head_cs * 4))) return rc;
@@ -468,7 +468,7 @@ int rs_engine::build() {
       ConvParams p;
       memset(&p, 0, sizeof p);
       p.in = t.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev; p.out = ho;
-      p.Ho = t.H; p.Wo = t.W; p.in_Hp = t.Hp(); p.in_Wp = t.Wp(); p.in_Cs = 256; p.in_off = 0; p.stride = 1;
+      p.Ho = t.H; p.Wo = t.W; p.in_Hp = t.Hp(); p.in_Wp = t.Wp(); p.in_Cs = 256; p.in_off = t.pad; p.stride = 1;
       p.KH = p.KW = 1; p.Cin = 256; p.Kpad = (int)w->dims[1]; p.Cout = head_cs;
       p.out_Hp = t.H; p.out_Wp = t.W; p.out_Cs = head_cs; p.out_pad = 0; p.out_f32 = 1;
       const int mpi = t.H * t.W;

@@ -7,9 +7,11 @@ struct RpnLossParams {
   half_t* dhead;            // gradient, same layout, fp16 (times loss_scale)
   const int* labels;        // [N][total_anchors]: 1 positive, 0 negative, -1 not sampled (after subsampling)
   const float* anchors;     // [total_anchors][4]
-  const float* matched_gt;  // [N][total_anchors][4]
+  const float* matched_gt;  // [N][total_anchors][4] matched gt box per anchor, or null: gathered from gt/matched below
+  const float* gt;          // [N][gt_cap][4]
+  const int* matched;       // [N][total_anchors] index of the matched gt
   float* loss_out;          // [2]: loss_rpn_cls, loss_rpn_loc (accumulated)
-  int A, cs, HW, n_anchors, level_off, total_anchors;
+  int A, cs, dcs, HW, n_anchors, level_off, total_anchors, gt_cap;   // dcs: row stride of dhead (>= 5A; 0 = cs)
   float normalizer;         // BATCH_SIZE_PER_IMAGE * N
   float loss_scale;
 };
@@ -20,7 +22,7 @@ struct BoxLossParams {
   const float* proposals;   // [n_rois][4]
   const float* gt_boxes;    // [n_rois][4] matched gt box (used for foreground rows)
   float* loss_out;          // [2]: loss_cls, loss_box_reg
-  int n_rois, K, cs;
+  int n_rois, K, cs, dcs;   // dcs: row stride of dpred (0 = cs)
   float n_valid;            // number of sampled RoIs (gt_classes >= 0): the mean's denominator
   float wx, wy, ww, wh;
   float loss_scale;
@@ -31,7 +33,7 @@ struct MaskLossParams {
   const uint8_t* targets;   // [n_masks][S*S] 0/1
   const int* gt_classes;    // [n_masks]
   float* loss_out;          // [1]
-  int n_masks, S, cs;
+  int n_masks, S, cs, dcs;  // dcs: row stride of dlogits (0 = cs)
   float loss_scale;
 };
 int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s);
@@ -41,7 +43,7 @@ int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, fl
                         float inv_loss_scale, int first_step, hipStream_t s);
 int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
                         int kc, int KpadT, hipStream_t s);
-int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, hipStream_t s);
+int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s);
 int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s);
 
 // ---- label assignment (Matcher + subsample_labels) ----

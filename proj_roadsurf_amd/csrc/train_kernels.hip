@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
     const int px = i / p.A, a = i - px * p.A;
     const long long row = ((long long)n * p.HW + px) * p.cs;
     const int label = p.labels[(long long)n * p.total_anchors + p.level_off + i];
-    half_t* g = p.dhead + row;
+    const int dcs = p.dcs ? p.dcs : p.cs;
+    half_t* g = p.dhead + ((long long)n * p.HW + px) * dcs;
     float gl = 0.f, gd[4] = {0.f, 0.f, 0.f, 0.f};
     if (label >= 0) {
       const float x = p.head[row + a], t = (float)label;
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
       gl = (sigmoidf(x) - t) / p.normalizer;
       if (label == 1) {
         const float* an = p.anchors + ((long long)p.level_off + i) * 4;
-        const float* gt = p.matched_gt + ((long long)n * p.total_anchors + p.level_off + i) * 4;
+        const long long ai = (long long)n * p.total_anchors + p.level_off + i;
+        const float* gt = p.matched_gt ? p.matched_gt + ai * 4 : p.gt + ((long long)n * p.gt_cap + p.matched[ai]) * 4;
         const float s[4] = {an[0], an[1], an[2], an[3]}, t4[4] = {gt[0], gt[1], gt[2], gt[3]};
         float tgt[4];
         get_deltas(s, t4, 1.f, 1.f, 1.f, 1.f, tgt);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
     }
     g[a] = (half_t)(gl * p.loss_scale);
     for (int d = 0; d < 4; ++d) g[p.A + a * 4 + d] = (half_t)(gd[d] * p.loss_scale);
-    if (a == 0) for (int c = 5 * p.A; c < p.cs; ++c) g[c] = (half_t)0.f;      // padding columns of the fused head
+    if (a == 0) for (int c = 5 * p.A; c < dcs; ++c) g[c] = (half_t)0.f;       // padding columns of the fused head
   }
   block_sum_to(lc, p.loss_out);
   block_sum_to(ll, p.loss_out + 1);
@@ -88,10 +90,11 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
   float lc = 0.f, ll = 0.f;
   if (r < p.n_rois) {
     const float* pr = p.pred + (long long)r * p.cs;
-    half_t* g = p.dpred + (long long)r * p.cs;
+    const int dcs = p.dcs ? p.dcs : p.cs;
+    half_t* g = p.dpred + (long long)r * dcs;
     const int K = p.K;
     const int cls = p.gt_classes[r];                       // 0..K-1 foreground, K background, -1 ignored slot
-    for (int c = 0; c < p.cs; ++c) g[c] = (half_t)0.f;
+    for (int c = 0; c < dcs; ++c) g[c] = (half_t)0.f;
     if (cls >= 0 && cls <= K) {                            // anything else (empty slot, corrupt label) contributes nothing
       float mx = pr[0];
       for (int c = 1; c <= K; ++c) mx = fmaxf(mx, pr[c]);
@@ -129,8 +132,9 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const MaskLossParams p) 
   if (i < (long long)p.n_masks * per) {
     const int m = (int)(i / per);
     const int cls = p.gt_classes[m];
-    half_t* g = p.dlogits + i * p.cs;
-    for (int c = 0; c < p.cs; ++c) g[c] = (half_t)0.f;
+    const int dcs = p.dcs ? p.dcs : p.cs;
+    half_t* g = p.dlogits + i * dcs;
+    for (int c = 0; c < dcs; ++c) g[c] = (half_t)0.f;
     if (cls >= 0 && cls < p.cs) {
       const float x = p.logits[i * p.cs + cls], t = (float)p.targets[i];
       const float norm = (float)p.n_masks * (float)per;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(1024) void subsample_kernel(const SubsampleParams p
 
 // bias gradient: grad[c] = sum over rows of dy[row][c] (halo rows are zero, so the whole buffer can be summed).
 // One workgroup per 8 channels, fixed summation order (bitwise reproducible).
-__global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* grad) {
+__global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate) {
   __shared__ float red[256][8];
   const int c0 = blockIdx.x * 8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -370,7 +374,8 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long l
       for (int i = 0; i < 8; ++i) red[threadIdx.x][i] += red[threadIdx.x + s][i];
     __syncthreads();
   }
-  if (threadIdx.x < 8 && c0 + (int)threadIdx.x < cout) grad[c0 + threadIdx.x] = red[0][threadIdx.x];
+  if (threadIdx.x < 8 && c0 + (int)threadIdx.x < cout)
+    grad[c0 + threadIdx.x] = accumulate ? grad[c0 + threadIdx.x] + red[0][threadIdx.x] : red[0][threadIdx.x];
 }
 
 // backward of LastLevelMaxPool (max_pool2d k=1 s=2): d_fine[2y][2x] += d_coarse[y][x]; both NHWC fp16 with halo 1
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(256) void subsample2_bwd_kernel(const half_t* dc, h
 }  // namespace
 
 int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s) {
-  RS_CHECK(p.head && p.dhead && p.labels && p.anchors && p.matched_gt && p.loss_out && p.n_anchors > 0 && p.cs >= 5 * p.A, RS_ERR_ARG, "rpn_loss: bad arguments");
+  RS_CHECK(p.head && p.dhead && p.labels && p.anchors && (p.matched_gt || (p.gt && p.matched)) && p.loss_out && p.n_anchors > 0 && p.cs >= 5 * p.A, RS_ERR_ARG, "rpn_loss: bad arguments");
   hipLaunchKernelGGL(rpn_loss_kernel, dim3(cdiv(p.n_anchors, 256), N), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
@@ -445,9 +450,9 @@ int launch_subsample(const SubsampleParams& p, int N, hipStream_t s) {
   return RS_OK;
 }
 
-int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, hipStream_t s) {
+int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s) {
   RS_CHECK(dy && grad && rows > 0 && C % 8 == 0 && cout > 0 && cout <= C, RS_ERR_ARG, "bias_grad: bad arguments");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(cout, 8)), dim3(256), 0, s, dy, rows, C, cout, grad);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(cout, 8)), dim3(256), 0, s, dy, rows, C, cout, grad, accumulate);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

@@ -485,6 +485,8 @@ class Trainer:
         lib.rs_trainer_forward_trunk.argtypes = [vp, vp, i32]
         lib.rs_trainer_backward_trunk.argtypes = [vp, i32]
         lib.rs_trainer_apply_sgd.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+        lib.rs_trainer_set_targets.argtypes = [vp, vp, vp, vp, i32, i32]
+        lib.rs_trainer_rpn_step.argtypes = [vp, i32, C.c_uint32, i32]
         lib.rs_trainer_sync.argtypes = [vp]
         lib.rs_trainer_tensor.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         lib.rs_trainer_tensor_count.argtypes = [vp]
@@ -549,6 +551,29 @@ class Trainer:
 
     def forward_trunk(self, tiles_ptr: int, n: int) -> None:
         _check(self.lib, self.lib.rs_trainer_forward_trunk(self._h, C.c_void_p(tiles_ptr), n), "rs_trainer_forward_trunk")
+
+    def set_targets(self, gt_boxes: Sequence[np.ndarray], gt_classes: Sequence[np.ndarray]) -> None:
+        """Ground truth per image: boxes (k_i, 4) in NETWORK-INPUT pixels, classes (k_i,)."""
+        n = len(gt_boxes)
+        cap = max(1, max(int(b.shape[0]) for b in gt_boxes))
+        bx = np.zeros((n, cap, 4), np.float32)
+        cl = np.zeros((n, cap), np.int32)
+        cnt = np.zeros(n, np.int32)
+        for i, (b, c) in enumerate(zip(gt_boxes, gt_classes)):
+            k = int(b.shape[0])
+            bx[i, :k], cl[i, :k], cnt[i] = b, c, k
+        _check(self.lib, self.lib.rs_trainer_set_targets(self._h, bx.ctypes.data_as(C.c_void_p), cl.ctypes.data_as(C.c_void_p),
+                                                         cnt.ctypes.data_as(C.c_void_p), n, cap), "rs_trainer_set_targets")
+
+    def rpn_step(self, n: int, seed: int = 1, external_labels: bool = False) -> None:
+        _check(self.lib, self.lib.rs_trainer_rpn_step(self._h, n, seed & 0xFFFFFFFF, int(external_labels)), "rs_trainer_rpn_step")
+
+    def write_tensor(self, name: str, data: np.ndarray) -> None:
+        """Overwrite a whole trainer tensor (no halo handling)."""
+        ptr, dt, shape, _ = self._tensor_ptr(name)
+        a = np.ascontiguousarray(data.astype(dt))
+        assert a.shape == shape, (a.shape, shape)
+        _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes), "rs_memcpy_h2d")
 
     def backward_trunk(self, n: int) -> None:
         _check(self.lib, self.lib.rs_trainer_backward_trunk(self._h, n), "rs_trainer_backward_trunk")

@@ -128,3 +128,76 @@ def test_sgd_step_updates_master_and_forward_weights(trunk):
     ref = feats["p2"].detach().permute(0, 2, 3, 1).numpy()
     assert 0 < float(np.abs(p2 - ref).max())                       # the step changed the network
     assert float(np.linalg.norm(p2 - ref) / np.linalg.norm(ref)) < 0.1 and scale.shape[0] == m1.shape[0]
+
+
+def test_rpn_losses_and_full_backward_match_autograd(gpu_required):
+    """RPN training step end to end: engine-side Matcher + sampler pick the anchors, then loss_rpn_cls / loss_rpn_loc and
+    the gradients of the RPN head AND (through d:p2..d:p6 and the trunk backward) of the backbone are compared with
+    autograd of the oracle evaluated on the SAME sampled anchors (loss scale 256 on the engine side)."""
+    from oracle import maskrcnn_oracle as O
+    from oracle import train_oracle as T
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=321)
+    scale = 256.0
+    tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=scale)
+    try:
+        gt_boxes = [np.array([[20.0, 30.0, 120.0, 160.0], [150.0, 40.0, 300.0, 130.0], [60.0, 200.0, 110.0, 260.0]], np.float32),
+                    np.array([[100.0, 100.0, 260.0, 280.0]], np.float32)]
+        gt_classes = [np.array([0, 1, 0]), np.array([1])]
+        tr.set_targets(gt_boxes, gt_classes)
+        tr.forward_trunk(tr.upload_tiles(tiles), 2)
+        tr.rpn_step(2, seed=7)
+        tr.backward_trunk(2)
+        tr.sync()
+        labels = torch.from_numpy(tr.tensor("rpn_labels").astype(np.int64))
+        matched = torch.from_numpy(tr.tensor("rpn_matched").astype(np.int64))
+        losses = tr.tensor("losses")
+        # engine-side targets are a valid sample of the oracle's Matcher output
+        anchors = torch.cat([O.grid_anchors(spec, l, hw, hw) for l, hw in enumerate((80, 40, 20, 10, 5))])
+        assert np.allclose(tr.tensor("anchors"), anchors.numpy())
+        for i in range(2):
+            gt = torch.from_numpy(gt_boxes[i])
+            m, lab = T.matcher(T.pairwise_iou(gt, anchors), [0.3, 0.7], [0, -1, 1], True)
+            assert torch.equal(m, matched[i])
+            assert bool((lab[labels[i] == 1] == 1).all()) and bool((lab[labels[i] == 0] == 0).all())
+            npos = int((labels[i] == 1).sum())
+            assert npos == min(int((lab == 1).sum()), 128) and int((labels[i] == 0).sum()) == 256 - npos
+        # oracle on the same sample
+        W = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in Wn.items()}
+        keys = [k for k in T.trainable_keys(W) if k.startswith("backbone.") or k.startswith("proposal_generator.")]
+        for k in keys:
+            W[k].requires_grad_(True)
+        x = torch.from_numpy(tr.tensor("net_input", engine=True)[..., :3].astype(np.float32)).permute(0, 3, 1, 2)
+        feats = O.resnet_forward(spec, W, x)
+        feats.update(O.fpn_forward(spec, W, feats))
+        logits, deltas = O.rpn_head(W, [feats[n] for n in spec.rpn_in_features])
+        lg = torch.cat([t.permute(0, 2, 3, 1).reshape(2, -1) for t in logits], 1)
+        dl = torch.cat([t.view(2, -1, 4, t.shape[2], t.shape[3]).permute(0, 3, 4, 1, 2).reshape(2, -1, 4) for t in deltas], 1)
+        mgt = [torch.from_numpy(gt_boxes[i])[matched[i]] for i in range(2)]
+        ref = T.rpn_losses(anchors, lg, dl, [labels[0].to(torch.int8), labels[1].to(torch.int8)], mgt, T.TrainSpec())
+        (ref["loss_rpn_cls"] + ref["loss_rpn_loc"]).backward()
+        assert abs(float(losses[0]) - float(ref["loss_rpn_cls"])) <= 1e-2 * float(ref["loss_rpn_cls"])
+        assert abs(float(losses[1]) - float(ref["loss_rpn_loc"])) <= 1e-2 * float(ref["loss_rpn_loc"]) + 1e-6
+        p = "proposal_generator.rpn_head."
+        # fused head: rows [0,A) objectness, [A,5A) deltas
+        got = tr.tensor("g:" + p + "heads.w") / scale
+        want = np.concatenate([_ohwi32(W[p + "objectness_logits.weight"].grad), _ohwi32(W[p + "anchor_deltas.weight"].grad)], 0)
+        assert np.linalg.norm(got[:15] - want) / np.linalg.norm(want) <= 2e-2 and float(np.abs(got[15:]).max()) == 0.0
+        gb = tr.tensor("g:" + p + "heads.b") / scale
+        wb = np.concatenate([W[p + "objectness_logits.bias"].grad.numpy(), W[p + "anchor_deltas.bias"].grad.numpy()])
+        assert np.linalg.norm(gb[:15] - wb) / np.linalg.norm(wb) <= 2e-2
+        got = tr.tensor("g:" + p + "conv.w") / scale
+        want = _ohwi32(W[p + "conv.weight"].grad)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 3e-2
+        got = tr.tensor("g:" + p + "conv.b") / scale
+        assert np.linalg.norm(got - W[p + "conv.bias"].grad.numpy()) / np.linalg.norm(W[p + "conv.bias"].grad.numpy()) <= 3e-2
+        # ... and through the FPN / ResNet
+        for n, tol in [("backbone.fpn_output2", 3e-2), ("backbone.fpn_lateral4", 3e-2), ("backbone.bottom_up.res5.2.conv3", 6e-2),
+                       ("backbone.bottom_up.res4.0.shortcut", 8e-2), ("backbone.bottom_up.res3.0.conv1", 1e-1)]:
+            got = tr.tensor(f"g:{n}.w") / scale
+            want = _ohwi32(W[n + ".weight"].grad)
+            rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+            assert rel <= tol, (n, rel)
+    finally:
+        tr.close()
