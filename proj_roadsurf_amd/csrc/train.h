@@ -23,7 +23,9 @@ struct BoxLossParams {
   const float* gt_boxes;    // [n_rois][4] matched gt box (used for foreground rows)
   float* loss_out;          // [2]: loss_cls, loss_box_reg
   int n_rois, K, cs, dcs;   // dcs: row stride of dpred (0 = cs)
-  float n_valid;            // number of sampled RoIs (gt_classes >= 0): the mean's denominator
+  float n_valid;            // number of sampled RoIs (gt_classes >= 0): the mean's denominator; used when n_valid_counts is null
+  const int* n_valid_counts;   // optional device array [n_valid_n][2] (sampled foreground, background per image): n_valid = their sum
+  int n_valid_n;
   float wx, wy, ww, wh;
   float loss_scale;
 };
@@ -71,3 +73,27 @@ struct SubsampleParams {
 };
 int launch_match(const MatchParams& p, int N, hipStream_t s);
 int launch_subsample(const SubsampleParams& p, int N, hipStream_t s);
+
+// ---- RoI-head proposal sampling glue (label_and_sample_proposals)
+struct RoiSampleParams {
+  const float* prop_boxes;  // [N][prop_cap][4] RPN proposals
+  const int* prop_count;    // [N]
+  const float* gt_boxes;    // [N][gt_cap][4]
+  const int* gt_classes;    // [N][gt_cap]
+  const int* gt_count;      // [N]
+  float* cand_boxes;        // [N][cand_cap][4]: proposals then the image's gt boxes (PROPOSAL_APPEND_GT, R:193)
+  int* cand_count;          // [N]
+  int* matched;             // [N][cand_cap] (from the Matcher)
+  int* labels;              // [N][cand_cap] in: Matcher label (1 / 0 / -1) -> out: class, K = background, -1 = no candidate
+  const int* sampled;       // [N][num_samples] candidate indices (subsample), -1 padded
+  const int* sampled_count; // [N][2]
+  float* out_boxes;         // [N][out_cap][4] sampled boxes (the box head's proposal buffer)
+  int* out_count;           // [N]
+  int* out_classes;         // [N][out_cap] class, K = background, -1 = empty slot
+  float* out_gt_boxes;      // [N][out_cap][4] matched gt box (foreground rows)
+  int* out_gt_index;        // [N][out_cap] matched gt index
+  int prop_cap, gt_cap, cand_cap, num_samples, out_cap, K;
+};
+int launch_roi_candidates(const RoiSampleParams& p, int N, hipStream_t s);
+int launch_roi_classes(const RoiSampleParams& p, int N, hipStream_t s);
+int launch_roi_gather(const RoiSampleParams& p, int N, hipStream_t s);

@@ -88,6 +88,12 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
 __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   float lc = 0.f, ll = 0.f;
+  float n_valid = p.n_valid;
+  if (p.n_valid_counts) {
+    int t = 0;
+    for (int i = 0; i < p.n_valid_n * 2; ++i) t += p.n_valid_counts[i];
+    n_valid = (float)(t > 0 ? t : 1);
+  }
   if (r < p.n_rois) {
     const float* pr = p.pred + (long long)r * p.cs;
     const int dcs = p.dcs ? p.dcs : p.cs;
@@ -101,10 +107,10 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
       float sum = 0.f;
       for (int c = 0; c <= K; ++c) sum += expf(pr[c] - mx);
       const float lse = mx + logf(sum);
-      lc = (lse - pr[cls]) / p.n_valid;
+      lc = (lse - pr[cls]) / n_valid;
       for (int c = 0; c <= K; ++c) {
         const float sm = expf(pr[c] - lse);
-        g[c] = (half_t)((sm - (c == cls ? 1.f : 0.f)) / p.n_valid * p.loss_scale);
+        g[c] = (half_t)((sm - (c == cls ? 1.f : 0.f)) / n_valid * p.loss_scale);
       }
       if (cls < K) {
         const float* pb = p.proposals + (long long)r * 4;
@@ -114,8 +120,8 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
         get_deltas(s, t4, p.wx, p.wy, p.ww, p.wh, tgt);
         for (int d = 0; d < 4; ++d) {
           const float diff = pr[K + 1 + cls * 4 + d] - tgt[d];
-          ll += fabsf(diff) / p.n_valid;
-          g[K + 1 + cls * 4 + d] = (half_t)(sgnf(diff) / p.n_valid * p.loss_scale);
+          ll += fabsf(diff) / n_valid;
+          g[K + 1 + cls * 4 + d] = (half_t)(sgnf(diff) / n_valid * p.loss_scale);
         }
       }
     }
@@ -397,6 +403,61 @@ __global__ __launch_bounds__(256) void subsample2_bwd_kernel(const half_t* dc, h
   *(half8*)o = b;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ROIHeads.label_and_sample_proposals glue ([EXT d2: modeling/roi_heads/roi_heads.py]): candidates = proposals + gt boxes,
+// Matcher labels -> classes, sampled candidates -> the box head's fixed-capacity proposal buffer and its targets.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_candidates_kernel(const RoiSampleParams p) {
+  const int n = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.cand_cap) return;
+  const int np = p.prop_count[n] < p.prop_cap ? p.prop_count[n] : p.prop_cap;
+  const int ng = p.gt_count[n] < p.gt_cap ? p.gt_count[n] : p.gt_cap;
+  float b[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < np) { const float* s = p.prop_boxes + ((long long)n * p.prop_cap + i) * 4; b[0] = s[0]; b[1] = s[1]; b[2] = s[2]; b[3] = s[3]; }
+  else if (i < np + ng) { const float* s = p.gt_boxes + ((long long)n * p.gt_cap + (i - np)) * 4; b[0] = s[0]; b[1] = s[1]; b[2] = s[2]; b[3] = s[3]; }
+  float* o = p.cand_boxes + ((long long)n * p.cand_cap + i) * 4;
+  o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
+  if (i == 0) p.cand_count[n] = (np + ng) < p.cand_cap ? (np + ng) : p.cand_cap;
+}
+
+__global__ __launch_bounds__(256) void roi_classes_kernel(const RoiSampleParams p) {
+  const int n = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.cand_cap) return;
+  const long long o = (long long)n * p.cand_cap + i;
+  int cls = -1;
+  if (i < p.cand_count[n]) {
+    const int lab = p.labels[o];
+    if (p.gt_count[n] <= 0) cls = p.K;                        // no ground truth: everything is background
+    else cls = lab == 1 ? p.gt_classes[(long long)n * p.gt_cap + p.matched[o]] : (lab == 0 ? p.K : -1);
+  }
+  p.labels[o] = cls;
+}
+
+__global__ __launch_bounds__(256) void roi_gather_kernel(const RoiSampleParams p) {
+  const int n = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.out_cap) return;
+  const int total = p.sampled_count[n * 2] + p.sampled_count[n * 2 + 1];
+  const long long o = (long long)n * p.out_cap + j;
+  float b[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+  int cls = -1, gi = 0;
+  if (j < total && j < p.num_samples) {
+    const int c = p.sampled[(long long)n * p.num_samples + j];
+    const long long ci = (long long)n * p.cand_cap + c;
+    const float* s = p.cand_boxes + ci * 4;
+    b[0] = s[0]; b[1] = s[1]; b[2] = s[2]; b[3] = s[3];
+    cls = p.labels[ci];
+    gi = p.matched[ci];
+    if (p.gt_count[n] > 0) { const float* q = p.gt_boxes + ((long long)n * p.gt_cap + gi) * 4; g[0] = q[0]; g[1] = q[1]; g[2] = q[2]; g[3] = q[3]; }
+  }
+  float* ob = p.out_boxes + o * 4;
+  ob[0] = b[0]; ob[1] = b[1]; ob[2] = b[2]; ob[3] = b[3];
+  float* og = p.out_gt_boxes + o * 4;
+  og[0] = g[0]; og[1] = g[1]; og[2] = g[2]; og[3] = g[3];
+  p.out_classes[o] = cls;
+  p.out_gt_index[o] = gi;
+  if (j == 0) p.out_count[n] = total < p.out_cap ? total : p.out_cap;
+}
+
 }  // namespace
 
 int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s) {
@@ -406,7 +467,7 @@ int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s) {
   return RS_OK;
 }
 int launch_box_loss(const BoxLossParams& p, hipStream_t s) {
-  RS_CHECK(p.pred && p.dpred && p.gt_classes && p.proposals && p.gt_boxes && p.loss_out && p.n_rois > 0 && p.cs >= 5 * p.K + 1 && p.n_valid > 0, RS_ERR_ARG, "box_loss: bad arguments");
+  RS_CHECK(p.pred && p.dpred && p.gt_classes && p.proposals && p.gt_boxes && p.loss_out && p.n_rois > 0 && p.cs >= 5 * p.K + 1 && (p.n_valid > 0 || p.n_valid_counts), RS_ERR_ARG, "box_loss: bad arguments");
   hipLaunchKernelGGL(box_loss_kernel, dim3(cdiv(p.n_rois, 256)), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
@@ -460,6 +521,26 @@ int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf,
   RS_CHECK(d_coarse && d_fine && C % 8 == 0 && 2 * (Hc - 1) < Hf && 2 * (Wc - 1) < Wf, RS_ERR_ARG, "subsample2_bwd: bad arguments");
   const long long total = (long long)N * Hc * Wc * (C >> 3);
   hipLaunchKernelGGL(subsample2_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, d_coarse, d_fine, N, Hf, Wf, Hc, Wc, C);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_roi_candidates(const RoiSampleParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.prop_boxes && p.cand_boxes && p.cand_count && p.cand_cap > 0, RS_ERR_ARG, "roi_candidates: bad arguments");
+  hipLaunchKernelGGL(roi_candidates_kernel, dim3(cdiv(p.cand_cap, 256), N), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_roi_classes(const RoiSampleParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.labels && p.matched && p.gt_classes && p.cand_count, RS_ERR_ARG, "roi_classes: bad arguments");
+  hipLaunchKernelGGL(roi_classes_kernel, dim3(cdiv(p.cand_cap, 256), N), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_roi_gather(const RoiSampleParams& p, int N, hipStream_t s) {
+  RS_CHECK(p.sampled && p.sampled_count && p.out_boxes && p.out_count && p.out_classes && p.out_gt_boxes && p.out_gt_index && p.num_samples <= p.out_cap,
+           RS_ERR_ARG, "roi_gather: bad arguments");
+  hipLaunchKernelGGL(roi_gather_kernel, dim3(cdiv(p.out_cap, 256), N), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

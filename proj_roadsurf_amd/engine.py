@@ -487,6 +487,9 @@ class Trainer:
         lib.rs_trainer_apply_sgd.argtypes = [vp, C.c_float, C.c_float, C.c_float]
         lib.rs_trainer_set_targets.argtypes = [vp, vp, vp, vp, i32, i32]
         lib.rs_trainer_rpn_step.argtypes = [vp, i32, C.c_uint32, i32]
+        lib.rs_trainer_rpn_forward.argtypes = [vp, i32]
+        lib.rs_trainer_roi_step.argtypes = [vp, i32, C.c_uint32]
+        lib.rs_trainer_set_sampling.argtypes = [vp, i32, C.c_float, i32, C.c_float]
         lib.rs_trainer_sync.argtypes = [vp]
         lib.rs_trainer_tensor.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         lib.rs_trainer_tensor_count.argtypes = [vp]
@@ -567,6 +570,15 @@ class Trainer:
 
     def rpn_step(self, n: int, seed: int = 1, external_labels: bool = False) -> None:
         _check(self.lib, self.lib.rs_trainer_rpn_step(self._h, n, seed & 0xFFFFFFFF, int(external_labels)), "rs_trainer_rpn_step")
+
+    def rpn_forward(self, n: int) -> None:
+        _check(self.lib, self.lib.rs_trainer_rpn_forward(self._h, n), "rs_trainer_rpn_forward")
+
+    def roi_step(self, n: int, seed: int = 1) -> None:
+        _check(self.lib, self.lib.rs_trainer_roi_step(self._h, n, seed & 0xFFFFFFFF), "rs_trainer_roi_step")
+
+    def set_sampling(self, rpn_batch: int = 256, rpn_positive_fraction: float = 0.5, roi_batch: int = 1024, roi_positive_fraction: float = 0.25) -> None:
+        _check(self.lib, self.lib.rs_trainer_set_sampling(self._h, rpn_batch, rpn_positive_fraction, roi_batch, roi_positive_fraction), "rs_trainer_set_sampling")
 
     def write_tensor(self, name: str, data: np.ndarray) -> None:
         """Overwrite a whole trainer tensor (no halo handling)."""

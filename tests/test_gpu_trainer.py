@@ -201,3 +201,93 @@ def test_rpn_losses_and_full_backward_match_autograd(gpu_required):
             assert rel <= tol, (n, rel)
     finally:
         tr.close()
+
+
+def test_box_head_training_step_matches_autograd(gpu_required):
+    """RPN + RoI box head training step: proposals + gt -> Matcher(0.5) -> sampler on the engine, then loss_cls /
+    loss_box_reg and all four losses' gradients (box head, RPN, FPN/ResNet incl. the RoIAlign-backward path) against
+    autograd of the oracle evaluated on the engine's own sampled anchors and RoIs."""
+    from oracle import maskrcnn_oracle as O
+    from oracle import train_oracle as T
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=654)
+    scale = 128.0
+    tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=scale)
+    try:
+        tr.set_sampling(256, 0.5, 96, 0.25)
+        gt_boxes = [np.array([[20.0, 30.0, 120.0, 160.0], [150.0, 40.0, 300.0, 130.0], [60.0, 200.0, 110.0, 260.0]], np.float32),
+                    np.array([[100.0, 100.0, 260.0, 280.0], [10.0, 10.0, 60.0, 50.0]], np.float32)]
+        gt_classes = [np.array([0, 1, 0]), np.array([1, 1])]
+        tr.set_targets(gt_boxes, gt_classes)
+        tr.forward_trunk(tr.upload_tiles(tiles), 2)
+        tr.rpn_forward(2)
+        tr.roi_step(2, seed=11)
+        tr.rpn_step(2, seed=11)
+        tr.backward_trunk(2)
+        tr.sync()
+        cnt = tr.tensor("roi_sampled_count")
+        boxes, cls, gtb = tr.tensor("roi_boxes"), tr.tensor("roi_classes"), tr.tensor("roi_gt_boxes")
+        gti = tr.tensor("roi_gt_index")
+        losses = tr.tensor("losses")
+        K = 2
+        sb, sc, sg, si = [], [], [], []
+        for i in range(2):
+            nf, nb = int(cnt[i, 0]), int(cnt[i, 1])
+            k = nf + nb
+            assert k == 96 and nf <= 24 and nf >= len(gt_boxes[i])          # the gt boxes themselves are foreground candidates
+            c = cls[i, :k]
+            assert (c[:nf] < K).all() and (c[:nf] >= 0).all() and (c[nf:] == K).all() and (cls[i, k:] == -1).all()
+            # every sampled row carries the oracle Matcher's verdict for its box
+            iou = T.pairwise_iou(torch.from_numpy(gt_boxes[i]), torch.from_numpy(boxes[i, :k]))
+            m, lab = T.matcher(iou, [0.5], [0, 1], False)
+            want = np.where(lab.numpy() == 1, gt_classes[i][m.numpy()], K)
+            assert np.array_equal(c, want) and np.array_equal(gti[i, :nf], m.numpy()[:nf])
+            assert np.allclose(gtb[i, :nf], gt_boxes[i][m.numpy()[:nf]])
+            sb.append(torch.from_numpy(boxes[i, :k])); sc.append(torch.from_numpy(c.astype(np.int64)))
+            sg.append(torch.from_numpy(np.where((c < K)[:, None], gtb[i, :k], boxes[i, :k])))
+            si.append(torch.full((k,), i, dtype=torch.int64))
+        # oracle on the same samples
+        W = {k2: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k2, v in Wn.items()}
+        keys = [k2 for k2 in T.trainable_keys(W) if not k2.startswith("roi_heads.mask_head")]
+        for k2 in keys:
+            W[k2].requires_grad_(True)
+        x = torch.from_numpy(tr.tensor("net_input", engine=True)[..., :3].astype(np.float32)).permute(0, 3, 1, 2)
+        feats = O.resnet_forward(spec, W, x)
+        feats.update(O.fpn_forward(spec, W, feats))
+        logits, deltas = O.rpn_head(W, [feats[n] for n in spec.rpn_in_features])
+        lg = torch.cat([t.permute(0, 2, 3, 1).reshape(2, -1) for t in logits], 1)
+        dl = torch.cat([t.view(2, -1, 4, t.shape[2], t.shape[3]).permute(0, 3, 4, 1, 2).reshape(2, -1, 4) for t in deltas], 1)
+        anchors = torch.cat([O.grid_anchors(spec, l, hw, hw) for l, hw in enumerate((80, 40, 20, 10, 5))])
+        labels = torch.from_numpy(tr.tensor("rpn_labels").astype(np.int64))
+        matched = torch.from_numpy(tr.tensor("rpn_matched").astype(np.int64))
+        mgt = [torch.from_numpy(gt_boxes[i])[matched[i]] for i in range(2)]
+        ts = T.TrainSpec()
+        ref = T.rpn_losses(anchors, lg, dl, [labels[0].to(torch.int8), labels[1].to(torch.int8)], mgt, ts)
+        rb, rc, rg, ri = torch.cat(sb), torch.cat(sc), torch.cat(sg), torch.cat(si)
+        roi_feats = [feats[n] for n in spec.roi_in_features]
+        pooled = T.roi_pooler_diff(roi_feats, [1 / 4, 1 / 8, 1 / 16, 1 / 32], rb, ri, 7)
+        _, scores, reg = O.box_head(W, pooled)
+        ref.update(T.fast_rcnn_losses(scores, reg, rb, rc, rg, K, spec.box_reg_weights, ts))
+        sum(ref[n] for n in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg")).backward()
+        for i, n in enumerate(("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg")):
+            assert abs(float(losses[i]) - float(ref[n].detach())) <= 1.5e-2 * abs(float(ref[n].detach())) + 1e-6, (n, float(losses[i]), float(ref[n].detach()))
+
+        def rel(name, want):
+            got = tr.tensor(name) / scale
+            assert got.shape == want.shape, (name, got.shape, want.shape)
+            return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+        p = "roi_heads."
+        w_pred = np.concatenate([W[p + "box_predictor.cls_score.weight"].grad.numpy(), W[p + "box_predictor.bbox_pred.weight"].grad.numpy()], 0)
+        got = tr.tensor("g:" + p + "box_predictor.w") / scale
+        assert np.linalg.norm(got[:11] - w_pred) / np.linalg.norm(w_pred) <= 3e-2 and float(np.abs(got[11:]).max()) == 0.0
+        assert rel("g:" + p + "box_head.fc2.w", W[p + "box_head.fc2.weight"].grad.numpy()) <= 3e-2
+        g1 = W[p + "box_head.fc1.weight"].grad.reshape(1024, 256, 7, 7).permute(0, 2, 3, 1).reshape(1024, -1).numpy()
+        assert rel("g:" + p + "box_head.fc1.w", g1) <= 3e-2
+        assert rel("g:" + p + "box_head.fc1.b", W[p + "box_head.fc1.bias"].grad.numpy()) <= 3e-2
+        for n, tol in [("backbone.fpn_output2", 3e-2), ("backbone.fpn_output4", 3e-2), ("backbone.fpn_lateral3", 3e-2),
+                       ("proposal_generator.rpn_head.conv", 3e-2), ("backbone.bottom_up.res5.2.conv3", 6e-2), ("backbone.bottom_up.res3.1.conv2", 1e-1)]:
+            r = rel(f"g:{n}.w", _ohwi32(W[n + ".weight"].grad))
+            assert r <= tol, (n, r)
+    finally:
+        tr.close()
