@@ -320,6 +320,13 @@ void rs_vec_counts(const rs_vec_result* r, int64_t* n_instances, int64_t* n_poly
 int rs_vec_copy(const rs_vec_result* r, int32_t* inst_poly_count, int32_t* poly_ring_count, int32_t* ring_len, double* xy);
 void rs_vec_free(rs_vec_result* r);
 
+/* Training targets of the mask head (host code): the polygons of ONE ground-truth instance cropped to `box` and rasterised at
+ * mask_size x mask_size -- PolygonMasks.crop_and_resize ([EXT d2: structures/masks.py rasterize_polygons_within_box]; rasteriser =
+ * pycocotools' rleFrPoly restated, parity unpinned).  polys: concatenated [x0,y0,x1,y1,...] of the polygons, poly_len[i] doubles
+ * each; out: [mask_size][mask_size] 0/1. */
+int rs_rasterize_polygons_within_box(const double* polys, const int32_t* poly_len, int n_polys, const double box[4], int mask_size,
+                                     uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,4 +290,86 @@ int rs_vec_copy(const rs_vec_result* r, int32_t* inst_poly_count, int32_t* poly_
 
 void rs_vec_free(rs_vec_result* r) { delete r; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ground-truth mask targets of the mask head (training): PolygonMasks.crop_and_resize -> rasterize_polygons_within_box
+// -> pycocotools frPyObjects / merge / decode ([EXT d2: structures/masks.py]; [EXT coco: common/maskApi.c rleFrPoly]).
+// detectron2 does this on the host too.  Restated from the published algorithm (pycocotools is absent: parity unpinned);
+// oracle/train_oracle.py holds the same restatement in Python and the tests compare the two bit for bit.
+// polys: concatenated [x0,y0,x1,y1,...] of every polygon of ONE instance, poly_len[i] = number of doubles of polygon i.
+// out: [mask_size][mask_size] 0/1, row-major.
+// ---------------------------------------------------------------------------------------------------------------
+static void rle_fr_poly(const double* xy, int k, int h, int w, std::vector<uint8_t>& colmajor) {
+  const double scale = 5.0;
+  std::vector<int> x(k + 1), y(k + 1);
+  for (int j = 0; j < k; ++j) { x[j] = (int)(scale * xy[j * 2 + 0] + .5); y[j] = (int)(scale * xy[j * 2 + 1] + .5); }
+  x[k] = x[0]; y[k] = y[0];
+  std::vector<int> u, v;
+  for (int j = 0; j < k; ++j) {
+    int xs = x[j], xe = x[j + 1], ys = y[j], ye = y[j + 1];
+    const int dx = std::abs(xe - xs), dy = std::abs(ys - ye);
+    const bool flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+    if (flip) { std::swap(xs, xe); std::swap(ys, ye); }
+    const double s = (dx >= dy && dx > 0) ? (double)(ye - ys) / dx : (dy > 0 ? (double)(xe - xs) / dy : 0.0);
+    if (dx >= dy) for (int d = 0; d <= dx; ++d) { const int t = flip ? dx - d : d; u.push_back(t + xs); v.push_back((int)(ys + s * t + .5)); }
+    else for (int d = 0; d <= dy; ++d) { const int t = flip ? dy - d : d; v.push_back(t + ys); u.push_back((int)(xs + s * t + .5)); }
+  }
+  std::vector<long long> pts;
+  for (size_t j = 1; j < u.size(); ++j) if (u[j] != u[j - 1]) {
+    double xd = (double)(u[j] < u[j - 1] ? u[j] : u[j] - 1);
+    xd = (xd + .5) / scale - .5;
+    if (std::floor(xd) != xd || xd < 0 || xd > w - 1) continue;
+    double yd = (double)(v[j] < v[j - 1] ? v[j] : v[j - 1]);
+    yd = (yd + .5) / scale - .5;
+    if (yd < 0) yd = 0; else if (yd > h) yd = h;
+    yd = std::ceil(yd);
+    pts.push_back((long long)((int)xd) * h + (int)yd);
+  }
+  pts.push_back((long long)h * w);
+  std::sort(pts.begin(), pts.end());
+  std::vector<long long> a(pts.size()), b;
+  a[0] = pts[0];
+  for (size_t i = 1; i < pts.size(); ++i) a[i] = pts[i] - pts[i - 1];
+  size_t j = 0;
+  b.push_back(a[j++]);
+  while (j < a.size()) {
+    if (a[j] > 0) b.push_back(a[j++]);
+    else { ++j; if (j < a.size()) b.back() += a[j++]; }
+  }
+  colmajor.assign((size_t)h * w, 0);
+  long long pos = 0;
+  int val = 0;
+  for (long long run : b) {
+    if (val) for (long long q = pos; q < pos + run && q < (long long)h * w; ++q) colmajor[(size_t)q] = 1;
+    pos += run;
+    val ^= 1;
+  }
+}
+
+int rs_rasterize_polygons_within_box(const double* polys, const int32_t* poly_len, int n_polys, const double box[4], int mask_size, uint8_t* out) {
+  if (!polys || !poly_len || !box || !out || n_polys < 0 || mask_size <= 0) return RS_ERR_ARG;
+  const int S = mask_size;
+  memset(out, 0, (size_t)S * S);
+  const double w = box[2] - box[0], h = box[3] - box[1];
+  const double ratio_h = S / std::max(h, 0.1), ratio_w = S / std::max(w, 0.1);
+  std::vector<double> p;
+  std::vector<uint8_t> cm;
+  size_t off = 0;
+  for (int i = 0; i < n_polys; ++i) {
+    const int len = poly_len[i];
+    if (len < 2 || (len & 1)) return RS_ERR_ARG;
+    p.assign(polys + off, polys + off + len);
+    off += (size_t)len;
+    for (int q = 0; q < len; q += 2) {
+      p[q] = p[q] - box[0];
+      p[q + 1] = p[q + 1] - box[1];
+      if (ratio_h == ratio_w) { p[q] *= ratio_h; p[q + 1] *= ratio_h; }
+      else { p[q] *= ratio_w; p[q + 1] *= ratio_h; }
+    }
+    rle_fr_poly(p.data(), len / 2, S, S, cm);
+    for (int xx = 0; xx < S; ++xx)
+      for (int yy = 0; yy < S; ++yy) out[(size_t)yy * S + xx] |= cm[(size_t)xx * S + yy];     // merge = union; RLE is column-major
+  }
+  return RS_OK;
+}
+
 }  // extern "C"

@@ -109,6 +109,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_vec_copy.argtypes = [vp, i32p, i32p, i32p, f64p]
     lib.rs_vec_free.argtypes = [vp]
     lib.rs_vec_free.restype = None
+    lib.rs_rasterize_polygons_within_box.argtypes = [f64p, i32p, i32, f64p, i32, u8p]
     lib.rs_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
     lib.rs_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
     if path is None:

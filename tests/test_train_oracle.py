@@ -142,3 +142,25 @@ def test_train_forward_small_losses_and_gradients():
     for s in out["_samples"]:
         k = s["classes"]
         assert int((k < 2).sum()) <= 8 and int((k < 2).sum()) >= 1 and k.numel() <= 32
+
+
+def test_native_polygon_rasteriser_equals_oracle_restatement():
+    """rs_rasterize_polygons_within_box (C++, the product's mask-target path) == oracle/train_oracle.py's Python restatement of
+    pycocotools' rleFrPoly + detectron2's rasterize_polygons_within_box, bit for bit, on random polygons and boxes."""
+    import os
+    from proj_roadsurf_amd.engine import LIB_PATH
+    if not os.path.exists(LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    from proj_roadsurf_amd.train_targets import rasterize_polygons_within_box as native
+    rng = np.random.default_rng(7)
+    for t in range(200):
+        k, n = int(rng.integers(3, 9)), int(rng.integers(1, 4))
+        polys = [(rng.random(2 * k) * 120).astype(np.float64) for _ in range(n)]
+        x0, y0 = rng.random(2) * 60
+        box = np.array([x0, y0, x0 + rng.random() * 70 + 2, y0 + rng.random() * 70 + 2])
+        S = 28 if t % 3 else 14
+        assert np.array_equal(T.rasterize_polygons_within_box(polys, box, S), native(polys, box, S)), t
+    sq = [np.array([10.0, 20, 50, 20, 50, 60, 10, 60])]
+    assert native(sq, np.array([10.0, 20.0, 50.0, 60.0]), 28).all()
+    assert not native(sq, np.array([100.0, 100.0, 120.0, 130.0]), 28).any()
