@@ -276,6 +276,13 @@ int rs_trainer_rpn_step(rs_trainer* t, int n, uint32_t seed, int external_labels
  * full step: forward_trunk, rpn_forward, roi_step, rpn_step, backward_trunk, apply_sgd. */
 int rs_trainer_rpn_forward(rs_trainer* t, int n);
 int rs_trainer_roi_step(rs_trainer* t, int n, uint32_t seed);
+/* Mask head of the training step (after rs_trainer_roi_step, before rs_trainer_rpn_step): forward on the sampled foreground RoIs
+ * -- entry e runs over images, then over each image's sampled foreground in order ("mask_slots", "mask_total") --; then, with the
+ * host-rasterised gt masks targets[n_entries][28*28] (rs_rasterize_polygons_within_box on "roi_boxes" / "roi_gt_index"),
+ * mask_rcnn_loss -> "losses"[4] and the backward of predictor / deconv / 4 convs / RoIAlign into "d32:p2".."d32:p5".  detectron2
+ * rasterises the polygons on the host at the same point ([EXT d2: structures/masks.py PolygonMasks.crop_and_resize]). */
+int rs_trainer_mask_forward(rs_trainer* t, int n);
+int rs_trainer_mask_backward(rs_trainer* t, int n, const uint8_t* targets_host, int n_entries);
 /* Sampler sizes (defaults = the reference YAML: 256 @ 0.5 anchors, 1024 @ 0.25 RoIs per image). */
 int rs_trainer_set_sampling(rs_trainer* t, int rpn_batch, float rpn_positive_fraction, int roi_batch, float roi_positive_fraction);
 int rs_trainer_apply_sgd(rs_trainer* t, float lr, float momentum, float weight_decay);

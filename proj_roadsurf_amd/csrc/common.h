@@ -102,6 +102,8 @@ struct WgradParams {
   int dy_Hp, dy_Wp, dy_Cs, dy_pad;
   int in_Hp, in_Wp, in_Cs, in_off;   // as ConvParams
   int stride, KH, KW, Cin, Cout, Kpad;
+  const int* m_count;   // optional device counter: rows = min(M, *m_count * m_mul) (RoI heads: valid entries only)
+  int m_mul;
   int splits;           // pixel-range splits (gridDim.z); wgrad_splits() proposes one
   int accumulate;       // 1: grad += result
 };

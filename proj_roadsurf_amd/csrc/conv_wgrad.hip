@@ -46,6 +46,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
   const int wr = wave >> 1, wc = wave & 1;      // wave tile: channels wr*64.., K columns wc*64..
 
   const int co0 = blockIdx.x * BM;
+  int M = p.M;
+  if (p.m_count) {
+    const long long mc = (long long)(*p.m_count) * p.m_mul;
+    if (mc < M) M = (int)mc;
+  }
   // K columns of this workgroup: two 64-wide halves, each one (tap, channel slice)
   const int slices = p.Cin >> 6;                // 64-channel slices per tap
   int x_off[2], k_col[2];
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
   const bool second_valid = (blockIdx.y * 2 + 1) < p.KH * p.KW * slices;
 
   // pixel range of this split (multiples of BK)
-  const int steps_total = (p.M + BK - 1) / BK;
+  const int steps_total = (M + BK - 1) / BK;
   const int per = (steps_total + gridDim.z - 1) / gridDim.z;
   const int s0 = blockIdx.z * per;
   int s1 = s0 + per;
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
       const int m = step * BK + r;
       const int src_chunk = (lchk ^ row_key(r)) * 8;
       const half_t *gy, *gx;
-      if (m < p.M) {
+      if (m < M) {
         const int x = m % p.Wo;
         const int t = m / p.Wo;
         const int y = t % p.Ho;
@@ -96,8 +101,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
       const half_t* gy1 = (co0 + 64 + src_chunk < p.dy_Cs) ? gy + 64 : p.zeros + src_chunk;
       glds16(gy0, dst);
       glds16(gy1, dst + SUB);
-      glds16(gx + (m < p.M ? x_off[0] : 0), dst + 2 * SUB);
-      glds16(gx + (m < p.M ? x_off[1] : 0), dst + 3 * SUB);
+      glds16(gx + (m < M ? x_off[0] : 0), dst + 2 * SUB);
+      glds16(gx + (m < M ? x_off[1] : 0), dst + 3 * SUB);
     }
   };
 

@@ -35,6 +35,7 @@ struct MaskLossParams {
   const uint8_t* targets;   // [n_masks][S*S] 0/1
   const int* gt_classes;    // [n_masks]
   float* loss_out;          // [1]
+  const int* n_masks_ptr;   // optional device count (<= n_masks = capacity): the mean runs over it
   int n_masks, S, cs, dcs;  // dcs: row stride of dlogits (0 = cs)
   float loss_scale;
 };
@@ -45,7 +46,8 @@ int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, fl
                         float inv_loss_scale, int first_step, hipStream_t s);
 int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
                         int kc, int KpadT, hipStream_t s);
-int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s);
+int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s, const int* m_count = nullptr,
+                     int m_mul = 0);
 int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s);
 
 // ---- label assignment (Matcher + subsample_labels) ----
@@ -97,3 +99,14 @@ struct RoiSampleParams {
 int launch_roi_candidates(const RoiSampleParams& p, int N, hipStream_t s);
 int launch_roi_classes(const RoiSampleParams& p, int N, hipStream_t s);
 int launch_roi_gather(const RoiSampleParams& p, int N, hipStream_t s);
+
+// foreground RoIs of the sampled set -> compact mask-head entry list
+struct MaskEntriesParams {
+  const int* sampled_count; // [N][2]
+  const int* roi_classes;   // [N][slots_per_image]
+  int* slots;               // [cap] out: slot = n * slots_per_image + j, image-major, j ascending
+  int* classes;             // [cap] out
+  int* total;               // [1] out
+  int N, slots_per_image, per_image_cap, cap;
+};
+int launch_mask_entries(const MaskEntriesParams& p, hipStream_t s);

@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const MaskLossParams p) 
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   float l = 0.f;
   const long long per = (long long)p.S * p.S;
-  if (i < (long long)p.n_masks * per) {
+  int n_masks = p.n_masks;
+  if (p.n_masks_ptr) { const int c = *p.n_masks_ptr; n_masks = c < n_masks ? c : n_masks; }
+  if (i < (long long)n_masks * per) {
     const int m = (int)(i / per);
     const int cls = p.gt_classes[m];
     const int dcs = p.dcs ? p.dcs : p.cs;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const MaskLossParams p) 
     for (int c = 0; c < dcs; ++c) g[c] = (half_t)0.f;
     if (cls >= 0 && cls < p.cs) {
       const float x = p.logits[i * p.cs + cls], t = (float)p.targets[i];
-      const float norm = (float)p.n_masks * (float)per;
+      const float norm = (float)n_masks * (float)per;
       l = bce_with_logits(x, t) / norm;
       g[cls] = (half_t)((sigmoidf(x) - t) / norm * p.loss_scale);
     }
@@ -362,8 +364,10 @@ __global__ __launch_bounds__(1024) void subsample_kernel(const SubsampleParams p
 
 // bias gradient: grad[c] = sum over rows of dy[row][c] (halo rows are zero, so the whole buffer can be summed).
 // One workgroup per 8 channels, fixed summation order (bitwise reproducible).
-__global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate) {
+__global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate,
+                                                       const int* m_count, int m_mul) {
   __shared__ float red[256][8];
+  if (m_count) { const long long mc = (long long)(*m_count) * m_mul; if (mc < rows) rows = mc; }
   const int c0 = blockIdx.x * 8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (long long r = threadIdx.x; r < rows; r += 256) {
@@ -458,6 +462,33 @@ __global__ __launch_bounds__(256) void roi_gather_kernel(const RoiSampleParams p
   if (j == 0) p.out_count[n] = total < p.out_cap ? total : p.out_cap;
 }
 
+// select_foreground_proposals ([EXT d2: modeling/roi_heads/roi_heads.py]): the sampled set is foreground-first, so image n's
+// mask-head entries are its slots j < (number of sampled foreground)
+__global__ __launch_bounds__(256) void mask_entries_kernel(const MaskEntriesParams p) {
+  __shared__ int s_off[65];
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int n = 0; n < p.N && n < 64; ++n) {
+      s_off[n] = acc;
+      int nf = p.sampled_count[n * 2];
+      if (nf > p.per_image_cap) nf = p.per_image_cap;
+      if (acc + nf > p.cap) nf = p.cap - acc;
+      acc += nf;
+    }
+    s_off[p.N < 64 ? p.N : 64] = acc;
+    *p.total = acc;
+  }
+  __syncthreads();
+  for (int n = 0; n < p.N && n < 64; ++n) {
+    const int nf = s_off[n + 1] - s_off[n];
+    for (int j = threadIdx.x; j < nf; j += 256) {
+      const int slot = n * p.slots_per_image + j;
+      p.slots[s_off[n] + j] = slot;
+      p.classes[s_off[n] + j] = p.roi_classes[slot];
+    }
+  }
+}
+
 }  // namespace
 
 int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s) {
@@ -511,9 +542,10 @@ int launch_subsample(const SubsampleParams& p, int N, hipStream_t s) {
   return RS_OK;
 }
 
-int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s) {
+int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s, const int* m_count,
+                     int m_mul) {
   RS_CHECK(dy && grad && rows > 0 && C % 8 == 0 && cout > 0 && cout <= C, RS_ERR_ARG, "bias_grad: bad arguments");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(cout, 8)), dim3(256), 0, s, dy, rows, C, cout, grad, accumulate);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(cout, 8)), dim3(256), 0, s, dy, rows, C, cout, grad, accumulate, m_count, m_mul);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
@@ -541,6 +573,13 @@ int launch_roi_gather(const RoiSampleParams& p, int N, hipStream_t s) {
   RS_CHECK(p.sampled && p.sampled_count && p.out_boxes && p.out_count && p.out_classes && p.out_gt_boxes && p.out_gt_index && p.num_samples <= p.out_cap,
            RS_ERR_ARG, "roi_gather: bad arguments");
   hipLaunchKernelGGL(roi_gather_kernel, dim3(cdiv(p.out_cap, 256), N), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+int launch_mask_entries(const MaskEntriesParams& p, hipStream_t s) {
+  RS_CHECK(p.sampled_count && p.roi_classes && p.slots && p.classes && p.total && p.N >= 1 && p.N <= 64, RS_ERR_ARG, "mask_entries: bad arguments");
+  hipLaunchKernelGGL(mask_entries_kernel, dim3(1), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

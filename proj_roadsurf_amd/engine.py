@@ -491,6 +491,8 @@ class Trainer:
         lib.rs_trainer_rpn_forward.argtypes = [vp, i32]
         lib.rs_trainer_roi_step.argtypes = [vp, i32, C.c_uint32]
         lib.rs_trainer_set_sampling.argtypes = [vp, i32, C.c_float, i32, C.c_float]
+        lib.rs_trainer_mask_forward.argtypes = [vp, i32]
+        lib.rs_trainer_mask_backward.argtypes = [vp, i32, vp, i32]
         lib.rs_trainer_sync.argtypes = [vp]
         lib.rs_trainer_tensor.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         lib.rs_trainer_tensor_count.argtypes = [vp]
@@ -522,6 +524,7 @@ class Trainer:
         """Copy a trainer tensor ("d:<act>", "g:<layer>.w", "m:<layer>.w") or, with ``engine=True``, a forward tensor to the host."""
         ptr, dt, shape, halo = self._tensor_ptr(name, engine)
         a = np.empty(shape, dt)
+        self.sync()                     # the trainer's stream is non-blocking: a plain memcpy would not wait for it
         _check(self.lib, self.lib.rs_memcpy_d2h(a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), a.nbytes), "rs_memcpy_d2h")
         if strip_halo and halo:
             a = a[:, halo:-halo, halo:-halo]
@@ -577,6 +580,29 @@ class Trainer:
 
     def roi_step(self, n: int, seed: int = 1) -> None:
         _check(self.lib, self.lib.rs_trainer_roi_step(self._h, n, seed & 0xFFFFFFFF), "rs_trainer_roi_step")
+
+    def mask_forward(self, n: int) -> None:
+        _check(self.lib, self.lib.rs_trainer_mask_forward(self._h, n), "rs_trainer_mask_forward")
+
+    def mask_backward(self, n: int, targets: np.ndarray) -> None:
+        """targets: (n_entries, 28, 28) bool/uint8 gt masks of the mask-head entries, in entry order."""
+        t = np.ascontiguousarray(targets.astype(np.uint8))
+        _check(self.lib, self.lib.rs_trainer_mask_backward(self._h, n, t.ctypes.data_as(C.c_void_p) if t.size else None, int(t.shape[0])),
+               "rs_trainer_mask_backward")
+
+    def mask_entries(self, gt_polygons: Sequence[Sequence[Sequence[np.ndarray]]], n: int) -> Tuple[np.ndarray, List[Tuple[int, int]]]:
+        """Host part of the mask branch: gt masks of the sampled foreground RoIs (``PolygonMasks.crop_and_resize``).
+        gt_polygons[image][gt index] = list of polygons ([x0,y0,...], network-input pixels).  Returns (targets, [(image, slot)])."""
+        from .train_targets import rasterize_polygons_within_box
+        cnt = self.tensor("roi_sampled_count")
+        boxes, gti = self.tensor("roi_boxes"), self.tensor("roi_gt_index")
+        side = 2 * self.spec.mask_pooler_resolution
+        out, where = [], []
+        for i in range(n):
+            for j in range(min(int(cnt[i, 0]), 256)):
+                out.append(rasterize_polygons_within_box(gt_polygons[i][int(gti[i, j])], boxes[i, j], side))
+                where.append((i, j))
+        return (np.stack(out) if out else np.zeros((0, side, side), bool)), where
 
     def set_sampling(self, rpn_batch: int = 256, rpn_positive_fraction: float = 0.5, roi_batch: int = 1024, roi_positive_fraction: float = 0.25) -> None:
         _check(self.lib, self.lib.rs_trainer_set_sampling(self._h, rpn_batch, rpn_positive_fraction, roi_batch, roi_positive_fraction), "rs_trainer_set_sampling")

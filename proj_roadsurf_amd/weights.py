@@ -323,6 +323,11 @@ def train_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], freeze_at: int = 2
             T[name + ".m32"], T[name + ".w"], T[name + ".b"] = wp, wp.astype(np.float16), bp
             continue
         T[name + ".m32"] = raw[name + ".w"].astype(np.float32)
+        if name == "roi_heads.mask_head.deconv":
+            # trainable layout [Cin][(dy,dx,co)] = transpose of the forward GEMM weight: the weight-gradient kernel produces this
+            # orientation directly and the fold writes the forward operand as its transposed copy
+            T[name + ".m32T"] = np.ascontiguousarray(T[name + ".m32"].T)
+            T[name + ".b256"] = W["roi_heads.mask_head.deconv.bias"].astype(np.float32)
         if has_norm.get(name, False):
             T[name + ".s"] = bn_scale(W, name, spec.bn_eps)
     return T

@@ -291,3 +291,112 @@ def test_box_head_training_step_matches_autograd(gpu_required):
             assert r <= tol, (n, r)
     finally:
         tr.close()
+
+
+def test_full_training_step_five_losses_match_autograd(gpu_required):
+    """The whole GeneralizedRCNN training forward + backward on the engine: trunk, RPN, proposals + gt -> sampled RoIs, box
+    head, mask head on the sampled foreground with host-rasterised polygon targets -- all five losses and the gradients of
+    every branch against autograd of the oracle on the engine's own samples, then one SGD step."""
+    from oracle import maskrcnn_oracle as O
+    from oracle import train_oracle as T
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=777)
+    scale = 128.0
+    tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=scale)
+    try:
+        tr.set_sampling(256, 0.5, 64, 0.25)
+        gt_boxes = [np.array([[20.0, 30.0, 120.0, 160.0], [150.0, 40.0, 300.0, 130.0]], np.float32), np.array([[100.0, 100.0, 260.0, 280.0]], np.float32)]
+        gt_classes = [np.array([0, 1]), np.array([1])]
+
+        def blob(b, k):            # a k-gon inscribed in the box (not the box itself: partial masks inside jittered proposals)
+            cx, cy, rx, ry = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2, (b[2] - b[0]) / 2, (b[3] - b[1]) / 2
+            th = np.linspace(0, 2 * np.pi, k, endpoint=False)
+            return [np.stack([cx + rx * np.cos(th), cy + ry * np.sin(th)], 1).reshape(-1)]
+        polys = [[blob(b, 7 + i) for i, b in enumerate(bs)] for bs in gt_boxes]
+        tr.set_targets(gt_boxes, gt_classes)
+        tr.forward_trunk(tr.upload_tiles(tiles), 2)
+        tr.rpn_forward(2)
+        tr.roi_step(2, seed=5)
+        tr.mask_forward(2)
+        targets, where = tr.mask_entries(polys, 2)
+        tr.mask_backward(2, targets)
+        tr.rpn_step(2, seed=5)
+        tr.backward_trunk(2)
+        tr.sync()
+        losses = tr.tensor("losses")
+        cnt = tr.tensor("roi_sampled_count")
+        assert int(tr.tensor("mask_total")[0]) == len(where) == int(cnt[:, 0].sum()) and len(where) >= 3
+        boxes, cls, gtb, gti = tr.tensor("roi_boxes"), tr.tensor("roi_classes"), tr.tensor("roi_gt_boxes"), tr.tensor("roi_gt_index")
+        K = 2
+        W = {k2: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k2, v in Wn.items()}
+        for k2 in T.trainable_keys(W):
+            W[k2].requires_grad_(True)
+        x = torch.from_numpy(tr.tensor("net_input", engine=True)[..., :3].astype(np.float32)).permute(0, 3, 1, 2)
+        feats = O.resnet_forward(spec, W, x)
+        feats.update(O.fpn_forward(spec, W, feats))
+        logits, deltas = O.rpn_head(W, [feats[n] for n in spec.rpn_in_features])
+        lg = torch.cat([t.permute(0, 2, 3, 1).reshape(2, -1) for t in logits], 1)
+        dl = torch.cat([t.view(2, -1, 4, t.shape[2], t.shape[3]).permute(0, 3, 4, 1, 2).reshape(2, -1, 4) for t in deltas], 1)
+        anchors = torch.cat([O.grid_anchors(spec, l, hw, hw) for l, hw in enumerate((80, 40, 20, 10, 5))])
+        labels = torch.from_numpy(tr.tensor("rpn_labels").astype(np.int64))
+        matched = torch.from_numpy(tr.tensor("rpn_matched").astype(np.int64))
+        ts = T.TrainSpec()
+        ref = T.rpn_losses(anchors, lg, dl, [labels[0].to(torch.int8), labels[1].to(torch.int8)],
+                           [torch.from_numpy(gt_boxes[i])[matched[i]] for i in range(2)], ts)
+        rb, rc, rg, ri = [], [], [], []
+        for i in range(2):
+            k = int(cnt[i].sum())
+            c = cls[i, :k]
+            rb.append(torch.from_numpy(boxes[i, :k])); rc.append(torch.from_numpy(c.astype(np.int64)))
+            rg.append(torch.from_numpy(np.where((c < K)[:, None], gtb[i, :k], boxes[i, :k]))); ri.append(torch.full((k,), i, dtype=torch.int64))
+        rb, rc, rg, ri = torch.cat(rb), torch.cat(rc), torch.cat(rg), torch.cat(ri)
+        roi_feats = [feats[n] for n in spec.roi_in_features]
+        scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+        _, scores, reg = O.box_head(W, T.roi_pooler_diff(roi_feats, scales, rb, ri, 7))
+        ref.update(T.fast_rcnn_losses(scores, reg, rb, rc, rg, K, spec.box_reg_weights, ts))
+        mb = torch.from_numpy(np.stack([boxes[i, j] for i, j in where]))
+        mi = torch.tensor([i for i, _ in where])
+        mc = torch.tensor([int(cls[i, j]) for i, j in where])
+        mlog, _ = O.mask_head(spec, W, T.roi_pooler_diff(roi_feats, scales, mb, mi, 14), mc)
+        gm = torch.from_numpy(np.stack([T.rasterize_polygons_within_box(polys[i][int(gti[i, j])], boxes[i, j], 28) for i, j in where]))
+        assert np.array_equal(gm.numpy(), targets) and 0.05 < float(gm.float().mean()) < 0.95
+        ref["loss_mask"] = T.mask_rcnn_loss(mlog, mc, gm)
+        names = ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask")
+        sum(ref[n] for n in names).backward()
+        for i, n in enumerate(names):
+            r = float(ref[n].detach())
+            assert abs(float(losses[i]) - r) <= 1.5e-2 * abs(r) + 1e-6, (n, float(losses[i]), r)
+
+        def rel(name, want):
+            got = tr.tensor(name) / scale
+            assert got.shape == want.shape, (name, got.shape, want.shape)
+            return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+        p = "roi_heads.mask_head."
+        worst = {}
+        for i in range(1, 5):
+            worst[f"fcn{i}.w"] = rel(f"g:{p}mask_fcn{i}.w", _ohwi32(W[f"{p}mask_fcn{i}.weight"].grad))
+            worst[f"fcn{i}.b"] = rel(f"g:{p}mask_fcn{i}.b", W[f"{p}mask_fcn{i}.bias"].grad.numpy())
+        worst["deconv.w"] = rel(f"g:{p}deconv.w", W[p + "deconv.weight"].grad.permute(0, 2, 3, 1).reshape(256, 1024).numpy())
+        worst["deconv.b"] = rel(f"g:{p}deconv.b", W[p + "deconv.bias"].grad.numpy())
+        gp = tr.tensor(f"g:{p}predictor16.w") / scale
+        wp = W[p + "predictor.weight"].grad[:, :, 0, 0].numpy()
+        worst["predictor.w"] = float(np.linalg.norm(gp[:K] - wp) / np.linalg.norm(wp))
+        assert float(np.abs(gp[K:]).max()) == 0.0
+        gb = tr.tensor(f"g:{p}predictor16.b") / scale
+        worst["predictor.b"] = float(np.linalg.norm(gb[:K] - W[p + "predictor.bias"].grad.numpy()) / np.linalg.norm(W[p + "predictor.bias"].grad.numpy()))
+        for n in ("roi_heads.box_head.fc2", "backbone.fpn_output2", "backbone.fpn_output3", "proposal_generator.rpn_head.conv"):
+            worst[n] = rel(f"g:{n}.w", _ohwi32(W[n + ".weight"].grad) if W[n + ".weight"].grad.dim() == 4 else W[n + ".weight"].grad.numpy())
+        worst["res4.2.conv2"] = rel("g:backbone.bottom_up.res4.2.conv2.w", _ohwi32(W["backbone.bottom_up.res4.2.conv2.weight"].grad))
+        print({k2: round(v, 4) for k2, v in worst.items()})
+        assert max(v for k2, v in worst.items() if not k2.startswith("res")) <= 4e-2, worst
+        assert worst["res4.2.conv2"] <= 8e-2
+        # one optimiser step with the YAML's hyper-parameters at iteration 0 (warm-up: lr = 0.01 * 0.001)
+        m0 = tr.tensor(f"m:{p}deconv.w").copy()
+        g0 = tr.tensor(f"g:{p}deconv.w") / scale
+        tr.apply_sgd(T.lr_at(ts, 0), ts.momentum, ts.weight_decay)
+        tr.sync()
+        m1 = tr.tensor(f"m:{p}deconv.w")
+        assert np.allclose(m1, m0 - np.float32(T.lr_at(ts, 0)) * (g0 + np.float32(ts.weight_decay) * m0), rtol=1e-5, atol=1e-9)
+    finally:
+        tr.close()
