@@ -290,6 +290,11 @@ int rs_trainer_sync(rs_trainer* t);
 int rs_trainer_tensor(rs_trainer* t, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo);
 int rs_trainer_tensor_count(rs_trainer* t);
 int rs_trainer_tensor_name(rs_trainer* t, int i, char* name_out);
+/* Data parallel: every rank all-reduces (SUM) the flat gradient buffer (rs_trainer_grad_buffer, rs_trainer_param_count floats,
+ * device memory) and sets the divisor to the world size, which rs_trainer_apply_sgd applies together with the loss scale
+ * (DistributedDataParallel's gradient averaging: [EXT d2: engine/defaults.py create_ddp_model]). */
+int rs_trainer_set_grad_divisor(rs_trainer* t, float divisor);
+void* rs_trainer_master_buffer(rs_trainer* t);
 int64_t rs_trainer_param_count(rs_trainer* t);
 void* rs_trainer_grad_buffer(rs_trainer* t);
 

@@ -491,6 +491,9 @@ class Trainer:
         lib.rs_trainer_rpn_forward.argtypes = [vp, i32]
         lib.rs_trainer_roi_step.argtypes = [vp, i32, C.c_uint32]
         lib.rs_trainer_set_sampling.argtypes = [vp, i32, C.c_float, i32, C.c_float]
+        lib.rs_trainer_set_grad_divisor.argtypes = [vp, C.c_float]
+        lib.rs_trainer_grad_buffer.argtypes = [vp]
+        lib.rs_trainer_grad_buffer.restype = vp
         lib.rs_trainer_mask_forward.argtypes = [vp, i32]
         lib.rs_trainer_mask_backward.argtypes = [vp, i32, vp, i32]
         lib.rs_trainer_sync.argtypes = [vp]
@@ -603,6 +606,57 @@ class Trainer:
                 out.append(rasterize_polygons_within_box(gt_polygons[i][int(gti[i, j])], boxes[i, j], side))
                 where.append((i, j))
         return (np.stack(out) if out else np.zeros((0, side, side), bool)), where
+
+    # ------------------------------------------------------------------ a whole step
+    def train_step(self, tiles: np.ndarray, gt_boxes: Sequence[np.ndarray], gt_classes: Sequence[np.ndarray],
+                   gt_polygons: Optional[Sequence[Sequence[Sequence[np.ndarray]]]], seed: int) -> Dict[str, float]:
+        """Forward + losses + backward of one batch (``SimpleTrainer.run_step`` up to ``losses.backward()``): gradients end
+        up in the flat gradient buffer; returns the five losses.  ``gt_*`` in NETWORK-INPUT pixels."""
+        n = int(tiles.shape[0])
+        self.set_targets(gt_boxes, gt_classes)
+        self.forward_trunk(self.upload_tiles(tiles), n)
+        self.rpn_forward(n)
+        self.roi_step(n, seed)
+        if self.spec.mask_on:
+            self.mask_forward(n)
+            targets, _ = self.mask_entries(gt_polygons, n)
+            self.mask_backward(n, targets)
+        self.rpn_step(n, seed)
+        self.backward_trunk(n)
+        l = self.tensor("losses")
+        names = ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask")
+        return {k: float(l[i]) for i, k in enumerate(names)}
+
+    def allreduce_gradients(self) -> None:
+        """Sum the flat gradient buffer over the ranks of the default process group (RCCL: the buffer is handed to
+        torch.distributed in place through ``__cuda_array_interface__``; gloo: through a host copy) and set the divisor the SGD
+        step applies (DDP's averaging)."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        n = self.param_count
+        ptr = int(self.lib.rs_trainer_grad_buffer(self._h))
+        self.sync()
+        if dist.get_backend() == "nccl":
+            class _Buf:                      # zero-copy view of the device buffer
+                __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+            t = torch.as_tensor(_Buf(), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        else:
+            host = np.empty(n, np.float32)
+            _check(self.lib, self.lib.rs_memcpy_d2h(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), host.nbytes), "rs_memcpy_d2h")
+            t = torch.from_numpy(host)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(ptr), host.ctypes.data_as(C.c_void_p), host.nbytes), "rs_memcpy_h2d")
+        _check(self.lib, self.lib.rs_trainer_set_grad_divisor(self._h, float(dist.get_world_size())), "rs_trainer_set_grad_divisor")
+
+    def export_weights(self, base: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+        """Current weights under detectron2's checkpoint key names: ``base`` (the weights the trainer was created from) with
+        every trainable tensor replaced by its fp32 master copy, converted back from the engine's GEMM layouts."""
+        from .weights import master_to_d2
+        return master_to_d2(self.spec, base, lambda name: self.tensor(name))
 
     def set_sampling(self, rpn_batch: int = 256, rpn_positive_fraction: float = 0.5, roi_batch: int = 1024, roi_positive_fraction: float = 0.25) -> None:
         _check(self.lib, self.lib.rs_trainer_set_sampling(self._h, rpn_batch, rpn_positive_fraction, roi_batch, roi_positive_fraction), "rs_trainer_set_sampling")

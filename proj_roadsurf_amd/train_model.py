@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Drop-in for the STDL object-detector's ``train_model.py`` call (R:README.md:77): same argv (one YAML path), same YAML
+section and keys (R:config/config_obj_detec.yaml:62-72), same artefacts -- ``<log_subfolder>/model_<iter>.pth`` and
+``model_final.pth`` in detectron2's checkpoint layout ({"model": state_dict, "iteration": n}; directly consumable by
+``make_detections.py`` via ``model_weights.pth_file``), ``metrics.json`` (one JSON object per logged iteration) -- with the
+training step (GeneralizedRCNN forward, five losses, backward, SGD) running on the MI355X training engine
+(``engine.Trainer`` -> ``rs_trainer_*``) instead of detectron2's ``DefaultTrainer``.
+
+    python -m proj_roadsurf_amd.train_model <config.yaml> [--synthetic-weights] [--max-iter N]
+    python -m torch.distributed.run --nproc-per-node 8 -m proj_roadsurf_amd.train_model <config.yaml>      # data parallel
+
+What follows the reference / detectron2 0.6 and where it is pinned:
+  * data: COCO JSON (polygons), FILTER_EMPTY_ANNOTATIONS (R:4), crowd annotations dropped, TrainingSampler (infinite seeded
+    shuffle, rank-strided), ResizeShortestEdge + RandomFlip(horizontal, 0.5)  [EXT d2: data/{build,dataset_mapper,samplers}.py];
+  * solver: SGD momentum 0.9, weight decay 1e-4, WarmupMultiStepLR (R:268-305), IMS_PER_BATCH 8 split over the ranks,
+    checkpoint every CHECKPOINT_PERIOD  [EXT d2: solver/build.py, engine/defaults.py];
+  * data parallel: one process per GPU, gradients all-reduced over RCCL/xGMI in one flat 175 MB fp32 buffer and averaged
+    (DistributedDataParallel semantics).
+Documented deviations: the network input size is fixed per run (MIN_SIZE_TRAIN's multi-scale "choice", R:31-38, is
+not sampled: the engine is built for one input geometry), RPN proposals use the engine's 1000-per-level capacity before NMS
+(R:250 asks 2000), fp16 activations/weights with fp32 master weights and static loss scaling instead of fp32 everywhere, the
+model-zoo URL of ``model_weights.model_zoo_checkpoint_url`` cannot be fetched offline (use ``model_weights.pth_file`` or
+``--synthetic-weights``), and the periodic COCO evaluation / validation-loss hooks are not built.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+import time
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import yaml
+
+from .spec import load_d2_yaml, resize_shortest_edge_shape
+from .weights import infer_num_classes, load_checkpoint, synthetic_weights
+
+log = logging.getLogger("train_model")
+SECTION = "train_model.py"
+
+
+def load_solver(d2_yaml: str) -> Dict[str, Any]:
+    """SOLVER / sampler keys of the detectron2 YAML with detectron2's defaults where the file is silent."""
+    with open(d2_yaml) as f:
+        cfg = yaml.safe_load(f) or {}
+    s = cfg.get("SOLVER", {}) or {}
+    m = cfg.get("MODEL", {}) or {}
+    return {
+        "base_lr": float(s.get("BASE_LR", 0.001)), "momentum": float(s.get("MOMENTUM", 0.9)), "weight_decay": float(s.get("WEIGHT_DECAY", 1e-4)),
+        "gamma": float(s.get("GAMMA", 0.1)), "steps": tuple(int(x) for x in s.get("STEPS", (30000,))), "max_iter": int(s.get("MAX_ITER", 40000)),
+        "warmup_factor": float(s.get("WARMUP_FACTOR", 0.001)), "warmup_iters": int(s.get("WARMUP_ITERS", 1000)),
+        "ims_per_batch": int(s.get("IMS_PER_BATCH", 16)), "checkpoint_period": int(s.get("CHECKPOINT_PERIOD", 5000)),
+        "rpn_batch": int((m.get("RPN", {}) or {}).get("BATCH_SIZE_PER_IMAGE", 256)), "rpn_pos": float((m.get("RPN", {}) or {}).get("POSITIVE_FRACTION", 0.5)),
+        "roi_batch": int((m.get("ROI_HEADS", {}) or {}).get("BATCH_SIZE_PER_IMAGE", 512)), "roi_pos": float((m.get("ROI_HEADS", {}) or {}).get("POSITIVE_FRACTION", 0.25)),
+        "flip": str((cfg.get("INPUT", {}) or {}).get("RANDOM_FLIP", "horizontal")),
+    }
+
+
+def lr_at(sv: Dict[str, Any], it: int) -> float:
+    """WarmupMultiStepLR ([EXT d2: solver/lr_scheduler.py]): linear warm-up factor times gamma^(milestones passed)."""
+    if it < sv["warmup_iters"]:
+        alpha = it / sv["warmup_iters"]
+        wf = sv["warmup_factor"] * (1 - alpha) + alpha
+    else:
+        wf = 1.0
+    return sv["base_lr"] * wf * sv["gamma"] ** sum(1 for s in sv["steps"] if s <= it)
+
+
+def load_coco_training_set(path: str) -> Tuple[List[Dict[str, Any]], List[int]]:
+    """COCO JSON -> per-image records {file_name, width, height, boxes (k,4) XYXY, classes (k,), polygons [k][...]} with
+    contiguous 0-based classes (sorted category ids), crowd annotations dropped and empty images filtered."""
+    with open(path) as f:
+        d = json.load(f)
+    cats = sorted(c["id"] for c in d.get("categories", []))
+    cid = {c: i for i, c in enumerate(cats)}
+    per: Dict[int, List[dict]] = {}
+    for a in d.get("annotations", []):
+        if a.get("iscrowd", 0):
+            continue
+        per.setdefault(a["image_id"], []).append(a)
+    recs = []
+    for im in d.get("images", []):
+        anns = per.get(im["id"], [])
+        if not anns:
+            continue                                        # FILTER_EMPTY_ANNOTATIONS
+        boxes, classes, polys = [], [], []
+        for a in anns:
+            seg = a.get("segmentation")
+            if not isinstance(seg, list):
+                raise SystemExit("RLE segmentations are not supported (INPUT.MASK_FORMAT is polygon)")
+            p = [np.asarray(s, np.float64) for s in seg if len(s) >= 6 and len(s) % 2 == 0]
+            if not p:
+                continue
+            x, y, w, h = a["bbox"]
+            boxes.append([x, y, x + w, y + h]); classes.append(cid[a["category_id"]]); polys.append(p)
+        if boxes:
+            recs.append({"file_name": im["file_name"], "width": im["width"], "height": im["height"], "boxes": np.asarray(boxes, np.float64),
+                         "classes": np.asarray(classes, np.int64), "polygons": polys})
+    return recs, cats
+
+
+def map_record(rec: Dict[str, Any], tile: np.ndarray, net_hw: Tuple[int, int], flip: bool):
+    """DatasetMapper for one image: optional horizontal flip, then the annotations scaled to the network input (the tile
+    itself is resized on the GPU by the engine's Pillow-exact preprocess)."""
+    h, w = tile.shape[:2]
+    boxes = rec["boxes"].copy()
+    polys = [[p.copy() for p in inst] for inst in rec["polygons"]]
+    if flip:
+        tile = tile[:, ::-1]
+        boxes[:, [0, 2]] = w - boxes[:, [2, 0]]
+        for inst in polys:
+            for p in inst:
+                p[0::2] = w - p[0::2]
+    sy, sx = net_hw[0] / h, net_hw[1] / w
+    boxes[:, [0, 2]] *= sx
+    boxes[:, [1, 3]] *= sy
+    boxes[:, [0, 2]] = np.clip(boxes[:, [0, 2]], 0, net_hw[1])
+    boxes[:, [1, 3]] = np.clip(boxes[:, [1, 3]], 0, net_hw[0])
+    for inst in polys:
+        for p in inst:
+            p[0::2] *= sx
+            p[1::2] *= sy
+    keep = ((boxes[:, 2] - boxes[:, 0]) > 1e-5) & ((boxes[:, 3] - boxes[:, 1]) > 1e-5)       # filter_empty_instances
+    idx = np.nonzero(keep)[0]
+    return np.ascontiguousarray(tile), boxes[idx].astype(np.float32), rec["classes"][idx], [polys[i] for i in idx]
+
+
+def training_sampler(n: int, seed: int, rank: int, world: int):
+    """TrainingSampler: an infinite stream of shuffled indices, every rank taking each world-th one."""
+    rng = np.random.default_rng(seed)
+    k = 0
+    while True:
+        for i in rng.permutation(n).tolist():
+            if k % world == rank:
+                yield i
+            k += 1
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("config_file", help="YAML with a 'train_model.py' section (R:config/config_obj_detec.yaml)")
+    ap.add_argument("--synthetic-weights", action="store_true", help="start from seeded synthetic weights (no checkpoint available offline)")
+    ap.add_argument("--max-iter", type=int, default=0, help="override SOLVER.MAX_ITER (smoke runs)")
+    ap.add_argument("--loss-scale", type=float, default=1024.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--log-period", type=int, default=20)
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s", stream=sys.stderr)
+    with open(args.config_file) as f:
+        cfg = yaml.safe_load(f)[SECTION]
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("RS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    os.chdir(cfg["working_directory"])
+    log_dir = cfg.get("log_subfolder", "logs")
+    os.makedirs(log_dir, exist_ok=True)
+    recs, cats = load_coco_training_set(cfg["COCO_files"]["trn"])
+    if not recs:
+        raise SystemExit("no annotated training images")
+    sv = load_solver(cfg["detectron2_config_file"])
+    max_iter = args.max_iter or sv["max_iter"]
+    mw = cfg.get("model_weights", {}) or {}
+    if args.synthetic_weights:
+        spec = load_d2_yaml(cfg["detectron2_config_file"], num_classes=max(len(cats), 1))
+        W = synthetic_weights(spec, seed=0)
+    elif mw.get("pth_file"):
+        W = load_checkpoint(mw["pth_file"])
+        spec = load_d2_yaml(cfg["detectron2_config_file"], num_classes=infer_num_classes(W))
+    else:
+        raise SystemExit("model_weights.model_zoo_checkpoint_url needs network access; give model_weights.pth_file or --synthetic-weights")
+
+    from .engine import Trainer      # fails loudly without librs_engine.so / a HIP device
+    from .make_detections import read_tile
+    first = read_tile(recs[0]["file_name"])
+    per_rank = max(1, sv["ims_per_batch"] // world)
+    trainer = Trainer(spec, W, first.shape, batch=per_rank, device=local_rank, loss_scale=args.loss_scale)
+    trainer.set_sampling(sv["rpn_batch"], sv["rpn_pos"], min(sv["roi_batch"], 1024), sv["roi_pos"])
+    net_hw = resize_shortest_edge_shape(first.shape[0], first.shape[1], spec.min_size_test, spec.max_size_test)
+    log.info("training: %d images, %d classes, batch %d x %d ranks, %d iterations, network input %s, %.1f M trainable values",
+             len(recs), len(cats), per_rank, world, max_iter, net_hw, trainer.param_count / 1e6)
+    sampler = training_sampler(len(recs), args.seed, rank, world)
+    flips = np.random.default_rng(args.seed * 7919 + rank)
+    metrics = open(os.path.join(log_dir, "metrics.json"), "a") if rank == 0 else None
+
+    def save(name: str, it: int) -> None:
+        if rank != 0:
+            return
+        import torch
+        state = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in trainer.export_weights(W).items()}
+        torch.save({"model": state, "iteration": it}, os.path.join(log_dir, name))
+        with open(os.path.join(log_dir, "last_checkpoint"), "w") as f:
+            f.write(name)
+
+    t0 = time.time()
+    for it in range(max_iter):
+        tiles, boxes, classes, polys = [], [], [], []
+        for _ in range(per_rank):
+            rec = recs[next(sampler)]
+            tile = read_tile(rec["file_name"])
+            if tile.shape != first.shape:
+                raise SystemExit(f"{rec['file_name']}: tile shape {tile.shape} != {first.shape} (one shape per run)")
+            t, b, c, p = map_record(rec, tile, net_hw, sv["flip"] == "horizontal" and flips.random() < 0.5)
+            tiles.append(t); boxes.append(b); classes.append(c); polys.append(p)
+        losses = trainer.train_step(np.stack(tiles), boxes, classes, polys, seed=args.seed * 1000003 + it * world + rank)
+        trainer.allreduce_gradients()
+        lr = lr_at(sv, it)
+        trainer.apply_sgd(lr, sv["momentum"], sv["weight_decay"])
+        if not all(np.isfinite(v) for v in losses.values()):
+            raise SystemExit(f"iteration {it}: non-finite loss {losses} (lower --loss-scale)")
+        if rank == 0 and ((it + 1) % args.log_period == 0 or it == max_iter - 1):
+            rec = {"iteration": it, "total_loss": float(sum(losses.values())), "lr": lr, "time": (time.time() - t0) / (it + 1), **losses}
+            metrics.write(json.dumps(rec) + "\n")
+            metrics.flush()
+            log.info("iter %d  total_loss %.4f  %s  lr %.6f  %.3f s/iter", it, rec["total_loss"],
+                     "  ".join(f"{k} {v:.4f}" for k, v in losses.items()), lr, rec["time"])
+        if (it + 1) % sv["checkpoint_period"] == 0 and it + 1 < max_iter:
+            save(f"model_{it:07d}.pth", it)
+    save("model_final.pth", max_iter - 1)
+    trainer.close()
+    if metrics:
+        metrics.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

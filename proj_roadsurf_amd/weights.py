@@ -333,6 +333,48 @@ def train_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], freeze_at: int = 2
     return T
 
 
+def master_to_d2(spec: EngineSpec, base: Dict[str, np.ndarray], fetch) -> Dict[str, np.ndarray]:
+    """Inverse of ``train_tensors``: ``fetch("m:<layer>.w" | "m:<layer>.b")`` -> detectron2-keyed tensors (the layout
+    ``DetectionCheckpointer`` saves and ``load_checkpoint`` reads), on top of a copy of ``base`` for the frozen tensors."""
+    out = {k: np.array(v, copy=True) for k, v in base.items()}
+    shapes = {n: (cin, cout, k) for n, cin, cout, k, _ in conv_layers(spec)}
+    has_norm = {n: hn for n, _, _, _, hn in conv_layers(spec)}
+    A, K = spec.num_anchors, spec.num_classes
+    for name in trainable_layers(spec):
+        m = fetch(f"m:{name}.w")
+        if name in shapes:
+            cin, cout, k = shapes[name]
+            out[name + ".weight"] = m[:cout, : k * k * cin].reshape(cout, k, k, cin).transpose(0, 3, 1, 2).astype(np.float32)
+            if not has_norm[name]:
+                out[name + ".bias"] = fetch(f"m:{name}.b")[:cout].astype(np.float32)
+        elif name == "proposal_generator.rpn_head.heads":
+            b = fetch(f"m:{name}.b")
+            p = "proposal_generator.rpn_head."
+            c = m.shape[1]
+            out[p + "objectness_logits.weight"] = m[:A].reshape(A, c, 1, 1).astype(np.float32)
+            out[p + "anchor_deltas.weight"] = m[A:5 * A].reshape(4 * A, c, 1, 1).astype(np.float32)
+            out[p + "objectness_logits.bias"], out[p + "anchor_deltas.bias"] = b[:A].astype(np.float32), b[A:5 * A].astype(np.float32)
+        elif name == "roi_heads.box_head.fc1":
+            r, c = spec.box_pooler_resolution, spec.fpn_out_channels
+            out[name + ".weight"] = m.reshape(-1, r, r, c).transpose(0, 3, 1, 2).reshape(m.shape[0], -1).astype(np.float32)
+            out[name + ".bias"] = fetch(f"m:{name}.b").astype(np.float32)
+        elif name == "roi_heads.box_head.fc2":
+            out[name + ".weight"], out[name + ".bias"] = m.astype(np.float32), fetch(f"m:{name}.b").astype(np.float32)
+        elif name == "roi_heads.box_predictor":
+            b = fetch(f"m:{name}.b")
+            out[name + ".cls_score.weight"], out[name + ".bbox_pred.weight"] = m[:K + 1].astype(np.float32), m[K + 1:5 * K + 1].astype(np.float32)
+            out[name + ".cls_score.bias"], out[name + ".bbox_pred.bias"] = b[:K + 1].astype(np.float32), b[K + 1:5 * K + 1].astype(np.float32)
+        elif name == "roi_heads.mask_head.deconv":
+            cin = m.shape[0]
+            out[name + ".weight"] = m.reshape(cin, 2, 2, -1).transpose(0, 3, 1, 2).astype(np.float32)      # [ci][(dy,dx,co)] -> (Cin,Cout,2,2)
+            out[name + ".bias"] = fetch(f"m:{name}.b").astype(np.float32)
+        elif name == "roi_heads.mask_head.predictor16":
+            b = fetch(f"m:{name}.b")
+            out["roi_heads.mask_head.predictor.weight"] = m[:K].reshape(K, -1, 1, 1).astype(np.float32)
+            out["roi_heads.mask_head.predictor.bias"] = b[:K].astype(np.float32)
+    return out
+
+
 def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False) -> bytes:
     T = engine_tensors(spec, W)
     if train:

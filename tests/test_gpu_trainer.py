@@ -400,3 +400,68 @@ def test_full_training_step_five_losses_match_autograd(gpu_required):
         assert np.allclose(m1, m0 - np.float32(T.lr_at(ts, 0)) * (g0 + np.float32(ts.weight_decay) * m0), rtol=1e-5, atol=1e-9)
     finally:
         tr.close()
+
+
+def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
+    """train_model.py drop-in: same YAML section/keys as the reference (R:config/config_obj_detec.yaml:62-72); a few iterations on
+    a tiny synthetic COCO set write metrics.json and model_final.pth in detectron2's checkpoint layout, which make_detections.py
+    then consumes through model_weights.pth_file; the weights moved and the losses are finite."""
+    import json
+    import os
+    import yaml
+    from PIL import Image
+    from proj_roadsurf_amd import make_detections, train_model
+    from proj_roadsurf_amd.weights import load_checkpoint
+
+    wd = tmp_path / "outputs" / "obj_detector"
+    (wd / "trn-images").mkdir(parents=True)
+    tiles = synthetic_tiles(4, 128, 128, 3, seed=19)
+    images, anns = [], []
+    rng = np.random.default_rng(0)
+    for i in range(4):
+        fn = f"trn-images/18_{100 + i}_200.tif"
+        Image.fromarray(tiles[i][:, :, ::-1]).save(str(wd / fn))
+        images.append({"id": i, "file_name": fn, "width": 128, "height": 128})
+        for j in range(2):
+            x, y = rng.integers(5, 60, 2)
+            w, h = rng.integers(20, 60, 2)
+            anns.append({"id": len(anns), "image_id": i, "category_id": 1 + (j % 2), "bbox": [int(x), int(y), int(w), int(h)], "iscrowd": 0,
+                         "segmentation": [[int(x), int(y), int(x + w), int(y), int(x + w), int(y + h), int(x), int(y + h)]], "area": int(w * h)})
+    cats = [{"id": 1, "name": "artificial"}, {"id": 2, "name": "natural"}]
+    json.dump({"images": images, "annotations": anns, "categories": cats}, open(wd / "COCO_trn.json", "w"))
+    d2 = {"INPUT": {"FORMAT": "RGB", "MIN_SIZE_TEST": 192, "MAX_SIZE_TEST": 320, "RANDOM_FLIP": "horizontal"},
+          "MODEL": {"RPN": {"PRE_NMS_TOPK_TEST": 200, "POST_NMS_TOPK_TEST": 200, "BATCH_SIZE_PER_IMAGE": 64}, "ROI_HEADS": {"NUM_CLASSES": 2, "BATCH_SIZE_PER_IMAGE": 64}},
+          "SOLVER": {"BASE_LR": 0.002, "IMS_PER_BATCH": 2, "MAX_ITER": 6, "WARMUP_ITERS": 2, "STEPS": [4], "GAMMA": 0.5, "CHECKPOINT_PERIOD": 3},
+          "TEST": {"DETECTIONS_PER_IMAGE": 20}}
+    yaml.safe_dump(d2, open(tmp_path / "d2.yaml", "w"))
+    cfg = {"train_model.py": {"working_directory": str(wd), "log_subfolder": "logs", "sample_tagged_img_subfolder": "sample_training_images",
+                              "COCO_files": {"trn": "COCO_trn.json", "val": "COCO_trn.json", "tst": "COCO_trn.json"},
+                              "detectron2_config_file": str(tmp_path / "d2.yaml"),
+                              "model_weights": {"model_zoo_checkpoint_url": "COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_1x.yaml"}},
+           "make_detections.py": {"working_directory": str(wd), "log_subfolder": "logs", "image_metadata_json": "img_metadata.json",
+                                  "COCO_files": {"trn": "COCO_trn.json"}, "detectron2_config_file": str(tmp_path / "d2.yaml"),
+                                  "model_weights": {"pth_file": "logs/model_final.pth"}, "rdp_simplification": {"enabled": True, "epsilon": 0.75},
+                                  "score_lower_threshold": 0.05}}
+    yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
+    cwd = os.getcwd()
+    try:
+        assert train_model.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--log-period", "1", "--loss-scale", "256"]) == 0
+        os.chdir(cwd)
+        lines = [json.loads(l) for l in open(wd / "logs" / "metrics.json")]
+        assert [l["iteration"] for l in lines] == list(range(6))
+        assert all(np.isfinite(l["total_loss"]) and l["total_loss"] > 0 for l in lines)
+        assert lines[0]["lr"] == pytest.approx(0.002 * 0.001) and lines[3]["lr"] == pytest.approx(0.002) and lines[5]["lr"] == pytest.approx(0.001)
+        assert (wd / "logs" / "model_0000002.pth").exists() and open(wd / "logs" / "last_checkpoint").read() == "model_final.pth"
+        W1 = load_checkpoint(str(wd / "logs" / "model_final.pth"))
+        spec = EngineSpec(num_classes=2)
+        W0 = synthetic_weights(spec, seed=0)
+        assert set(W1) == set(W0)
+        moved = float(np.abs(W1["roi_heads.box_head.fc2.weight"] - W0["roi_heads.box_head.fc2.weight"]).max())
+        assert 0 < moved < 0.1
+        assert np.array_equal(W1["backbone.bottom_up.res2.0.conv1.weight"], W0["backbone.bottom_up.res2.0.conv1.weight"])     # FREEZE_AT 2
+        json.dump({}, open(wd / "img_metadata.json", "w"))
+        assert make_detections.main([str(tmp_path / "config.yaml"), "--batch", "2"]) == 0
+        os.chdir(cwd)
+        assert (wd / "trn_detections_at_0dot05_threshold.gpkg").exists()
+    finally:
+        os.chdir(cwd)
