@@ -160,6 +160,10 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world > 1:
+        import torch
+        ndev = max(1, torch.cuda.device_count())            # counting devices does not initialise the GPU
+        local_rank = local_rank % ndev                      # several ranks may share a card (tests on a one-GPU box, gloo)
     os.chdir(cfg["working_directory"])
     log_dir = cfg.get("log_subfolder", "logs")
     os.makedirs(log_dir, exist_ok=True)

@@ -465,3 +465,44 @@ def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
         assert (wd / "trn_detections_at_0dot05_threshold.gpkg").exists()
     finally:
         os.chdir(cwd)
+
+
+def test_train_model_two_ranks_data_parallel(gpu_required, tmp_path):
+    """Data-parallel path end to end with two ranks (both on this box's one GPU, gloo all-reduce through host copies; on a node
+    the same code runs one rank per GPU over RCCL): TrainingSampler strides, flat-gradient all-reduce, averaged SGD step, rank-0
+    checkpoint."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import yaml
+    from PIL import Image
+
+    wd = tmp_path / "w"
+    (wd / "trn-images").mkdir(parents=True)
+    tiles = synthetic_tiles(4, 128, 128, 3, seed=23)
+    images, anns = [], []
+    for i in range(4):
+        fn = f"trn-images/18_{i}_0.tif"
+        Image.fromarray(tiles[i][:, :, ::-1]).save(str(wd / fn))
+        images.append({"id": i, "file_name": fn, "width": 128, "height": 128})
+        anns.append({"id": i, "image_id": i, "category_id": 1 + i % 2, "bbox": [20 + i, 30, 60, 50], "iscrowd": 0,
+                     "segmentation": [[20 + i, 30, 80 + i, 30, 80 + i, 80, 20 + i, 80]]})
+    json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "a"}, {"id": 2, "name": "b"}]}, open(wd / "COCO_trn.json", "w"))
+    d2 = {"INPUT": {"FORMAT": "RGB", "MIN_SIZE_TEST": 192, "MAX_SIZE_TEST": 320},
+          "MODEL": {"RPN": {"PRE_NMS_TOPK_TEST": 200, "POST_NMS_TOPK_TEST": 200, "BATCH_SIZE_PER_IMAGE": 64}, "ROI_HEADS": {"NUM_CLASSES": 2, "BATCH_SIZE_PER_IMAGE": 64}},
+          "SOLVER": {"BASE_LR": 0.002, "IMS_PER_BATCH": 2, "MAX_ITER": 3, "WARMUP_ITERS": 1, "CHECKPOINT_PERIOD": 100}}
+    yaml.safe_dump(d2, open(tmp_path / "d2.yaml", "w"))
+    cfg = {"train_model.py": {"working_directory": str(wd), "log_subfolder": "logs", "COCO_files": {"trn": "COCO_trn.json"},
+                              "detectron2_config_file": str(tmp_path / "d2.yaml"), "model_weights": {}}}
+    yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RS_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", "-m", "proj_roadsurf_amd.train_model", str(tmp_path / "config.yaml"), "--synthetic-weights",
+                        "--log-period", "1", "--loss-scale", "256"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in open(wd / "logs" / "metrics.json")]
+    assert [l["iteration"] for l in lines] == [0, 1, 2] and all(np.isfinite(l["total_loss"]) for l in lines)
+    assert (wd / "logs" / "model_final.pth").exists()
+    assert "batch 1 x 2 ranks" in r.stderr
