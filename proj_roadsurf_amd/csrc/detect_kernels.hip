@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
   const int n = slot / p.slots_per_image;
   const int P = p.P, PP = P + 2 * p.out_pad;
   const half_t* gout = p.out + (long long)entry * PP * PP * 256;
-  const int hw = tid >> 5, l32 = tid & 31;
+  const int l32 = tid & 31;
   if (p.per_image_count && (slot - n * p.slots_per_image) >= p.per_image_count[n]) return;
   const float* r = p.rois + (long long)slot * 4;
   const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
@@ -792,17 +792,23 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
     s_len[ax][b] = overflow ? -1 : len;
   }
   __syncthreads();
-  for (int b0 = 0; b0 < P * P; b0 += 8) {
-    const int b = b0 + hw;
-    if (b >= P * P) break;
+  // One WAVE per bin, lane l owns channels l, l+64, l+128, l+192: every atomic instruction of the wave then covers 64
+  // CONSECUTIVE floats (four full 64-byte lines) of one cell, which the L2 atomic units take as four line updates --
+  // with 8 consecutive channels per lane (the forward layout) the same instruction scatters 64 words over 2 KB and the
+  // kernel is ~6x slower (measured: 25.7 -> see DESIGN.md ms for 8 x 1024 RoIs).
+  const int wv = tid >> 6, ln = tid & 63;
+  float* dfl = dfeat - l32 * 8 + ln;              // undo the forward-style channel offset baked into dfeat
+  for (int b0 = 0; b0 < P * P; b0 += 4) {
+    const int b = b0 + wv;
+    if (b >= P * P) break;                        // uniform per wave; no barrier below
     const int ph = b / P, pw = b - ph * P;
-    const half8 gv = *(const half8*)(gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8);
-    float gsc[8];
+    const half_t* gp = gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + ln;
+    float gsc[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) gsc[c] = (float)gv[c] / count;
+    for (int c = 0; c < 4; ++c) gsc[c] = (float)gp[c * 64] / count;
     const int ny = s_len[0][ph], nx = s_len[1][pw];
     if (ny >= 0 && nx >= 0) {
-      float* f0 = dfeat + ((long long)s_base[0][ph] * (W + 2) + s_base[1][pw]) * 256;
+      float* f0 = dfl + ((long long)s_base[0][ph] * (W + 2) + s_base[1][pw]) * 256;
       for (int j = 0; j < ny; ++j) {
         const float wj = s_w[0][ph][j];
         if (wj == 0.f) continue;
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
           if (wgt == 0.f) continue;
           float* d = f0 + ((long long)j * (W + 2) + i) * 256;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) atomicAdd(d + c, wgt * gsc[c]);
+          for (int c = 0; c < 4; ++c) atomicAdd(d + c * 64, wgt * gsc[c]);
         }
       }
     } else {
@@ -829,16 +835,16 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
           int xlo = (int)x, xhi;
           if (xlo >= W - 1) { xhi = xlo = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
           const float lx = x - (float)xlo, hx = 1.f - lx;
-          float* d1 = dfeat + ((long long)ylo * (W + 2) + xlo) * 256;
-          float* d2 = dfeat + ((long long)ylo * (W + 2) + xhi) * 256;
-          float* d3 = dfeat + ((long long)yhi * (W + 2) + xlo) * 256;
-          float* d4 = dfeat + ((long long)yhi * (W + 2) + xhi) * 256;
+          float* d1 = dfl + ((long long)ylo * (W + 2) + xlo) * 256;
+          float* d2 = dfl + ((long long)ylo * (W + 2) + xhi) * 256;
+          float* d3 = dfl + ((long long)yhi * (W + 2) + xlo) * 256;
+          float* d4 = dfl + ((long long)yhi * (W + 2) + xhi) * 256;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            atomicAdd(d1 + c, hy * hx * gsc[c]);
-            atomicAdd(d2 + c, hy * lx * gsc[c]);
-            atomicAdd(d3 + c, ly * hx * gsc[c]);
-            atomicAdd(d4 + c, ly * lx * gsc[c]);
+          for (int c = 0; c < 4; ++c) {
+            atomicAdd(d1 + c * 64, hy * hx * gsc[c]);
+            atomicAdd(d2 + c * 64, hy * lx * gsc[c]);
+            atomicAdd(d3 + c * 64, ly * hx * gsc[c]);
+            atomicAdd(d4 + c * 64, ly * lx * gsc[c]);
           }
         }
       }

@@ -363,14 +363,19 @@ __global__ __launch_bounds__(1024) void subsample_kernel(const SubsampleParams p
 }
 
 // bias gradient: grad[c] = sum over rows of dy[row][c] (halo rows are zero, so the whole buffer can be summed).
-// One workgroup per 8 channels, fixed summation order (bitwise reproducible).
-__global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate,
+// Stage 1: workgroup (8 channels, row slice z) -> scratch[z][c], fixed order inside; stage 2 adds the slices in order
+// (bitwise reproducible, no atomics).
+__global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* scratch,
                                                        const int* m_count, int m_mul) {
   __shared__ float red[256][8];
   if (m_count) { const long long mc = (long long)(*m_count) * m_mul; if (mc < rows) rows = mc; }
   const int c0 = blockIdx.x * 8;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = (long long)blockIdx.y * per;
+  long long r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long long r = threadIdx.x; r < rows; r += 256) {
+  for (long long r = r0 + threadIdx.x; r < r1; r += 256) {
     const half8 v = *(const half8*)(dy + r * C + c0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
@@ -384,8 +389,14 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long l
       for (int i = 0; i < 8; ++i) red[threadIdx.x][i] += red[threadIdx.x + s][i];
     __syncthreads();
   }
-  if (threadIdx.x < 8 && c0 + (int)threadIdx.x < cout)
-    grad[c0 + threadIdx.x] = accumulate ? grad[c0 + threadIdx.x] + red[0][threadIdx.x] : red[0][threadIdx.x];
+  if (threadIdx.x < 8 && c0 + (int)threadIdx.x < cout) scratch[(long long)blockIdx.y * cout + c0 + threadIdx.x] = red[0][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float* scratch, int slices, int cout, float* grad, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cout) return;
+  float s = 0.f;
+  for (int z = 0; z < slices; ++z) s += scratch[(long long)z * cout + c];
+  grad[c] = accumulate ? grad[c] + s : s;
 }
 
 // backward of LastLevelMaxPool (max_pool2d k=1 s=2): d_fine[2y][2x] += d_coarse[y][x]; both NHWC fp16 with halo 1
@@ -543,9 +554,13 @@ int launch_subsample(const SubsampleParams& p, int N, hipStream_t s) {
 }
 
 int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s, const int* m_count,
-                     int m_mul) {
-  RS_CHECK(dy && grad && rows > 0 && C % 8 == 0 && cout > 0 && cout <= C, RS_ERR_ARG, "bias_grad: bad arguments");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(cout, 8)), dim3(256), 0, s, dy, rows, C, cout, grad, accumulate, m_count, m_mul);
+                     int m_mul, float* scratch) {
+  RS_CHECK(dy && grad && scratch && rows > 0 && C % 8 == 0 && cout > 0 && cout <= C, RS_ERR_ARG, "bias_grad: bad arguments");
+  int slices = (int)(rows / 2048);               // >= 8 rows per thread and slice
+  if (slices < 1) slices = 1;
+  if (slices > RS_BIAS_GRAD_SLICES) slices = RS_BIAS_GRAD_SLICES;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(cout, 8), slices), dim3(256), 0, s, dy, rows, C, cout, scratch, m_count, m_mul);
+  hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, s, scratch, slices, cout, grad, accumulate);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
