@@ -154,6 +154,11 @@ int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, co
                  int stride, int pad, int cout, int kpad, int out_halo, int relu, int out_f32, int deconv2x,
                  int variant, int use_glds, void* stream);
 
+/* Diagnostic builds only (csrc compiled with -DRS_CLOCK_PROBE, tools/ubench/clock_probe.py): device buffer of 2 int64 per
+ * workgroup that rs_op_conv2d's 256x256 deep-prefetch kernel fills with {shader clocks, 100 MHz ticks} spent in its K loop.
+ * No effect in the production build. */
+int rs_debug_set_conv_probe(void* buffer);
+
 /* Bottleneck output with a projection shortcut as ONE GEMM over two activation sources:
  *   out = act( conv_khxkw(in; W[:, :kh*kw*cin]) + conv_1x1_stride2(in2; W[:, kh*kw*cin:]) + bias )
  * i.e. BottleneckBlock.forward's `out = conv3(out); shortcut = self.shortcut(x); out += shortcut; relu`

@@ -83,6 +83,7 @@ struct ConvParams {
                         // applied after bias/res/up/down/res32, before `relu`
   int out_stride;       // 0/1 = dense; s > 1: output pixel (y, x) is stored at (y*s, x*s) of the out/res/res32/mask maps
                         // (input gradient of a stride-s 1x1 convolution; the other positions are the caller's zeros)
+  long long* probe;     // diagnostic builds only (-DRS_CLOCK_PROBE): per workgroup {shader clocks, 100 MHz ticks} around the K loop
   int persist;          // >0: persistent launch with this many workgroups per CU; -1: per-variant default; 0: one per tile
   int stages;           // LDS K-step buffers: 0/2 = double buffered, 1 = single (set by launch_conv for shallow K)
 };

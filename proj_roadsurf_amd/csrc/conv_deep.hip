@@ -142,6 +142,11 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
     const unsigned wa = wa1 + ((DBG & 2) ? 0 : wb) * WSTAGE, xa = xa1 + ((DBG & 2) ? 0 : ab) * ASTAGE;
     RS_READS(wf1, xf1, wa, xa)
   };
+#ifdef RS_CLOCK_PROBE
+  // in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6); stamps go to a
+  // buffer nothing else reads
+  const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime(), pr_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // prologue: w(0), acts(0), acts(1); publish step 0; then w(1), acts(2) and the first fragments
   stage_w();
   stage_a();
@@ -190,6 +195,12 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
   }
 
+#ifdef RS_CLOCK_PROBE
+  if (p.probe && tid == 0) {
+    p.probe[2 * q] = (long long)(__builtin_amdgcn_s_memtime() - pr_t0);
+    p.probe[2 * q + 1] = (long long)(__builtin_amdgcn_s_memrealtime() - pr_r0);
+  }
+#endif
   // ---- epilogue (as conv_igemm.hip, mode 0): lane holds channels crow .. crow+15 of pixel (j, fi)
   const int crow = n0 + wch * 64 + fq * 16;
   float bias[16];

@@ -1118,6 +1118,7 @@ int rs_engine_net_shape(rs_engine* e, int* rh, int* rw, int* ph, int* pw) {
 }
 
 // ------------------------------------------------------------------------- stand-alone operators
+static long long* g_conv_probe = nullptr;   // -DRS_CLOCK_PROBE diagnostic builds: see rs_debug_set_conv_probe
 static int op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual, const void* upsample_add,
                      int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
                      int out_halo, int relu, int out_f32, int deconv2x, int variant, int use_glds, void* stream,
@@ -1136,6 +1137,7 @@ static int op_conv2d(const void* in, const void* w, const float* bias, void* out
   p.out_Hp = oh + 2 * out_halo; p.out_Wp = ow + 2 * out_halo; p.out_Cs = cout; p.out_pad = out_halo;
   if (upsample_add) { p.up_Hp = ho / 2 + 2 * out_halo; p.up_Wp = wo / 2 + 2 * out_halo; p.up_Cs = cout; p.up_pad = out_halo; }
   p.relu = relu; p.mode = deconv2x ? 1 : 0; p.out_f32 = out_f32;
+  p.probe = g_conv_probe;
   if (in2) {
     RS_CHECK(stride2 >= 1 && (ho - 1) * stride2 < h2 && (wo - 1) * stride2 < w2, RS_ERR_ARG, "second source geometry");
     p.in2 = (const half_t*)in2; p.in2_Hp = h2 + 2 * in2_halo; p.in2_Wp = w2 + 2 * in2_halo; p.in2_Cs = cin2;
@@ -1157,6 +1159,8 @@ static int op_conv2d(const void* in, const void* w, const float* bias, void* out
   }
   return rc;
 }
+
+int rs_debug_set_conv_probe(void* buffer) { g_conv_probe = (long long*)buffer; return RS_OK; }
 
 int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual, const void* upsample_add,
                  int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
