@@ -295,6 +295,10 @@ int rs_trainer_sync(rs_trainer* t);
 int rs_trainer_tensor(rs_trainer* t, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo);
 int rs_trainer_tensor_count(rs_trainer* t);
 int rs_trainer_tensor_name(rs_trainer* t, int i, char* name_out);
+/* Multi-scale training (INPUT.MIN_SIZE_TRAIN sampling "choice", R:31-38): build one trainer per network-input size (same
+ * weights, spec.min_size_test = that size) and, when the size of the next batch differs from the previous one's, carry the
+ * optimiser state over: master weights + momentum are copied device to device and dst's fp16 operands refolded. */
+int rs_trainer_copy_state(rs_trainer* dst, rs_trainer* src);
 /* Data parallel: every rank all-reduces (SUM) the flat gradient buffer (rs_trainer_grad_buffer, rs_trainer_param_count floats,
  * device memory) and sets the divisor to the world size, which rs_trainer_apply_sgd applies together with the loss scale
  * (DistributedDataParallel's gradient averaging: [EXT d2: engine/defaults.py create_ddp_model]). */

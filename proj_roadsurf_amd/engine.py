@@ -492,6 +492,7 @@ class Trainer:
         lib.rs_trainer_roi_step.argtypes = [vp, i32, C.c_uint32]
         lib.rs_trainer_set_sampling.argtypes = [vp, i32, C.c_float, i32, C.c_float]
         lib.rs_trainer_set_grad_divisor.argtypes = [vp, C.c_float]
+        lib.rs_trainer_copy_state.argtypes = [vp, vp]
         lib.rs_trainer_grad_buffer.argtypes = [vp]
         lib.rs_trainer_grad_buffer.restype = vp
         lib.rs_trainer_mask_forward.argtypes = [vp, i32]
@@ -627,6 +628,10 @@ class Trainer:
         names = ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask")
         return {k: float(l[i]) for i, k in enumerate(names)}
 
+    def copy_state_from(self, other: "Trainer") -> None:
+        """Carry master weights + momentum over from ``other`` (a trainer of another input size) and refold."""
+        _check(self.lib, self.lib.rs_trainer_copy_state(self._h, other._h), "rs_trainer_copy_state")
+
     def allreduce_gradients(self) -> None:
         """Sum the flat gradient buffer over the ranks of the default process group (RCCL: the buffer is handed to
         torch.distributed in place through ``__cuda_array_interface__``; gloo: through a host copy) and set the divisor the SGD
@@ -691,3 +696,45 @@ class Trainer:
             self.close()
         except Exception:
             pass
+
+
+class MultiScaleTrainer:
+    """``INPUT.MIN_SIZE_TRAIN`` with ``MIN_SIZE_TRAIN_SAMPLING: choice`` (R:31-38): one ``Trainer`` per shortest-edge size,
+    built lazily; each batch runs at one randomly chosen size (detectron2 draws the size per image and pads the batch to the
+    largest -- with the reference's 1 image per GPU, IMS_PER_BATCH 8 on 8 GPUs, that is the same thing) and the optimiser state
+    follows the batch from trainer to trainer (``rs_trainer_copy_state``)."""
+
+    def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], sizes: Sequence[int], batch: int = 1,
+                 device: int = 0, loss_scale: float = 1024.0):
+        self.spec, self.weights, self.tile_shape, self.batch, self.device, self.loss_scale = spec, weights, tile_shape, batch, device, loss_scale
+        self.sizes = [int(s) for s in sizes]
+        self._t: Dict[int, Trainer] = {}
+        self.current: Optional[Trainer] = None
+        self._sampling: Optional[Tuple[int, float, int, float]] = None
+
+    def set_sampling(self, *a) -> None:
+        self._sampling = tuple(a)
+        for t in self._t.values():
+            t.set_sampling(*a)
+
+    def select(self, size: int) -> Trainer:
+        """The trainer for shortest-edge ``size``, holding the up-to-date optimiser state."""
+        if size not in self._t:
+            t = Trainer(self.spec.replace(min_size_test=int(size)), self.weights, self.tile_shape, self.batch, self.device, self.loss_scale)
+            if self._sampling:
+                t.set_sampling(*self._sampling)
+            self._t[size] = t
+        t = self._t[size]
+        if self.current is not None and self.current is not t:
+            t.copy_state_from(self.current)
+        self.current = t
+        return t
+
+    def net_shape(self, size: int) -> Tuple[int, int]:
+        from .spec import resize_shortest_edge_shape
+        return resize_shortest_edge_shape(self.tile_shape[0], self.tile_shape[1], int(size), self.spec.max_size_test)
+
+    def close(self) -> None:
+        for t in self._t.values():
+            t.close()
+        self._t.clear()

@@ -16,8 +16,8 @@ What follows the reference / detectron2 0.6 and where it is pinned:
     checkpoint every CHECKPOINT_PERIOD  [EXT d2: solver/build.py, engine/defaults.py];
   * data parallel: one process per GPU, gradients all-reduced over RCCL/xGMI in one flat 175 MB fp32 buffer and averaged
     (DistributedDataParallel semantics).
-Documented deviations: the network input size is fixed per run (MIN_SIZE_TRAIN's multi-scale "choice", R:31-38, is
-not sampled: the engine is built for one input geometry), RPN proposals use the engine's 1000-per-level capacity before NMS
+Documented deviations: MIN_SIZE_TRAIN's multi-scale "choice" (R:31-38) is drawn once per BATCH, not per image
+(identical at the reference's one image per GPU), RPN proposals use the engine's 1000-per-level capacity before NMS
 (R:250 asks 2000), fp16 activations/weights with fp32 master weights and static loss scaling instead of fp32 everywhere, the
 model-zoo URL of ``model_weights.model_zoo_checkpoint_url`` cannot be fetched offline (use ``model_weights.pth_file`` or
 ``--synthetic-weights``), and the periodic COCO evaluation / validation-loss hooks are not built.
@@ -56,6 +56,8 @@ def load_solver(d2_yaml: str) -> Dict[str, Any]:
         "rpn_batch": int((m.get("RPN", {}) or {}).get("BATCH_SIZE_PER_IMAGE", 256)), "rpn_pos": float((m.get("RPN", {}) or {}).get("POSITIVE_FRACTION", 0.5)),
         "roi_batch": int((m.get("ROI_HEADS", {}) or {}).get("BATCH_SIZE_PER_IMAGE", 512)), "roi_pos": float((m.get("ROI_HEADS", {}) or {}).get("POSITIVE_FRACTION", 0.25)),
         "flip": str((cfg.get("INPUT", {}) or {}).get("RANDOM_FLIP", "horizontal")),
+        "min_size_train": tuple(int(x) for x in ((cfg.get("INPUT", {}) or {}).get("MIN_SIZE_TRAIN") or ())),
+        "min_size_sampling": str((cfg.get("INPUT", {}) or {}).get("MIN_SIZE_TRAIN_SAMPLING", "choice")),
     }
 
 
@@ -182,15 +184,21 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     else:
         raise SystemExit("model_weights.model_zoo_checkpoint_url needs network access; give model_weights.pth_file or --synthetic-weights")
 
-    from .engine import Trainer      # fails loudly without librs_engine.so / a HIP device
+    from .engine import MultiScaleTrainer      # fails loudly without librs_engine.so / a HIP device
     from .make_detections import read_tile
     first = read_tile(recs[0]["file_name"])
     per_rank = max(1, sv["ims_per_batch"] // world)
-    trainer = Trainer(spec, W, first.shape, batch=per_rank, device=local_rank, loss_scale=args.loss_scale)
-    trainer.set_sampling(sv["rpn_batch"], sv["rpn_pos"], min(sv["roi_batch"], 1024), sv["roi_pos"])
-    net_hw = resize_shortest_edge_shape(first.shape[0], first.shape[1], spec.min_size_test, spec.max_size_test)
-    log.info("training: %d images, %d classes, batch %d x %d ranks, %d iterations, network input %s, %.1f M trainable values",
-             len(recs), len(cats), per_rank, world, max_iter, net_hw, trainer.param_count / 1e6)
+    # INPUT.MIN_SIZE_TRAIN (R:31-38): "choice" draws one of the listed sizes, "range" any size in [lo, hi] (here: the listed
+    # end points and every 32nd size between them, one engine geometry each); no list = the test size
+    sizes = list(sv["min_size_train"]) or [spec.min_size_test]
+    if sv["min_size_sampling"] == "range" and len(sizes) == 2:
+        sizes = list(range(sizes[0], sizes[1] + 1, 32))
+    ms = MultiScaleTrainer(spec, W, first.shape, sizes, batch=per_rank, device=local_rank, loss_scale=args.loss_scale)
+    ms.set_sampling(sv["rpn_batch"], sv["rpn_pos"], min(sv["roi_batch"], 1024), sv["roi_pos"])
+    size_rng = np.random.default_rng(args.seed * 104729 + rank)
+    trainer = ms.select(sizes[-1])
+    log.info("training: %d images, %d classes, batch %d x %d ranks, %d iterations, shortest-edge sizes %s, %.1f M trainable values",
+             len(recs), len(cats), per_rank, world, max_iter, sizes, trainer.param_count / 1e6)
     sampler = training_sampler(len(recs), args.seed, rank, world)
     flips = np.random.default_rng(args.seed * 7919 + rank)
     metrics = open(os.path.join(log_dir, "metrics.json"), "a") if rank == 0 else None
@@ -199,13 +207,16 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         if rank != 0:
             return
         import torch
-        state = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in trainer.export_weights(W).items()}
+        state = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ms.current.export_weights(W).items()}
         torch.save({"model": state, "iteration": it}, os.path.join(log_dir, name))
         with open(os.path.join(log_dir, "last_checkpoint"), "w") as f:
             f.write(name)
 
     t0 = time.time()
     for it in range(max_iter):
+        size = int(sizes[int(size_rng.integers(len(sizes)))])
+        trainer = ms.select(size)
+        net_hw = ms.net_shape(size)
         tiles, boxes, classes, polys = [], [], [], []
         for _ in range(per_rank):
             rec = recs[next(sampler)]
@@ -229,7 +240,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         if (it + 1) % sv["checkpoint_period"] == 0 and it + 1 < max_iter:
             save(f"model_{it:07d}.pth", it)
     save("model_final.pth", max_iter - 1)
-    trainer.close()
+    ms.close()
     if metrics:
         metrics.close()
     if world > 1:

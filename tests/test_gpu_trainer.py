@@ -429,7 +429,8 @@ def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
                          "segmentation": [[int(x), int(y), int(x + w), int(y), int(x + w), int(y + h), int(x), int(y + h)]], "area": int(w * h)})
     cats = [{"id": 1, "name": "artificial"}, {"id": 2, "name": "natural"}]
     json.dump({"images": images, "annotations": anns, "categories": cats}, open(wd / "COCO_trn.json", "w"))
-    d2 = {"INPUT": {"FORMAT": "RGB", "MIN_SIZE_TEST": 192, "MAX_SIZE_TEST": 320, "RANDOM_FLIP": "horizontal"},
+    d2 = {"INPUT": {"FORMAT": "RGB", "MIN_SIZE_TEST": 192, "MAX_SIZE_TEST": 320, "RANDOM_FLIP": "horizontal",
+                    "MIN_SIZE_TRAIN": [160, 192], "MIN_SIZE_TRAIN_SAMPLING": "choice"},          # multi-scale: two engine geometries
           "MODEL": {"RPN": {"PRE_NMS_TOPK_TEST": 200, "POST_NMS_TOPK_TEST": 200, "BATCH_SIZE_PER_IMAGE": 64}, "ROI_HEADS": {"NUM_CLASSES": 2, "BATCH_SIZE_PER_IMAGE": 64}},
           "SOLVER": {"BASE_LR": 0.002, "IMS_PER_BATCH": 2, "MAX_ITER": 6, "WARMUP_ITERS": 2, "STEPS": [4], "GAMMA": 0.5, "CHECKPOINT_PERIOD": 3},
           "TEST": {"DETECTIONS_PER_IMAGE": 20}}
@@ -506,3 +507,35 @@ def test_train_model_two_ranks_data_parallel(gpu_required, tmp_path):
     assert [l["iteration"] for l in lines] == [0, 1, 2] and all(np.isfinite(l["total_loss"]) for l in lines)
     assert (wd / "logs" / "model_final.pth").exists()
     assert "batch 1 x 2 ranks" in r.stderr
+
+
+def test_multi_scale_state_handover(gpu_required):
+    """MIN_SIZE_TRAIN "choice": the optimiser state follows the batch from the trainer of one input size to the next -- after a
+    step at 160 px, the 192 px trainer holds bit-identical master weights and momentum and a refolded forward."""
+    from proj_roadsurf_amd.engine import MultiScaleTrainer
+    spec = EngineSpec(num_classes=2, min_size_test=192, max_size_test=320, rpn_pre_nms_topk_test=200, rpn_post_nms_topk_test=200)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(1, 128, 128, 3, seed=31)
+    ms = MultiScaleTrainer(spec, Wn, (128, 128, 3), [160, 192], batch=1, loss_scale=64.0)
+    try:
+        ms.set_sampling(64, 0.5, 64, 0.25)
+        a = ms.select(160)
+        assert ms.net_shape(160) == (160, 160) and ms.net_shape(192) == (192, 192)
+        s = 160 / 128
+        gb = [np.array([[20.0, 30.0, 90.0, 100.0]], np.float32) * s]
+        polys = [[[np.array([20.0, 30, 90, 30, 90, 100, 20, 100]) * s]]]
+        l0 = a.train_step(tiles, gb, [np.array([1])], polys, seed=3)
+        a.apply_sgd(1e-3, 0.9, 1e-4)
+        n = "roi_heads.box_head.fc2"
+        m_a = a.tensor(f"m:{n}.w").copy()
+        assert float(np.abs(m_a - Wn[n + ".weight"]).max()) > 0 and all(np.isfinite(v) for v in l0.values())
+        b = ms.select(192)
+        assert b is not a and np.array_equal(b.tensor(f"m:{n}.w"), m_a)
+        assert np.array_equal(b.tensor("m:backbone.bottom_up.res4.3.conv2.w"), a.tensor("m:backbone.bottom_up.res4.3.conv2.w"))
+        s2 = 192 / 128
+        l1 = b.train_step(tiles, [gb[0] / s * s2], [np.array([1])], [[[polys[0][0][0] / s * s2]]], seed=4)
+        b.apply_sgd(1e-3, 0.9, 1e-4)                   # second step: momentum carried over, not re-initialised
+        assert all(np.isfinite(v) for v in l1.values())
+        assert float(np.abs(b.tensor(f"m:{n}.w") - m_a).max()) > 0
+    finally:
+        ms.close()
