@@ -132,13 +132,16 @@ def main():
             a["calls"] += b["calls"]
     for e in engs:
         e.set_profiling(0)
-    # PCIe-inclusive rate of the host-buffer entry point (H2D tiles + forward + D2H boxes/scores/masks);
-    # reported beside the headline, never as `value`
-    eng.infer(tiles)
+    # PCIe-inclusive rate of the streaming host interface (pinned H2D of the tiles + forward + D2H of boxes/scores/packed
+    # masks + host-side collection into Instances, LanePipeline.run); reported beside the headline, never as `value`
+    nb = 8
+    for _ in pipe.run(tiles for _ in range(2)):
+        pass
     t1 = time.perf_counter()
-    for _ in range(3):
-        eng.infer(tiles)
-    pcie_tiles_per_s = 3 * B / (time.perf_counter() - t1)
+    for res in pipe.run(tiles for _ in range(nb)):
+        pass
+    pcie_tiles_per_s = nb * B / (time.perf_counter() - t1)
+    eng.infer_device(ptrs[0], B)
     dets = eng.fetch(B)
     nprop = eng.tensor("proposal_count", n=B)
     ndet = [len(d) for d in dets]

@@ -114,6 +114,18 @@ int rs_engine_fetch(rs_engine* e, int n, rs_dets* out_host);
 int rs_engine_infer_phase(rs_engine* e, const uint8_t* tiles_dev, int n, int phase);
 int rs_engine_phase_count(void);
 
+/* Asynchronous host interface (what a streaming caller -- make_detections.py over a tile list -- uses instead of rs_engine_infer):
+ * pinned host memory, the upload enqueued on the engine's stream in front of the forward, and the results copied back on a
+ * separate copy stream behind an event, so batch k's device-to-host copy (3.3 MB of packed masks per 512x512 tile) overlaps batch
+ * k+1's forward.  With two engines on one shared stream (rs_engine_infer_phase) call rs_engine_fetch_async right after the
+ * engine's phase 2 has been enqueued.  Buffers given to upload/fetch_async must come from rs_host_alloc and stay untouched until
+ * rs_engine_fetch_wait returns. */
+void* rs_host_alloc(size_t nbytes);
+void rs_host_free(void* p);
+int rs_engine_upload_async(rs_engine* e, const uint8_t* tiles_host, int n);
+int rs_engine_fetch_async(rs_engine* e, int n, rs_dets* out_host);
+int rs_engine_fetch_wait(rs_engine* e);
+
 /* Stream the engine launches on (hipStream_t), for event timing by the caller. */
 void* rs_engine_stream(rs_engine* e);
 

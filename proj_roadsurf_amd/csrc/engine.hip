@@ -122,6 +122,10 @@ struct rs_engine {
   int device = 0;
   hipStream_t stream = nullptr;         // "wide" stream: every kernel that fills the chip (may be shared between engines)
   bool own_stream = false;
+  hipStream_t copy_stream = nullptr;    // device-to-host result copies (rs_engine_fetch_async), overlapping the next batch
+  hipEvent_t ev_results = nullptr;      // recorded on `stream` when a forward's results are complete
+  hipEvent_t ev_copied = nullptr;       // recorded on `copy_stream` after the last result copy; the next forward's box head waits for it
+  bool copy_pending = false;
   hipStream_t narrow = nullptr;         // side stream for the latency-bound glue kernels (null = everything on `stream`)
   bool on_narrow = false;               // which stream the most recently enqueued stage went to
   hipEvent_t ev_join = nullptr;         // narrow -> wide join at the end of a forward that ends on the side stream
@@ -871,6 +875,11 @@ int rs_engine::run(const uint8_t* tiles, int n, int phase) {
     const long long idx = forward_index++;
     cur_record = profiling == 1 || profiling == 2 || (profiling == 3 && (idx & 3) == 0);
   }
+  if (copy_pending && (phase < 0 || phase == 1)) {
+    // the box head rewrites the result buffers: let an outstanding rs_engine_fetch_async of the previous forward finish first
+    RS_HIP(hipStreamWaitEvent(stream, ev_copied, 0));
+    copy_pending = false;
+  }
   const bool record = cur_record;
   if (phase >= 0 || record || !use_graph || !warmed.count(n)) {
     int rc = run_stages(n, record, phase);
@@ -971,6 +980,9 @@ void rs_engine_destroy(rs_engine* e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->narrow) { hipStreamSynchronize(e->narrow); hipStreamDestroy(e->narrow); }
+  if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+  if (e->ev_results) (void)hipEventDestroy(e->ev_results);
+  if (e->ev_copied) (void)hipEventDestroy(e->ev_copied);
   if (e->ev_join) hipEventDestroy(e->ev_join);
   for (Stage& st : e->stages) if (st.handoff) hipEventDestroy(st.handoff);
   for (void* p : e->allocs) hipFree(p);
@@ -1022,6 +1034,47 @@ int rs_engine_fetch(rs_engine* e, int n, rs_dets* o) {
     RS_HIP(hipMemcpyAsync(o->mask_probs, e->mask_probs, (size_t)n * D * RS_MASK_SIDE * RS_MASK_SIDE * 4, hipMemcpyDeviceToHost, s));
   }
   RS_HIP(hipStreamSynchronize(s));
+  return RS_OK;
+}
+
+// ---- asynchronous host interface: pinned buffers, H2D on the forward stream, D2H on a copy stream behind an event
+void* rs_host_alloc(size_t nbytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, nbytes ? nbytes : 16, hipHostMallocDefault) != hipSuccess) { rs_set_error("hipHostMalloc(%zu) failed", nbytes); return nullptr; }
+  return p;
+}
+void rs_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int rs_engine_upload_async(rs_engine* e, const uint8_t* tiles_host, int n) {
+  RS_CHECK(e && tiles_host && n >= 1 && n <= e->max_batch, RS_ERR_ARG, "bad argument");
+  RS_HIP(hipMemcpyAsync(e->tiles_dev, tiles_host, (size_t)n * e->tile_h * e->tile_w * e->tile_c, hipMemcpyHostToDevice, e->stream));
+  return RS_OK;
+}
+
+int rs_engine_fetch_async(rs_engine* e, int n, rs_dets* o) {
+  RS_CHECK(e && o && o->count && n >= 1 && n <= e->max_batch, RS_ERR_ARG, "bad argument");
+  if (!e->copy_stream) {
+    RS_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    RS_HIP(hipEventCreateWithFlags(&e->ev_results, hipEventDisableTiming));
+    RS_HIP(hipEventCreateWithFlags(&e->ev_copied, hipEventDisableTiming));
+  }
+  const int D = e->D;
+  hipStream_t s = e->copy_stream;
+  RS_HIP(hipEventRecord(e->ev_results, e->stream));          // everything enqueued so far for this engine (its last phase included)
+  RS_HIP(hipStreamWaitEvent(s, e->ev_results, 0));
+  RS_HIP(hipMemcpyAsync(o->count, e->det_count, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  if (o->boxes) RS_HIP(hipMemcpyAsync(o->boxes, e->det_boxes, (size_t)n * D * 16, hipMemcpyDeviceToHost, s));
+  if (o->scores) RS_HIP(hipMemcpyAsync(o->scores, e->det_scores, (size_t)n * D * 4, hipMemcpyDeviceToHost, s));
+  if (o->classes) RS_HIP(hipMemcpyAsync(o->classes, e->det_classes, (size_t)n * D * 4, hipMemcpyDeviceToHost, s));
+  if (o->masks && e->masks) RS_HIP(hipMemcpyAsync(o->masks, e->masks, (size_t)n * D * e->tile_h * ((e->tile_w + 7) / 8), hipMemcpyDeviceToHost, s));
+  RS_HIP(hipEventRecord(e->ev_copied, s));
+  e->copy_pending = true;
+  return RS_OK;
+}
+
+int rs_engine_fetch_wait(rs_engine* e) {
+  RS_CHECK(e, RS_ERR_ARG, "null engine");
+  if (e->copy_stream) RS_HIP(hipStreamSynchronize(e->copy_stream));
   return RS_OK;
 }
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import Any, Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -72,6 +72,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_infer_device.argtypes = [vp, vp, i32]
     lib.rs_engine_infer_phase.argtypes = [vp, vp, i32, i32]
     lib.rs_engine_sync.argtypes = [vp]
+    lib.rs_host_alloc.argtypes = [C.c_size_t]
+    lib.rs_host_alloc.restype = vp
+    lib.rs_host_free.argtypes = [vp]
+    lib.rs_host_free.restype = None
+    lib.rs_engine_upload_async.argtypes = [vp, vp, i32]
+    lib.rs_engine_fetch_async.argtypes = [vp, i32, C.POINTER(RsDets)]
+    lib.rs_engine_fetch_wait.argtypes = [vp]
     lib.rs_engine_fetch.argtypes = [vp, i32, C.POINTER(RsDets)]
     lib.rs_engine_stream.argtypes = [vp]
     lib.rs_engine_stream.restype = vp
@@ -241,14 +248,27 @@ class Engine:
         self._alloc_out(self.max_batch)
 
     # ------------------------------------------------------------------ plumbing
+    def _pinned(self, shape: Tuple[int, ...], dtype) -> np.ndarray:
+        """numpy array over pinned host memory (rs_host_alloc): device<->host copies run at PCIe speed and asynchronously."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = self.lib.rs_host_alloc(max(nbytes, 16))
+        if not ptr:
+            raise RsError(f"rs_host_alloc({nbytes}) failed")
+        self._pinned_ptrs.append(ptr)
+        a = np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(ptr))[:nbytes].view(dtype).reshape(shape)
+        a[...] = 0
+        return a
+
     def _alloc_out(self, n: int) -> None:
         D, h, wb = self.D, self.tile_h, (self.tile_w + 7) // 8
-        self._count = np.zeros(n, np.int32)
-        self._boxes = np.zeros((n, D, 4), np.float32)
-        self._scores = np.zeros((n, D), np.float32)
-        self._classes = np.zeros((n, D), np.int32)
-        self._masks = np.zeros((n, D, h, wb), np.uint8) if self.spec.mask_on else None
+        self._pinned_ptrs: List[int] = []
+        self._count = self._pinned((n,), np.int32)
+        self._boxes = self._pinned((n, D, 4), np.float32)
+        self._scores = self._pinned((n, D), np.float32)
+        self._classes = self._pinned((n, D), np.int32)
+        self._masks = self._pinned((n, D, h, wb), np.uint8) if self.spec.mask_on else None
         self._probs = np.zeros((n, D, MASK_SIDE, MASK_SIDE), np.float32) if self.spec.mask_on else None
+        self._stage_tiles = self._pinned((n, self.tile_h, self.tile_w, self.tile_c), np.uint8)
 
     def _dets_struct(self, want_probs: bool) -> RsDets:
         d = RsDets()
@@ -285,6 +305,24 @@ class Engine:
         rc = self.lib.rs_engine_infer(self._h, tiles.ctypes.data_as(C.c_void_p), n, C.byref(d))
         _check(self.lib, rc, "rs_engine_infer")
         return self._collect(n, want_probs)
+
+    # ------------------------------------------------------------------ asynchronous host interface
+    def upload_async(self, tiles: np.ndarray) -> int:
+        """Stage ``tiles`` in pinned memory and enqueue their upload on the engine's stream; returns the device pointer."""
+        n = tiles.shape[0]
+        if tiles.dtype != np.uint8 or tiles.shape[1:] != (self.tile_h, self.tile_w, self.tile_c) or not 1 <= n <= self.max_batch:
+            raise ValueError(f"tiles must be uint8 (<= {self.max_batch},{self.tile_h},{self.tile_w},{self.tile_c}), got {tiles.dtype} {tiles.shape}")
+        self._stage_tiles[:n] = tiles
+        _check(self.lib, self.lib.rs_engine_upload_async(self._h, self._stage_tiles.ctypes.data_as(C.c_void_p), n), "rs_engine_upload_async")
+        return self.tensor_ptr("tiles")[0]
+
+    def fetch_async(self, n: int) -> None:
+        d = self._dets_struct(False)
+        _check(self.lib, self.lib.rs_engine_fetch_async(self._h, n, C.byref(d)), "rs_engine_fetch_async")
+
+    def fetch_wait(self, n: int) -> List[Instances]:
+        _check(self.lib, self.lib.rs_engine_fetch_wait(self._h), "rs_engine_fetch_wait")
+        return self._collect(n, False)
 
     def infer_device(self, tiles_dev_ptr: int, n: int) -> None:
         """Enqueue a forward on tiles already in device memory (no wait)."""
@@ -368,6 +406,11 @@ class Engine:
         if getattr(self, "_h", None):
             self.lib.rs_engine_destroy(self._h)
             self._h = None
+            for name in ("_count", "_boxes", "_scores", "_classes", "_masks", "_stage_tiles"):
+                setattr(self, name, None)             # views over the pinned memory freed below
+            for p in getattr(self, "_pinned_ptrs", []):
+                self.lib.rs_host_free(p)
+            self._pinned_ptrs = []
 
     def __del__(self) -> None:
         try:
@@ -424,6 +467,50 @@ class LanePipeline:
     def flush(self) -> None:
         """Enqueue the outstanding mask-head phase; after this every submitted batch is fully enqueued."""
         self._finish_pending()
+
+    def run(self, batches) -> "Iterator[List[Instances]]":
+        """Stream host batches ((n,h,w,c) uint8 arrays) through the lanes and yield their detections in order.  Uploads go
+        through pinned staging on the wide stream, every batch's results come back on its lane's copy stream behind an event,
+        and the generator runs two batches ahead of what it yields, so host-side collection overlaps the GPU:
+            submit(k): upload(k), phase0(k), phase2(k-1) + fetch_async(k-1), phase1(k);   then collect + yield batch k-2."""
+        L = len(self.engines)
+        inflight = []                               # (lane, n) of submitted batches not yet yielded
+        for tiles in batches:
+            n = int(tiles.shape[0])
+            lane = self.k % L
+            e = self.engines[lane]
+            self.k += 1
+            if L == 1:                              # one lane has one set of host buffers: no look-ahead
+                e.infer_device(e.upload_async(np.ascontiguousarray(tiles)), n)
+                e.fetch_async(n)
+                yield e.fetch_wait(n)
+                continue
+            done = None
+            if len(inflight) == L:
+                # this lane's previous batch: its result copy was enqueued one submit ago; once it has landed the lane's pinned
+                # staging buffer (upload) is free again.  The other lane's batch keeps the GPU busy meanwhile.
+                ol, on = inflight.pop(0)
+                _check(self.engines[ol].lib, self.engines[ol].lib.rs_engine_fetch_wait(self.engines[ol]._h), "rs_engine_fetch_wait")
+                done = (ol, on)
+            ptr = e.upload_async(np.ascontiguousarray(tiles))
+            e.infer_phase(ptr, n, 0)
+            if self._pending is not None:
+                pl, pp, pn = self._pending
+                self.engines[pl].infer_phase(pp, pn, 2)
+                self.engines[pl].fetch_async(pn)
+                self._pending = None
+            e.infer_phase(ptr, n, 1)
+            self._pending = (lane, ptr, n)
+            inflight.append((lane, n))
+            if done is not None:                    # host-side collection overlaps the batches just enqueued; this lane's next
+                yield self.engines[done[0]]._collect(done[1], False)      # fetch_async comes one submit later
+        if self._pending is not None:
+            pl, pp, pn = self._pending
+            self.engines[pl].infer_phase(pp, pn, 2)
+            self.engines[pl].fetch_async(pn)
+            self._pending = None
+        for ol, on in inflight:
+            yield self.engines[ol].fetch_wait(on)
 
     def sync(self) -> None:
         self.flush()

@@ -272,6 +272,29 @@ def test_lane_pipeline_equals_single_engine(small):
         pipe.close()
 
 
+def test_lane_pipeline_streaming_host_interface(small):
+    """LanePipeline.run: host batches in, detections out, two batches of look-ahead, pinned staging + asynchronous result
+    copies (rs_engine_upload_async / fetch_async / fetch_wait) -- same detections as the synchronous single engine, in order,
+    including a ragged last batch; also with a single lane."""
+    from proj_roadsurf_amd.engine import LanePipeline
+    spec, W, tiles, eng, _ = small
+    batches = [synthetic_tiles(3 if k != 6 else 2, 256, 256, 3, seed=900 + k) for k in range(7)]
+    want = [eng.infer(b) for b in batches]
+    for lanes in (2, 1):
+        pipe = LanePipeline(spec, W, (256, 256, 3), max_batch=4, lanes=lanes)
+        try:
+            got = list(pipe.run(iter(batches)))
+            assert len(got) == len(want)
+            for w_b, g_b in zip(want, got):
+                assert len(w_b) == len(g_b)
+                for a, b in zip(w_b, g_b):
+                    assert len(a) == len(b) and len(a) > 0
+                    assert np.array_equal(a.pred_boxes, b.pred_boxes) and np.array_equal(a.scores, b.scores)
+                    assert np.array_equal(a.pred_classes, b.pred_classes) and np.array_equal(a._packed, b._packed)
+        finally:
+            pipe.close()
+
+
 def test_full_size_512_tile(gpu_required):
     """BASELINE config 1/2 geometry: 512x512x3 tiles -> 800x800 network input, 1000 proposals, 100 detections.
     fp16 production mode vs fp32 oracle is a STATISTICAL comparison on this random-weight workload (a single
