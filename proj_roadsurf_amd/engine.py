@@ -524,36 +524,44 @@ class LanePipeline:
 
 class Predictor:
     """Drop-in for ``detectron2.engine.DefaultPredictor``: ``predictor(im_bgr) -> {"instances": Instances}``.
-    One engine is built per tile shape on first use (tilesets are single-shape: 256^2/512^2 z18 tiles,
-    R:config/config_obj_detec.yaml:45).  ``predict_batch`` is the batched form the CLI shim uses."""
+    One two-lane pipeline is built per tile shape on first use (tilesets are single-shape: 256^2/512^2 z18 tiles,
+    R:config/config_obj_detec.yaml:45).  ``predict_batch`` is the batched, streaming form the CLI shim uses."""
 
-    def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], max_batch: int = 16, device: int = 0):
-        self.spec, self.weights, self.max_batch, self.device = spec, weights, max_batch, device
-        self._engines: Dict[Tuple[int, int, int], Engine] = {}
+    def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], max_batch: int = 16, device: int = 0, lanes: int = 2):
+        self.spec, self.weights, self.max_batch, self.device, self.lanes = spec, weights, max_batch, device, lanes
+        self._pipes: Dict[Tuple[int, int, int], LanePipeline] = {}
 
-    def _engine(self, shape: Tuple[int, int, int]) -> Engine:
-        if shape not in self._engines:
-            self._engines[shape] = Engine(self.spec, self.weights, shape, self.max_batch, self.device)
-        return self._engines[shape]
+    def _pipe(self, shape: Tuple[int, int, int]) -> LanePipeline:
+        if shape not in self._pipes:
+            self._pipes[shape] = LanePipeline(self.spec, self.weights, shape, self.max_batch, self.device, self.lanes)
+        return self._pipes[shape]
 
     def __call__(self, original_image: np.ndarray) -> Dict[str, Instances]:
         if original_image.ndim != 3:
             raise ValueError("expected an HWC image")
-        eng = self._engine(tuple(original_image.shape))
+        eng = self._pipe(tuple(original_image.shape)).engines[0]
         return {"instances": eng.infer(original_image[None])[0]}
 
     def predict_batch(self, images: Sequence[np.ndarray]) -> List[Dict[str, Instances]]:
+        """Any number of images; runs of equal shape are cut into batches of ``max_batch`` and streamed through the lanes
+        (``LanePipeline.run``: uploads, forwards and result copies of consecutive batches overlap)."""
         out: List[Dict[str, Instances]] = []
         i = 0
         while i < len(images):
             shape = tuple(images[i].shape)
             j = i
-            while j < len(images) and j - i < self.max_batch and tuple(images[j].shape) == shape:
+            while j < len(images) and tuple(images[j].shape) == shape:
                 j += 1
-            res = self._engine(shape).infer(np.stack(images[i:j]))
-            out.extend({"instances": r} for r in res)
+            chunks = (np.stack(images[k:min(k + self.max_batch, j)]) for k in range(i, j, self.max_batch))
+            for res in self._pipe(shape).run(chunks):
+                out.extend({"instances": r} for r in res)
             i = j
         return out
+
+    def close(self) -> None:
+        for p in self._pipes.values():
+            p.close()
+        self._pipes.clear()
 
 
 class Trainer:
