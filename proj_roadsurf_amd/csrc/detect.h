@@ -21,6 +21,7 @@ struct RpnParams {
   int* cand_count;          // [N][L]
   int* cand_index;          // optional [N][L][1024]: anchor index (y*W+x)*A+a
   int debug;                // timing experiments only: stop after phase <debug>
+  int cand_cap;             // candidate slots per (image, level): 0/1024 (inference) or 2048 (training, PRE_NMS_TOPK_TRAIN 2000)
 };
 
 struct NmsParams {
@@ -31,6 +32,7 @@ struct NmsParams {
   int cap;                  // 1024
   float thresh;
   int debug;                // timing experiments only: 1 = skip the scan, 2 = skip the mask build
+  unsigned long long* scratch;   // cap > 1024: [segments][2048][32] suppression-mask words in global memory
 };
 
 struct RpnMergeParams {
@@ -39,6 +41,7 @@ struct RpnMergeParams {
   const uint8_t* keep;
   const int* cand_count;
   int L, post_topk, cap;
+  int cand_cap;             // 0/1024 or 2048: slots per (image, level) of the candidate arrays
   float* prop_boxes;        // [N][cap][4]
   float* prop_scores;       // [N][cap]
   int* prop_level;          // optional [N][cap]

@@ -77,8 +77,10 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // ---------------------------------------------------------------------------------------------
 // RPN: select + decode
 // ---------------------------------------------------------------------------------------------
+// CAP = candidate capacity per (image, level): 1024 (inference, PRE_NMS_TOPK_TEST 1000) or 2048 (training, PRE_NMS_TOPK_TRAIN 2000)
+template <int CAP>
 __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
-  __shared__ unsigned long long list[1024];
+  __shared__ unsigned long long list[CAP];
   __shared__ int hist[256];
   __shared__ int hist16[16 * 257];
   __shared__ unsigned int sh_prefix, sh_need, sh_cnt, sh_idx_thr, sh_ccount, sh_tie;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
   // Scan A: ordered keys to scratch + histogram of the top 8 bits.
   if (tid < 256) hist[tid] = 0;
   if (tid == 0) { sh_prefix = 0; sh_need = (unsigned)k; sh_cnt = 0; sh_ccount = 0; sh_idx_thr = 0xFFFFFFFFu; }
-  list[tid] = 0ull;
+  for (int i = tid; i < CAP; i += 1024) list[i] = 0ull;
   __syncthreads();
   // Logits share sign and exponent, so the top digit hits a handful of bins: 16 privatised, bank-
   // staggered sub-histograms cut the same-address serialisation of the LDS atomics 16-fold.
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
         const uint32_t top = key >> 24;
         if (top > b0) {
           const unsigned pos = atomicAdd(&sh_cnt, 1u);
-          if (pos < 1024u) list[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e);
+          if (pos < (unsigned)CAP) list[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e);
         } else if (top == b0) {
           const unsigned c = atomicAdd(&sh_ccount, 1u);
           cidx[c] = (uint32_t)e;
@@ -226,18 +228,18 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     const uint32_t key = keys[e];
     if (key > T || (key == T && e <= idx_thr)) {
       const unsigned pos = atomicAdd(&sh_cnt, 1u);
-      if (pos < 1024u) list[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - e);
+      if (pos < (unsigned)CAP) list[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - e);
     }
   }
   __syncthreads();
   if (p.debug == 5) return;
-  bitonic_sort_desc<1024>(list, 1024, tid);
+  bitonic_sort_desc<1024>(list, CAP, tid);
   if (p.debug == 6) return;
 
-  const long long ob = ((long long)n * p.L + l) * 1024;
+  const long long ob = ((long long)n * p.L + l) * CAP;
   if (tid == 0) p.cand_count[n * p.L + l] = k;
-  if (tid < k) {
-    const unsigned long long c = list[tid];
+  for (int ti = tid; ti < k; ti += 1024) {
+    const unsigned long long c = list[ti];
     const uint32_t e = 0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull);
     const float score = fkey_inv((uint32_t)(c >> 32));
     const int pix = e / A, a = e - pix * A;
@@ -253,37 +255,41 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     b[1] = clampf(b[1], 0.f, p.img_h);
     b[2] = clampf(b[2], 0.f, p.img_w);
     b[3] = clampf(b[3], 0.f, p.img_h);
-    float* ob4 = p.cand_boxes + (ob + tid) * 4;
+    float* ob4 = p.cand_boxes + (ob + ti) * 4;
     ob4[0] = b[0]; ob4[1] = b[1]; ob4[2] = b[2]; ob4[3] = b[3];
-    p.cand_scores[ob + tid] = score;
-    p.cand_valid[ob + tid] = ((b[2] - b[0]) > p.min_size && (b[3] - b[1]) > p.min_size) ? 1 : 0;
-    if (p.cand_index) p.cand_index[ob + tid] = (int)e;
+    p.cand_scores[ob + ti] = score;
+    p.cand_valid[ob + ti] = ((b[2] - b[0]) > p.min_size && (b[3] - b[1]) > p.min_size) ? 1 : 0;
+    if (p.cand_index) p.cand_index[ob + ti] = (int)e;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// NMS over a segment of <= 1024 boxes already in priority order
+// NMS over a segment of <= CAP boxes already in priority order.  CAP 1024: the suppression mask (128 KB) lives in LDS;
+// CAP 2048 (training, PRE_NMS_TOPK_TRAIN 2000): 512 KB per segment in a global scratch buffer (L2-resident).
 // ---------------------------------------------------------------------------------------------
+template <int CAP>
 __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
+  constexpr int WPR = CAP / 64;                                       // mask words per row
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4* sbox = (float4*)smem;                                       // 1024 * 16
-  float* sarea = (float*)(smem + 1024 * 16);                          // 1024 * 4
-  unsigned long long* mask = (unsigned long long*)(smem + 1024 * 20); // 1024 * 16 * 8
-  unsigned long long* sremoved = (unsigned long long*)(smem + 1024 * 20 + 1024 * 128);   // 16 * 8
+  float4* sbox = (float4*)smem;                                       // CAP * 16
+  float* sarea = (float*)(smem + CAP * 16);                           // CAP * 4
+  unsigned long long* sremoved = (unsigned long long*)(smem + CAP * 20);   // WPR * 8
   const int s = blockIdx.x, tid = threadIdx.x;
+  unsigned long long* mask = CAP == 1024 ? (unsigned long long*)(smem + CAP * 20 + 256)
+                                         : p.scratch + (long long)s * CAP * WPR;
   int n = p.count[s];
-  if (n > 1024) n = 1024;
+  if (n > CAP) n = CAP;
   const float* boxes = p.boxes + (long long)s * p.cap * 4;
   const uint8_t* valid = p.valid ? p.valid + (long long)s * p.cap : nullptr;
   uint8_t* keep = p.keep + (long long)s * p.cap;
   for (int i = tid; i < p.cap; i += 1024) keep[i] = 0;
-  if (tid < 16) sremoved[tid] = 0ull;
+  if (tid < WPR) sremoved[tid] = 0ull;
   __syncthreads();
-  if (tid < n) {
-    const float4 b = *(const float4*)(boxes + tid * 4);
-    sbox[tid] = b;
-    sarea[tid] = (b.z - b.x) * (b.w - b.y);
-    if (valid && !valid[tid]) atomicOr(&sremoved[tid >> 6], 1ull << (tid & 63));
+  for (int ti = tid; ti < n; ti += 1024) {
+    const float4 b = *(const float4*)(boxes + ti * 4);
+    sbox[ti] = b;
+    sarea[ti] = (b.z - b.x) * (b.w - b.y);
+    if (valid && !valid[ti]) atomicOr(&sremoved[ti >> 6], 1ull << (ti & 63));
   }
   __syncthreads();
   const int nw = (n + 63) >> 6;
@@ -335,20 +341,21 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
       }
       bits = ((unsigned long long)hi << 32) | lo;
     }
-    mask[(long long)i * 16 + w] = bits;
+    mask[(long long)i * WPR + w] = bits;
   }
+  if (CAP != 1024) __threadfence();       // mask rows in global memory: visible to the scanning wave after the barrier
   __syncthreads();
   // Greedy scan, one wave, 64 boxes (one mask word) per step: the intra-chunk part is resolved on
   // the scalar unit from the diagonal words (lane b holds row b), then the rows of the survivors
   // are OR-ed into the later words by all 64 lanes in parallel.
   if (tid < 64 && p.debug != 1) {
     const int lane = tid;
-    unsigned long long removed = lane < 16 ? sremoved[lane] : 0ull;   // lane w holds word w
+    unsigned long long removed = lane < WPR ? sremoved[lane] : 0ull;   // lane w holds word w
     for (int c = 0; c < nw; ++c) {
       const int base = c * 64;
       const int cnt = (n - base) < 64 ? (n - base) : 64;
       const unsigned long long rem_c = __shfl(removed, c);
-      const unsigned long long diag = lane < cnt ? mask[(long long)(base + lane) * 16 + c] : 0ull;
+      const unsigned long long diag = lane < cnt ? mask[(long long)(base + lane) * WPR + c] : 0ull;
       const int dlo = (int)(unsigned)(diag & 0xFFFFFFFFull), dhi = (int)(unsigned)(diag >> 32);
       unsigned long long alive = ~rem_c;
       if (cnt < 64) alive &= (1ull << cnt) - 1ull;
@@ -365,15 +372,15 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
         al &= ~(1ull << b);
       }
       if (lane < cnt) keep[base + lane] = (uint8_t)((kept >> lane) & 1ull);
-      const int w = lane & 15;
+      const int w = lane & (WPR - 1);
       unsigned long long part = 0ull;
       if (w > c && w < nw) {
-        for (int b = lane >> 4; b < cnt; b += 4)
-          if ((kept >> b) & 1ull) part |= mask[(long long)(base + b) * 16 + w];
+        for (int b = lane / WPR; b < cnt; b += 64 / WPR)
+          if ((kept >> b) & 1ull) part |= mask[(long long)(base + b) * WPR + w];
       }
-      part |= __shfl_xor(part, 16);
+      if (WPR == 16) part |= __shfl_xor(part, 16);
       part |= __shfl_xor(part, 32);
-      if (lane < 16) removed |= part;
+      if (lane < WPR) removed |= part;
     }
   }
 }
@@ -381,37 +388,39 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
 // ---------------------------------------------------------------------------------------------
 // RPN: merge levels (score desc, ties: lower (level, rank) first), keep post_topk
 // ---------------------------------------------------------------------------------------------
+template <int CAP>
 __global__ __launch_bounds__(1024) void rpn_merge_kernel(const RpnMergeParams p) {
+  constexpr int SORTN = CAP * 8;                          // up to 8 levels' candidates (power of two for the bitonic sort)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* list = (unsigned long long*)smem;   // 8192
+  unsigned long long* list = (unsigned long long*)smem;   // SORTN
   __shared__ unsigned int cnt;
   const int n = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) cnt = 0;
-  for (int i = tid; i < 8192; i += 1024) list[i] = 0ull;
+  for (int i = tid; i < SORTN; i += 1024) list[i] = 0ull;
   __syncthreads();
   for (int l = 0; l < p.L; ++l) {
     const int c = p.cand_count[n * p.L + l];
-    const long long ob = ((long long)n * p.L + l) * 1024;
+    const long long ob = ((long long)n * p.L + l) * CAP;
     for (int i = tid; i < c; i += 1024) {
       if (p.keep[ob + i]) {
         const unsigned pos = atomicAdd(&cnt, 1u);
-        list[pos] = ((unsigned long long)fkey(p.cand_scores[ob + i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(l * 1024 + i));
+        list[pos] = ((unsigned long long)fkey(p.cand_scores[ob + i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(l * CAP + i));
       }
     }
   }
   __syncthreads();
-  bitonic_sort_desc<1024>(list, 8192, tid);
+  bitonic_sort_desc<1024>(list, SORTN, tid);
   const int total = (int)cnt < p.post_topk ? (int)cnt : p.post_topk;
   if (tid == 0) p.prop_count[n] = total;
   for (int i = tid; i < p.cap; i += 1024) {
     float* o = p.prop_boxes + ((long long)n * p.cap + i) * 4;
     if (i < total) {
       const uint32_t pos = 0xFFFFFFFFu - (uint32_t)(list[i] & 0xFFFFFFFFull);
-      const long long src = (long long)n * p.L * 1024 + pos;
+      const long long src = (long long)n * p.L * CAP + pos;
       const float* b = p.cand_boxes + src * 4;
       o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
       p.prop_scores[(long long)n * p.cap + i] = p.cand_scores[src];
-      if (p.prop_level) p.prop_level[(long long)n * p.cap + i] = (int)(pos >> 10);
+      if (p.prop_level) p.prop_level[(long long)n * p.cap + i] = (int)(pos / CAP);
     } else {
       o[0] = o[1] = o[2] = o[3] = 0.f;
       p.prop_scores[(long long)n * p.cap + i] = 0.f;
@@ -1099,37 +1108,46 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
 
 // ----------------------------------------------------------------------------------------------- launchers
 int launch_rpn_select(const RpnParams& p, hipStream_t s) {
-  RS_CHECK(p.topk <= 1024 && p.A <= RS_MAX_ANCHORS && p.L <= RS_MAX_LEVELS, RS_ERR_UNSUPPORTED, "rpn: topk %d / A %d / L %d out of range", p.topk, p.A, p.L);
+  const int cap = p.cand_cap ? p.cand_cap : 1024;
+  RS_CHECK((cap == 1024 || cap == 2048) && p.topk <= cap && p.A <= RS_MAX_ANCHORS && p.L <= RS_MAX_LEVELS, RS_ERR_UNSUPPORTED,
+           "rpn: topk %d / capacity %d / A %d / L %d out of range", p.topk, cap, p.A, p.L);
   RpnParams q = p;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("RS_SELECT_DEBUG"); dbg = e ? atoi(e) : 0; } q.debug = dbg; }
-  hipLaunchKernelGGL(rpn_select_kernel, dim3(p.L, p.N), dim3(1024), 0, s, q);
+  if (cap == 1024) hipLaunchKernelGGL(rpn_select_kernel<1024>, dim3(p.L, p.N), dim3(1024), 0, s, q);
+  else hipLaunchKernelGGL(rpn_select_kernel<2048>, dim3(p.L, p.N), dim3(1024), 0, s, q);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
 
 int launch_nms(const NmsParams& p, int segments, hipStream_t s) {
-  const int lds = 1024 * 20 + 1024 * 128 + 128;
+  const int lds = 1024 * 20 + 256 + 1024 * 128;
+  const int lds_big = 2048 * 20 + 256;
   static bool done = false;
   if (!done) {
-    RS_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    RS_HIP(hipFuncSetAttribute((const void*)nms_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    RS_HIP(hipFuncSetAttribute((const void*)nms_kernel<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
     done = true;
   }
-  RS_CHECK(p.cap >= 1024 || p.cap > 0, RS_ERR_ARG, "nms: cap");
+  RS_CHECK(p.cap > 0 && p.cap <= 2048 && (p.cap <= 1024 || p.scratch), RS_ERR_ARG, "nms: capacity %d (more than 1024 boxes need NmsParams::scratch)", p.cap);
   NmsParams q = p;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("RS_NMS_DEBUG"); dbg = e ? atoi(e) : 0; } q.debug = dbg; }
-  hipLaunchKernelGGL(nms_kernel, dim3(segments), dim3(1024), lds, s, q);
+  if (p.cap <= 1024) hipLaunchKernelGGL(nms_kernel<1024>, dim3(segments), dim3(1024), lds, s, q);
+  else hipLaunchKernelGGL(nms_kernel<2048>, dim3(segments), dim3(1024), lds_big, s, q);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
 
 int launch_rpn_merge(const RpnMergeParams& p, int N, hipStream_t s) {
-  RS_CHECK(p.L * 1024 <= 8192, RS_ERR_UNSUPPORTED, "rpn merge: too many levels");
+  const int cap = p.cand_cap ? p.cand_cap : 1024;
+  RS_CHECK(p.L <= 8 && (cap == 1024 || cap == 2048), RS_ERR_UNSUPPORTED, "rpn merge: %d levels / capacity %d", p.L, cap);
   static bool done = false;
   if (!done) {
-    RS_HIP(hipFuncSetAttribute((const void*)rpn_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    RS_HIP(hipFuncSetAttribute((const void*)rpn_merge_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    RS_HIP(hipFuncSetAttribute((const void*)rpn_merge_kernel<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     done = true;
   }
-  hipLaunchKernelGGL(rpn_merge_kernel, dim3(N), dim3(1024), 65536, s, p);
+  if (cap == 1024) hipLaunchKernelGGL(rpn_merge_kernel<1024>, dim3(N), dim3(1024), 65536, s, p);
+  else hipLaunchKernelGGL(rpn_merge_kernel<2048>, dim3(N), dim3(1024), 131072, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

@@ -517,7 +517,7 @@ int rs_engine::build() {
     stages.push_back(st);
   }
   {
-    NmsParams np;
+    NmsParams np = {};
     np.boxes = rp.cand_boxes; np.count = rp.cand_count; np.valid = rp.cand_valid; np.keep = cand_keep; np.cap = 1024;
     np.thresh = S.rpn_nms_thresh;
     Stage st;
@@ -537,7 +537,7 @@ int rs_engine::build() {
   reg("proposal_level", prop_level, DT_I32, {NB, PC}, 0);
   reg("proposal_count", prop_count, DT_I32, {NB}, 0);
   {
-    RpnMergeParams mp;
+    RpnMergeParams mp = {};
     mp.cand_boxes = rp.cand_boxes; mp.cand_scores = rp.cand_scores; mp.keep = cand_keep; mp.cand_count = rp.cand_count;
     mp.L = L; mp.post_topk = S.rpn_post_nms_topk; mp.cap = PC;
     mp.prop_boxes = prop_boxes; mp.prop_scores = prop_scores; mp.prop_level = prop_level; mp.prop_count = prop_count;
@@ -632,7 +632,7 @@ int rs_engine::build() {
     stages.push_back(st);
   }
   {
-    NmsParams np;
+    NmsParams np = {};
     np.boxes = bc.seg_boxes; np.count = bc.seg_count; np.valid = nullptr; np.keep = seg_keep; np.cap = 1024; np.thresh = S.nms_thresh_test;
     Stage st;
     st.name = "box.nms";
@@ -1291,10 +1291,17 @@ int rs_op_conv2d_wgrad(const void* dy, const void* x, float* grad, const float* 
 int rs_op_nms(const float* boxes, const int32_t* counts, const uint8_t* valid, uint8_t* keep, int segments, int cap,
               float thresh, void* stream) {
   RS_CHECK(boxes && counts && keep && segments > 0, RS_ERR_ARG, "bad argument");
-  RS_CHECK(cap >= 1 && cap <= 1024, RS_ERR_ARG, "cap %d outside [1,1024]", cap);
-  NmsParams p;
+  RS_CHECK(cap >= 1 && cap <= 2048, RS_ERR_ARG, "cap %d outside [1,2048]", cap);
+  NmsParams p = {};
   p.boxes = boxes; p.count = counts; p.valid = valid; p.keep = keep; p.cap = cap; p.thresh = thresh;
-  return launch_nms(p, segments, (hipStream_t)stream);
+  void* scratch = nullptr;
+  if (cap > 1024) {            // training capacity: the suppression mask lives in global memory
+    RS_HIP(hipMalloc(&scratch, (size_t)segments * 2048 * 32 * 8));
+    p.scratch = (unsigned long long*)scratch;
+  }
+  int rc = launch_nms(p, segments, (hipStream_t)stream);
+  if (scratch) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(scratch); }
+  return rc;
 }
 
 int rs_op_roi_align(const void* const feats[4], const int32_t heights[4], const int32_t widths[4], const float scales[4],

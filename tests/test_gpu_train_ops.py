@@ -507,3 +507,34 @@ def test_subsample_is_a_valid_uniform_sample(gpu_required):
     p_sel = (512 - min(nfg, 128)) / int(bgmask.sum())
     z = (hits[bgmask] - trials * p_sel) / math.sqrt(trials * p_sel * (1 - p_sel))
     assert float(z.abs().max()) < 5.0 and abs(float(z.mean())) < 0.2
+
+
+@pytest.mark.parametrize("cap", [1024, 2048])
+def test_nms_operator_both_capacities(gpu_required, cap):
+    """rs_op_nms == the oracle's greedy NMS (torchvision semantics, IoU > thr suppresses), exactly: capacity 1024 (inference, mask in
+    LDS) and 2048 (training, PRE_NMS_TOPK_TRAIN 2000, mask in global scratch); full, ragged, tiny and empty segments, a validity
+    mask, heavily overlapping boxes."""
+    from oracle import maskrcnn_oracle as O
+    lib = load_library()
+    g = torch.Generator().manual_seed(cap)
+    counts = [cap, cap - 37, 700, 65, 1, 0]
+    S = len(counts)
+    boxes = torch.zeros(S, cap, 4)
+    valid = torch.ones(S, cap, dtype=torch.uint8)
+    for s_, c in enumerate(counts):
+        ctr = torch.rand(c, 2, generator=g) * 300                 # dense: many overlaps around the threshold
+        wh = torch.rand(c, 2, generator=g) * 80 + 20
+        boxes[s_, :c] = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    valid[1, ::7] = 0
+    bd, cd, vd = _dev(boxes), _dev(torch.tensor(counts, dtype=torch.int32)), _dev(valid)
+    keep = torch.full((S, cap), 7, dtype=torch.uint8, device=bd.device)
+    _check(lib, lib.rs_op_nms(_ptr(bd), _ptr(cd), _ptr(vd), _ptr(keep), S, cap, 0.7, None), "rs_op_nms")
+    torch.cuda.synchronize()
+    k = keep.cpu().numpy()
+    for s_, c in enumerate(counts):
+        b = boxes[s_, :c].numpy()
+        v = valid[s_, :c].numpy().astype(bool)
+        want = np.zeros(c, bool)
+        want[np.nonzero(v)[0][O.nms_sorted_np(b[v], 0.7)]] = True
+        assert np.array_equal(k[s_, :c].astype(bool), want), (cap, s_, c)
+        assert (k[s_, c:] == 0).all()
