@@ -287,8 +287,8 @@ int rs_trainer_set_targets(rs_trainer* t, const float* gt_boxes, const int32_t* 
  * the caller's "rpn_labels" / "rpn_matched" (parity tests feed the oracle's sample). */
 int rs_trainer_rpn_step(rs_trainer* t, int n, uint32_t seed, int external_labels);
 /* RPN head forward alone (rs_trainer_rpn_step runs it itself), then the RoI box head of the training step:
- * RPN proposals (engine's test-time top-k/NMS capacities: 1000 per level -- R:250 asks 2000 before NMS in training, a documented
- * deviation) + gt boxes (R:193), Matcher at 0.5, subsample_labels (1024 @ 0.25, R:178,192), box-head forward on the sample,
+ * RPN proposals in training mode (PRE_NMS_TOPK_TRAIN 2000 per level, NMS 0.7, POST_NMS_TOPK_TRAIN 1000 per image: R:245-250;
+ * rs_trainer_set_rpn_topk overrides) + gt boxes (R:193), Matcher at 0.5, subsample_labels (1024 @ 0.25, R:178,192), box-head forward on the sample,
  * loss_cls / loss_box_reg into "losses"[2..3], backward of predictor/fc2/fc1 and RoIAlign into "d32:p2".."d32:p5".  Call order of a
  * full step: forward_trunk, rpn_forward, roi_step, rpn_step, backward_trunk, apply_sgd. */
 int rs_trainer_rpn_forward(rs_trainer* t, int n);
@@ -300,6 +300,7 @@ int rs_trainer_roi_step(rs_trainer* t, int n, uint32_t seed);
  * rasterises the polygons on the host at the same point ([EXT d2: structures/masks.py PolygonMasks.crop_and_resize]). */
 int rs_trainer_mask_forward(rs_trainer* t, int n);
 int rs_trainer_mask_backward(rs_trainer* t, int n, const uint8_t* targets_host, int n_entries);
+int rs_trainer_set_rpn_topk(rs_trainer* t, int pre_nms_topk_train, int post_nms_topk_train);
 /* Sampler sizes (defaults = the reference YAML: 256 @ 0.5 anchors, 1024 @ 0.25 RoIs per image). */
 int rs_trainer_set_sampling(rs_trainer* t, int rpn_batch, float rpn_positive_fraction, int roi_batch, float roi_positive_fraction);
 int rs_trainer_apply_sgd(rs_trainer* t, float lr, float momentum, float weight_decay);

@@ -586,6 +586,7 @@ class Trainer:
         lib.rs_trainer_rpn_forward.argtypes = [vp, i32]
         lib.rs_trainer_roi_step.argtypes = [vp, i32, C.c_uint32]
         lib.rs_trainer_set_sampling.argtypes = [vp, i32, C.c_float, i32, C.c_float]
+        lib.rs_trainer_set_rpn_topk.argtypes = [vp, i32, i32]
         lib.rs_trainer_set_grad_divisor.argtypes = [vp, C.c_float]
         lib.rs_trainer_copy_state.argtypes = [vp, vp]
         lib.rs_trainer_grad_buffer.argtypes = [vp]
@@ -760,6 +761,9 @@ class Trainer:
 
     def set_sampling(self, rpn_batch: int = 256, rpn_positive_fraction: float = 0.5, roi_batch: int = 1024, roi_positive_fraction: float = 0.25) -> None:
         _check(self.lib, self.lib.rs_trainer_set_sampling(self._h, rpn_batch, rpn_positive_fraction, roi_batch, roi_positive_fraction), "rs_trainer_set_sampling")
+
+    def set_rpn_topk(self, pre_nms_topk_train: int = 2000, post_nms_topk_train: int = 1000) -> None:
+        _check(self.lib, self.lib.rs_trainer_set_rpn_topk(self._h, pre_nms_topk_train, post_nms_topk_train), "rs_trainer_set_rpn_topk")
 
     def write_tensor(self, name: str, data: np.ndarray) -> None:
         """Overwrite a whole trainer tensor (no halo handling)."""

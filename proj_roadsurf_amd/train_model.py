@@ -17,8 +17,7 @@ What follows the reference / detectron2 0.6 and where it is pinned:
   * data parallel: one process per GPU, gradients all-reduced over RCCL/xGMI in one flat 175 MB fp32 buffer and averaged
     (DistributedDataParallel semantics).
 Documented deviations: MIN_SIZE_TRAIN's multi-scale "choice" (R:31-38) is drawn once per BATCH, not per image
-(identical at the reference's one image per GPU), RPN proposals use the engine's 1000-per-level capacity before NMS
-(R:250 asks 2000), fp16 activations/weights with fp32 master weights and static loss scaling instead of fp32 everywhere, the
+(identical at the reference's one image per GPU), fp16 activations/weights with fp32 master weights and static loss scaling instead of fp32 everywhere, the
 model-zoo URL of ``model_weights.model_zoo_checkpoint_url`` cannot be fetched offline (use ``model_weights.pth_file`` or
 ``--synthetic-weights``), and the periodic COCO evaluation / validation-loss hooks are not built.
 """

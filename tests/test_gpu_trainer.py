@@ -539,3 +539,40 @@ def test_multi_scale_state_handover(gpu_required):
         assert float(np.abs(b.tensor(f"m:{n}.w") - m_a).max()) > 0
     finally:
         ms.close()
+
+
+def test_training_mode_proposals_match_oracle(gpu_required):
+    """RPN proposals of the TRAINING forward (PRE_NMS_TOPK_TRAIN 2000 per level, NMS 0.7, POST_NMS_TOPK_TRAIN 1000 per image, R:245-250:
+    the 2048-capacity select / NMS / merge kernels) against the oracle's find_top_rpn_proposals on the engine's own head outputs,
+    followed by the appended ground-truth boxes (PROPOSAL_APPEND_GT)."""
+    from oracle import maskrcnn_oracle as O
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=888)
+    tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=64.0)
+    try:
+        gt_boxes = [np.array([[20.0, 30.0, 120.0, 160.0]], np.float32), np.array([[100.0, 100.0, 260.0, 280.0], [10.0, 10.0, 60.0, 50.0]], np.float32)]
+        tr.set_targets(gt_boxes, [np.array([0]), np.array([1, 1])])
+        tr.set_sampling(256, 0.5, 128, 0.25)
+        tr.forward_trunk(tr.upload_tiles(tiles), 2)
+        tr.rpn_forward(2)
+        tr.roi_step(2, seed=1)
+        tr.sync()
+        cand, cc = tr.tensor("roi_candidates"), tr.tensor("roi_candidate_count")
+        A = spec.num_anchors
+        logits, deltas = [], []
+        for l in range(2, 7):
+            h = torch.from_numpy(tr.tensor(f"rpn_head{l}", engine=True))            # (2, H, W, 16)
+            logits.append(h[..., :A].permute(0, 3, 1, 2).contiguous())
+            deltas.append(h[..., A:5 * A].permute(0, 3, 1, 2).contiguous())
+        train_spec = spec.replace(rpn_pre_nms_topk_test=2000, rpn_post_nms_topk_test=1000)
+        props = O.rpn_proposals(train_spec, logits, deltas, [(320, 320)] * 2, nms_trick=False)
+        for i in range(2):
+            pb = props[i]["boxes"].numpy()
+            k = pb.shape[0]
+            assert k > 300                                                             # more than the inference capacity of this config
+            assert int(cc[i]) == k + gt_boxes[i].shape[0]
+            assert float(np.abs(cand[i, :k] - pb).max()) <= 1e-3
+            assert np.array_equal(cand[i, k:k + gt_boxes[i].shape[0]], gt_boxes[i])
+    finally:
+        tr.close()
