@@ -19,7 +19,7 @@ What follows the reference / detectron2 0.6 and where it is pinned:
 Documented deviations: MIN_SIZE_TRAIN's multi-scale "choice" (R:31-38) is drawn once per BATCH, not per image
 (identical at the reference's one image per GPU), fp16 activations/weights with fp32 master weights and static loss scaling instead of fp32 everywhere, the
 model-zoo URL of ``model_weights.model_zoo_checkpoint_url`` cannot be fetched offline (use ``model_weights.pth_file`` or
-``--synthetic-weights``), and the periodic COCO evaluation / validation-loss hooks are not built.
+``--synthetic-weights``), and the periodic COCO AP evaluation is not built (the validation loss every TEST.EVAL_PERIOD is).
 """
 from __future__ import annotations
 
@@ -55,6 +55,7 @@ def load_solver(d2_yaml: str) -> Dict[str, Any]:
         "rpn_batch": int((m.get("RPN", {}) or {}).get("BATCH_SIZE_PER_IMAGE", 256)), "rpn_pos": float((m.get("RPN", {}) or {}).get("POSITIVE_FRACTION", 0.5)),
         "roi_batch": int((m.get("ROI_HEADS", {}) or {}).get("BATCH_SIZE_PER_IMAGE", 512)), "roi_pos": float((m.get("ROI_HEADS", {}) or {}).get("POSITIVE_FRACTION", 0.25)),
         "flip": str((cfg.get("INPUT", {}) or {}).get("RANDOM_FLIP", "horizontal")),
+        "eval_period": int((cfg.get("TEST", {}) or {}).get("EVAL_PERIOD", 0)),
         "min_size_train": tuple(int(x) for x in ((cfg.get("INPUT", {}) or {}).get("MIN_SIZE_TRAIN") or ())),
         "min_size_sampling": str((cfg.get("INPUT", {}) or {}).get("MIN_SIZE_TRAIN_SAMPLING", "choice")),
     }
@@ -148,6 +149,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log-period", type=int, default=20)
+    ap.add_argument("--val-max-images", type=int, default=0, help="cap on the validation images per evaluation (0 = all)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s", stream=sys.stderr)
     with open(args.config_file) as f:
@@ -211,6 +213,38 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         with open(os.path.join(log_dir, "last_checkpoint"), "w") as f:
             f.write(name)
 
+    # validation loss every TEST.EVAL_PERIOD iterations (R:322): the five training losses on the `val` set with the training
+    # forward at the test size, no flip, no update -- what the object-detector's loss-evaluation hook logs as "validation_loss"
+    val_recs: List[Dict[str, Any]] = []
+    if sv["eval_period"] > 0 and cfg["COCO_files"].get("val") and os.path.exists(cfg["COCO_files"]["val"]):
+        val_recs, _ = load_coco_training_set(cfg["COCO_files"]["val"])
+        if args.val_max_images:
+            val_recs = val_recs[: args.val_max_images]
+
+    def validation_loss(it: int) -> Optional[float]:
+        if not val_recs:
+            return None
+        vt = ms.select(sizes[-1])
+        hw = ms.net_shape(sizes[-1])
+        mine = val_recs[rank::world]
+        tot, cnt = 0.0, 0
+        for k in range(0, len(mine), per_rank):
+            chunk = mine[k:k + per_rank]
+            mapped = [map_record(r, read_tile(r["file_name"]), hw, False) for r in chunk]
+            l = vt.train_step(np.stack([m[0] for m in mapped]), [m[1] for m in mapped], [m[2] for m in mapped], [m[3] for m in mapped],
+                              seed=777 + k)                      # gradients are discarded: the next training step overwrites them
+            tot += sum(l.values()) * len(chunk)
+            cnt += len(chunk)
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([tot, float(cnt)], dtype=torch.float64)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t)
+            tot, cnt = float(t[0]), int(t[1])
+        return tot / max(cnt, 1)
+
     t0 = time.time()
     for it in range(max_iter):
         size = int(sizes[int(size_rng.integers(len(sizes)))])
@@ -230,8 +264,11 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         trainer.apply_sgd(lr, sv["momentum"], sv["weight_decay"])
         if not all(np.isfinite(v) for v in losses.values()):
             raise SystemExit(f"iteration {it}: non-finite loss {losses} (lower --loss-scale)")
-        if rank == 0 and ((it + 1) % args.log_period == 0 or it == max_iter - 1):
+        vloss = validation_loss(it) if (sv["eval_period"] > 0 and ((it + 1) % sv["eval_period"] == 0 or it == max_iter - 1)) else None
+        if rank == 0 and ((it + 1) % args.log_period == 0 or it == max_iter - 1 or vloss is not None):
             rec = {"iteration": it, "total_loss": float(sum(losses.values())), "lr": lr, "time": (time.time() - t0) / (it + 1), **losses}
+            if vloss is not None:
+                rec["validation_loss"] = vloss
             metrics.write(json.dumps(rec) + "\n")
             metrics.flush()
             log.info("iter %d  total_loss %.4f  %s  lr %.6f  %.3f s/iter", it, rec["total_loss"],

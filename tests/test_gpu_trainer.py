@@ -433,7 +433,7 @@ def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
                     "MIN_SIZE_TRAIN": [160, 192], "MIN_SIZE_TRAIN_SAMPLING": "choice"},          # multi-scale: two engine geometries
           "MODEL": {"RPN": {"PRE_NMS_TOPK_TEST": 200, "POST_NMS_TOPK_TEST": 200, "BATCH_SIZE_PER_IMAGE": 64}, "ROI_HEADS": {"NUM_CLASSES": 2, "BATCH_SIZE_PER_IMAGE": 64}},
           "SOLVER": {"BASE_LR": 0.002, "IMS_PER_BATCH": 2, "MAX_ITER": 6, "WARMUP_ITERS": 2, "STEPS": [4], "GAMMA": 0.5, "CHECKPOINT_PERIOD": 3},
-          "TEST": {"DETECTIONS_PER_IMAGE": 20}}
+          "TEST": {"DETECTIONS_PER_IMAGE": 20, "EVAL_PERIOD": 3}}
     yaml.safe_dump(d2, open(tmp_path / "d2.yaml", "w"))
     cfg = {"train_model.py": {"working_directory": str(wd), "log_subfolder": "logs", "sample_tagged_img_subfolder": "sample_training_images",
                               "COCO_files": {"trn": "COCO_trn.json", "val": "COCO_trn.json", "tst": "COCO_trn.json"},
@@ -452,6 +452,8 @@ def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
         assert [l["iteration"] for l in lines] == list(range(6))
         assert all(np.isfinite(l["total_loss"]) and l["total_loss"] > 0 for l in lines)
         assert lines[0]["lr"] == pytest.approx(0.002 * 0.001) and lines[3]["lr"] == pytest.approx(0.002) and lines[5]["lr"] == pytest.approx(0.001)
+        assert [("validation_loss" in l) for l in lines] == [False, False, True, False, False, True]       # TEST.EVAL_PERIOD 3
+        assert all(np.isfinite(l["validation_loss"]) and l["validation_loss"] > 0 for l in lines if "validation_loss" in l)
         assert (wd / "logs" / "model_0000002.pth").exists() and open(wd / "logs" / "last_checkpoint").read() == "model_final.pth"
         W1 = load_checkpoint(str(wd / "logs" / "model_final.pth"))
         spec = EngineSpec(num_classes=2)
