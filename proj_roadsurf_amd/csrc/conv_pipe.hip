@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, NW = 8, NT = 512, MI = 4, NJ = 8, WCH = 4;
+constexpr int BM = 256, BN = 256, NT = 512, MI = 4, NJ = 8, WCH = 4;
 constexpr int ROWB = 64;                       // bytes per LDS row (32 fp16 of K)
 constexpr int STAGE = (BM + BN) * ROWB;        // 32 KB
 constexpr int NSTAGE = 4;

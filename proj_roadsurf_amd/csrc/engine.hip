@@ -565,7 +565,7 @@ int rs_engine::build() {
     Stage st;
     st.name = "box.roi_align";
     st.bytes_per_image = (double)PC * PR * PR * 256 * 2 * 2;
-    st.fn = [q, PC](int n, hipStream_t s) mutable { q.S = n * PC; return launch_roi_align(q, s); };
+    st.fn = [q](int n, hipStream_t s) mutable { q.S = n * PC; return launch_roi_align(q, s); };
     stages.push_back(st);
   }
   // FC layers as 1x1 "convs" over a (M x 1) image
@@ -593,7 +593,7 @@ int rs_engine::build() {
     st.name = name;
     st.flops_per_image = 2.0 * PC * (double)in.C * p.Cout;
     st.bytes_per_image = (double)PC * (in.C * 2 + p.Cout * (out32 ? 4 : 2));
-    st.fn = [p, PC, glds, variant](int n, hipStream_t s) mutable { p.M = n * PC; return launch_conv(p, s, variant, glds); };
+    st.fn = [p, glds, variant](int n, hipStream_t s) mutable { p.M = n * PC; return launch_conv(p, s, variant, glds); };
     stages.push_back(st);
     return RS_OK;
   };
@@ -977,21 +977,21 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
 
 void rs_engine_destroy(rs_engine* e) {
   if (!e) return;
-  hipSetDevice(e->device);
-  if (e->stream) hipStreamSynchronize(e->stream);
-  if (e->narrow) { hipStreamSynchronize(e->narrow); hipStreamDestroy(e->narrow); }
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->narrow) { (void)hipStreamSynchronize(e->narrow); (void)hipStreamDestroy(e->narrow); }
   if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
   if (e->ev_results) (void)hipEventDestroy(e->ev_results);
   if (e->ev_copied) (void)hipEventDestroy(e->ev_copied);
-  if (e->ev_join) hipEventDestroy(e->ev_join);
-  for (Stage& st : e->stages) if (st.handoff) hipEventDestroy(st.handoff);
-  for (void* p : e->allocs) hipFree(p);
-  if (e->blob_dev) hipFree(e->blob_dev);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  for (Stage& st : e->stages) if (st.handoff) (void)hipEventDestroy(st.handoff);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->blob_dev) (void)hipFree(e->blob_dev);
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-  for (auto& pr : e->ev_pool) { if (pr.first) hipEventDestroy(pr.first); if (pr.second) hipEventDestroy(pr.second); }
-  if (e->ev0) hipEventDestroy(e->ev0);
-  if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  for (auto& pr : e->ev_pool) { if (pr.first) (void)hipEventDestroy(pr.first); if (pr.second) (void)hipEventDestroy(pr.second); }
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -1207,8 +1207,8 @@ static int op_conv2d(const void* in, const void* w, const float* bias, void* out
   }
   int rc = launch_conv(p, (hipStream_t)stream, variant, use_glds);
   if (koff_dev) {
-    hipStreamSynchronize((hipStream_t)stream);
-    hipFree(koff_dev);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(koff_dev);
   }
   return rc;
 }
@@ -1256,8 +1256,8 @@ int rs_op_conv2d_dgrad(const void* dy, const void* w_t, void* dx, const void* re
   p.out_stride = stride;
   if (down) { p.down_Hp = 2 * hi + 2 * halo; p.down_Wp = 2 * wi + 2 * halo; p.down_Cs = cin; p.down_pad = halo; }
   int rc = launch_conv(p, (hipStream_t)stream, variant, 1);
-  hipStreamSynchronize((hipStream_t)stream);
-  hipFree(zero_bias);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(zero_bias);
   return rc;
 }
 
@@ -1282,9 +1282,9 @@ int rs_op_conv2d_wgrad(const void* dy, const void* x, float* grad, const float* 
   RS_HIP(hipMemsetAsync(partial, 0, (size_t)p.splits * cout * kpad * 4, s));   // K padding columns stay zero
   p.partial = (float*)partial; p.zeros = (const half_t*)zeros;
   int rc = launch_conv_wgrad(p, s);
-  hipStreamSynchronize(s);
-  hipFree(partial);
-  hipFree(zeros);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(partial);
+  (void)hipFree(zeros);
   return rc;
 }
 
@@ -1374,7 +1374,7 @@ int rs_op_match(const float* boxes, int per_image_boxes, const int32_t* box_coun
     p.gt_best = (unsigned int*)scratch;
   }
   int rc = launch_match(p, n_images, (hipStream_t)stream);
-  if (scratch) { hipStreamSynchronize((hipStream_t)stream); hipFree(scratch); }
+  if (scratch) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(scratch); }
   return rc;
 }
 
