@@ -53,7 +53,7 @@ def cpu_baseline(spec, W, tiles, max_seconds=30.0):
             break
     dt = time.time() - t0
     return {"value": n / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 512x512x3 tile(s), batch 1 as DefaultPredictor does, torch CPU fp32, {dt:.1f} s"}
+            "sample": f"{n} synthetic {tiles[0].shape[0]}x{tiles[0].shape[1]}x{tiles[0].shape[2]} tile(s), batch 1 as DefaultPredictor does, torch CPU fp32, {dt:.1f} s"}
 
 
 def main():
@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tile", type=int, default=512)
+    ap.add_argument("--bands", type=int, default=3, help="3 = BASELINE configs[1] (headline); 4 = RGB+NIR tiles (configs[3], with --tile 1024 --batch 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-stage table to stderr")
     ap.add_argument("--lanes", type=int, default=2,
@@ -93,12 +94,15 @@ def main():
     from tests.util import synthetic_tiles
 
     spec = EngineSpec(num_classes=2)      # R:config/detectron2_config_3bands.yaml defaults, 2 classes (artificial/natural)
+    if args.bands == 4:                   # no 4-band YAML exists in the reference: PIXEL_MEAN/STD extended by a NIR entry
+        spec = spec.replace(pixel_mean=spec.pixel_mean + (110.0,), pixel_std=spec.pixel_std + (1.0,))
     W = synthetic_weights(spec, seed=0)
     B, T = args.batch, args.tile
     # rank r owns tiles r*B .. r*B+B-1 of the synthetic tileset (seed = 1234 + tile id)
-    tiles = synthetic_tiles(B, T, T, 3, seed=1234 + rank * B)
+    C_in = args.bands
+    tiles = synthetic_tiles(B, T, T, C_in, seed=1234 + rank * B)
     L = max(1, args.lanes)
-    pipe = LanePipeline(spec, W, (T, T, 3), max_batch=B, device=local_rank, lanes=L)
+    pipe = LanePipeline(spec, W, (T, T, C_in), max_batch=B, device=local_rank, lanes=L)
     engs = pipe.engines
     ptrs = [e.upload_tiles(tiles) for e in engs]
     eng = engs[0]
@@ -196,11 +200,12 @@ def main():
                     print(f"{s['name']:28s} {mc:9.4f} {s['flops'] / mc / 1e9 if mc else 0:9.1f} {s['bytes'] / mc / 1e6 if mc else 0:9.1f}", file=sys.stderr)
             print(f"sum of stage times {tot_ms / max(stages[0]['calls'], 1):.3f} ms/batch; wall {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr)
         out = {
-            "metric": "tiles_per_sec_512x512x3", "value": value, "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
+            "metric": f"tiles_per_sec_{T}x{T}x{C_in}", "value": value, "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"Mask R-CNN R50-FPN inference, batch {B} of {T}x{T} 3-band tiles per GPU (BASELINE configs[1]), 800x800 network input",
-                       "batch_per_gpu": B, "lanes": L, "tile": [T, T, 3], "num_classes": 2,
+            "config": {"workload": f"Mask R-CNN R50-FPN inference, batch {B} of {T}x{T} {C_in}-band tiles per GPU "
+                                   f"(BASELINE configs[{1 if C_in == 3 else 3}]), 800x800 network input",
+                       "batch_per_gpu": B, "lanes": L, "tile": [T, T, C_in], "num_classes": 2,
                        "proposals_per_tile": float(np.mean(nprop)), "detections_per_tile": float(np.mean(ndet)),
                        "sharding": "tiles across ranks, no data-path collective"},
             "roofline": roofline,

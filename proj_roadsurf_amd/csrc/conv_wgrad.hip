@@ -143,24 +143,42 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
       __syncthreads();
       if (s + 1 < s1) stage(buf ^ 1, s + 1);
       const unsigned bo = (unsigned)(buf * STAGE);
+      // the 16 transposed reads of the first 32-pixel half and 12 of the second are issued before the first MFMA (lgkmcnt is a
+      // 4-bit counter: at most 15 may be left in flight); the first 16 MFMAs wait only for the older 16, so the second half's
+      // LDS latency hides behind them
+      half4v a_lo[2][4], a_hi[2][4], b_lo[2][4], b_hi[2][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        RS_TR(a_lo[0][i], a_addr[i][0][0] + bo);
+        RS_TR(a_hi[0][i], a_addr[i][0][1] + bo);
+        RS_TR(b_lo[0][i], b_addr[i][0][0] + bo);
+        RS_TR(b_hi[0][i], b_addr[i][0][1] + bo);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        RS_TR(a_lo[1][i], a_addr[i][1][0] + bo);
+        RS_TR(a_hi[1][i], a_addr[i][1][1] + bo);
+        RS_TR(b_lo[1][i], b_addr[i][1][0] + bo);
+        RS_TR(b_hi[1][i], b_addr[i][1][1] + bo);
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        half4v a_lo[4], a_hi[4], b_lo[4], b_hi[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          RS_TR(a_lo[i], a_addr[i][ks][0] + bo);
-          RS_TR(a_hi[i], a_addr[i][ks][1] + bo);
-          RS_TR(b_lo[i], b_addr[i][ks][0] + bo);
-          RS_TR(b_hi[i], b_addr[i][ks][1] + bo);
-        }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ks == 0) {
+          asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+          RS_TR(a_lo[1][3], a_addr[3][1][0] + bo);                 // the last four of the second half go out behind the wait
+          RS_TR(a_hi[1][3], a_addr[3][1][1] + bo);
+          RS_TR(b_lo[1][3], b_addr[3][1][0] + bo);
+          RS_TR(b_hi[1][3], b_addr[3][1][1] + bo);
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
         half8 af[4], bf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          af[i] = __builtin_shufflevector(a_lo[i], a_hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
-          bf[i] = __builtin_shufflevector(b_lo[i], b_hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+          af[i] = __builtin_shufflevector(a_lo[ks][i], a_hi[ks][i], 0, 1, 2, 3, 4, 5, 6, 7);
+          bf[i] = __builtin_shufflevector(b_lo[ks][i], b_hi[ks][i], 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
