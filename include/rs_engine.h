@@ -353,6 +353,12 @@ rs_vec_result* rs_vectorize_masks(const uint8_t* masks, int n, int h, int w, dou
 void rs_vec_counts(const rs_vec_result* r, int64_t* n_instances, int64_t* n_polygons, int64_t* n_rings, int64_t* n_vertices);
 int rs_vec_copy(const rs_vec_result* r, int32_t* inst_poly_count, int32_t* poly_ring_count, int32_t* ring_len, double* xy);
 void rs_vec_free(rs_vec_result* r);
+/* GeoPackage geometry blobs ('GP' header + little-endian WKB Polygon, OGC 12-128r15) of every polygon of a result, coordinates
+ * georeferenced per instance: X = xform[i][0] + x*xform[i][2], Y = xform[i][1] - y*xform[i][3] (xform NULL = pixel coordinates,
+ * Y = y) -- what the reference writes through geopandas.to_file(driver="GPKG") (R:config/config_obj_detec.yaml:100-103).
+ * out NULL: returns the bytes needed; else fills out, offsets[n_polygons+1] and bbox[minx,miny,maxx,maxy]. */
+int64_t rs_vec_gpkg_blobs(const rs_vec_result* r, const double* xform, int32_t srs_id, uint8_t* out, int64_t out_cap,
+                          int64_t* offsets, double bbox[4]);
 
 /* Training targets of the mask head (host code): the polygons of ONE ground-truth instance cropped to `box` and rasterised at
  * mask_size x mask_size -- PolygonMasks.crop_and_resize ([EXT d2: structures/masks.py rasterize_polygons_within_box]; rasteriser =

@@ -290,6 +290,67 @@ int rs_vec_copy(const rs_vec_result* r, int32_t* inst_poly_count, int32_t* poly_
 
 void rs_vec_free(rs_vec_result* r) { delete r; }
 
+// GeoPackage geometry blobs of every polygon of a result (OGC 12-128r15: 'GP' header, little-endian, envelope
+// [minx,maxx,miny,maxy], then a WKB Polygon), with the pixel-corner coordinates georeferenced per instance:
+//   X = xform[i][0] + x * xform[i][2],   Y = xform[i][1] - y * xform[i][3]        (xform == NULL: pixel coordinates)
+// -- byte for byte what proj_roadsurf_amd/gpkg.py:gpkg_geom builds from the Python feature list.  out == NULL: returns the
+// number of bytes needed.  offsets: [n_polygons + 1] byte offsets; bbox: [minx, miny, maxx, maxy] over everything.
+int64_t rs_vec_gpkg_blobs(const rs_vec_result* r, const double* xform, int32_t srs_id, uint8_t* out, int64_t out_cap, int64_t* offsets,
+                          double bbox[4]) {
+  if (!r) return RS_ERR_ARG;
+  int64_t need = 0;
+  size_t ri = 0;
+  for (size_t pi = 0; pi < r->poly_ring_count.size(); ++pi) {
+    need += 8 + 32 + 9;
+    for (int k = 0; k < r->poly_ring_count[pi]; ++k) need += 4 + 16 * (int64_t)r->ring_len[ri++];
+  }
+  if (!out) return need;
+  if (out_cap < need) return RS_ERR_ARG;
+  uint8_t* o = out;
+  auto put = [&](const void* p, size_t n) { memcpy(o, p, n); o += n; };
+  double gb[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
+  size_t pi = 0, vi = 0;
+  ri = 0;
+  for (size_t inst = 0; inst < r->inst_poly_count.size(); ++inst) {
+    const double x0 = xform ? xform[inst * 4] : 0.0, y0 = xform ? xform[inst * 4 + 1] : 0.0;
+    const double sx = xform ? xform[inst * 4 + 2] : 1.0, sy = xform ? xform[inst * 4 + 3] : -1.0;
+    for (int q = 0; q < r->inst_poly_count[inst]; ++q, ++pi) {
+      if (offsets) offsets[pi] = (int64_t)(o - out);
+      // envelope first pass
+      double e[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};     // minx, maxx, miny, maxy
+      size_t rj = ri, vj = vi;
+      for (int k = 0; k < r->poly_ring_count[pi]; ++k, ++rj)
+        for (int t = 0; t < r->ring_len[rj]; ++t, ++vj) {
+          const double X = x0 + r->xy[2 * vj] * sx, Y = y0 - r->xy[2 * vj + 1] * sy;
+          if (X < e[0]) e[0] = X;
+          if (X > e[1]) e[1] = X;
+          if (Y < e[2]) e[2] = Y;
+          if (Y > e[3]) e[3] = Y;
+        }
+      const uint8_t hdr[4] = {'G', 'P', 0, 0x03};
+      put(hdr, 4); put(&srs_id, 4); put(e, 32);
+      const uint8_t bo = 1;
+      const uint32_t typ = 3, nr = (uint32_t)r->poly_ring_count[pi];
+      put(&bo, 1); put(&typ, 4); put(&nr, 4);
+      for (int k = 0; k < r->poly_ring_count[pi]; ++k, ++ri) {
+        const uint32_t np = (uint32_t)r->ring_len[ri];
+        put(&np, 4);
+        for (uint32_t t = 0; t < np; ++t, ++vi) {
+          const double X = x0 + r->xy[2 * vi] * sx, Y = y0 - r->xy[2 * vi + 1] * sy;
+          put(&X, 8); put(&Y, 8);
+        }
+      }
+      if (e[0] < gb[0]) gb[0] = e[0];
+      if (e[2] < gb[1]) gb[1] = e[2];
+      if (e[1] > gb[2]) gb[2] = e[1];
+      if (e[3] > gb[3]) gb[3] = e[3];
+    }
+  }
+  if (offsets) offsets[pi] = (int64_t)(o - out);
+  if (bbox) for (int i = 0; i < 4; ++i) bbox[i] = gb[i];
+  return need;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Ground-truth mask targets of the mask head (training): PolygonMasks.crop_and_resize -> rasterize_polygons_within_box
 // -> pycocotools frPyObjects / merge / decode ([EXT d2: structures/masks.py]; [EXT coco: common/maskApi.c rleFrPoly]).

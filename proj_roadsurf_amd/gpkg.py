@@ -84,6 +84,57 @@ def write_gpkg(path: str, features: Iterable[dict], table: str = "detections", e
         con.close()
 
 
+class GpkgWriter:
+    """Streaming form of ``write_gpkg`` for rows that already carry the GeoPackage geometry blob (``rs_vec_gpkg_blobs``):
+    ``add_rows([(blob, score, det_class, image), ...], bbox)`` per batch, ``close()`` writes the contents/geometry metadata."""
+
+    def __init__(self, path: str, table: str = "detections", epsg: Optional[int] = None):
+        self.table, self.srs_id = table, int(epsg) if epsg else -1
+        self.con = sqlite3.connect(path)
+        self.n = 0
+        self.bx = [float("inf"), float("inf"), float("-inf"), float("-inf")]
+        cur = self.con.cursor()
+        cur.execute("PRAGMA application_id = 1196444487")
+        cur.execute("PRAGMA user_version = 10200")
+        cur.execute("PRAGMA journal_mode = OFF")
+        cur.execute("PRAGMA synchronous = OFF")
+        cur.executescript("""
+            DROP TABLE IF EXISTS gpkg_spatial_ref_sys; DROP TABLE IF EXISTS gpkg_contents; DROP TABLE IF EXISTS gpkg_geometry_columns;
+            CREATE TABLE gpkg_spatial_ref_sys (srs_name TEXT NOT NULL, srs_id INTEGER NOT NULL PRIMARY KEY, organization TEXT NOT NULL,
+                organization_coordsys_id INTEGER NOT NULL, definition TEXT NOT NULL, description TEXT);
+            CREATE TABLE gpkg_contents (table_name TEXT NOT NULL PRIMARY KEY, data_type TEXT NOT NULL, identifier TEXT UNIQUE, description TEXT DEFAULT '',
+                last_change DATETIME NOT NULL DEFAULT (strftime('%Y-%m-%dT%H:%M:%fZ','now')), min_x DOUBLE, min_y DOUBLE, max_x DOUBLE, max_y DOUBLE, srs_id INTEGER);
+            CREATE TABLE gpkg_geometry_columns (table_name TEXT NOT NULL, column_name TEXT NOT NULL, geometry_type_name TEXT NOT NULL, srs_id INTEGER NOT NULL,
+                z TINYINT NOT NULL, m TINYINT NOT NULL, CONSTRAINT pk_geom_cols PRIMARY KEY (table_name, column_name));
+        """)
+        cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES ('Undefined cartesian SRS', -1, 'NONE', -1, 'undefined', 'undefined cartesian coordinate reference system')")
+        cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES ('Undefined geographic SRS', 0, 'NONE', 0, 'undefined', 'undefined geographic coordinate reference system')")
+        name4326, def4326 = _SRS[4326]
+        cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES (?, 4326, 'EPSG', 4326, ?, NULL)", (name4326, def4326))
+        if self.srs_id not in (-1, 0, 4326):
+            name, definition = _SRS.get(self.srs_id, (f"EPSG:{self.srs_id}", "undefined"))
+            cur.execute("INSERT INTO gpkg_spatial_ref_sys VALUES (?, ?, 'EPSG', ?, ?, NULL)", (name, self.srs_id, self.srs_id, definition))
+        cur.execute(f'DROP TABLE IF EXISTS "{table}"')
+        cur.execute(f'CREATE TABLE "{table}" (fid INTEGER PRIMARY KEY AUTOINCREMENT NOT NULL, geom BLOB, score REAL, det_class INTEGER, image TEXT)')
+
+    def add_rows(self, rows: Sequence[Tuple[bytes, float, int, str]], bbox: Optional[Sequence[float]]) -> None:
+        if not rows:
+            return
+        self.con.executemany(f'INSERT INTO "{self.table}" (geom, score, det_class, image) VALUES (?, ?, ?, ?)', rows)
+        self.n += len(rows)
+        if bbox is not None:
+            self.bx = [min(self.bx[0], bbox[0]), min(self.bx[1], bbox[1]), max(self.bx[2], bbox[2]), max(self.bx[3], bbox[3])]
+
+    def close(self) -> int:
+        bx = self.bx if self.n else [None, None, None, None]
+        self.con.execute("INSERT INTO gpkg_contents (table_name, data_type, identifier, min_x, min_y, max_x, max_y, srs_id) VALUES (?, 'features', ?, ?, ?, ?, ?, ?)",
+                         (self.table, self.table, bx[0], bx[1], bx[2], bx[3], self.srs_id))
+        self.con.execute("INSERT INTO gpkg_geometry_columns VALUES (?, 'geom', 'POLYGON', ?, 0, 0)", (self.table, self.srs_id))
+        self.con.commit()
+        self.con.close()
+        return self.n
+
+
 def read_gpkg(path: str, table: str = "detections") -> List[dict]:
     """Read back what ``write_gpkg`` wrote (used by the tests; a reader for consumers without geopandas)."""
     con = sqlite3.connect(path)

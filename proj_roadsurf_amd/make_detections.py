@@ -26,10 +26,10 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import yaml
 
-from .gpkg import write_gpkg
+from .gpkg import GpkgWriter
 from .shard import run_sharded
 from .spec import load_d2_yaml
-from .vectorize import instances_to_features
+from .vectorize import instances_to_features, instances_to_gpkg_rows
 from .weights import infer_num_classes, load_checkpoint, synthetic_weights
 
 SECTION = "make_detections.py"
@@ -87,6 +87,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                     help="use seeded synthetic weights instead of model_weights.pth_file (demo / smoke tests)")
     ap.add_argument("--host-workers", type=int, default=4, help="threads for tile decode / vectorisation around the GPU call")
     ap.add_argument("--vector-threads", type=int, default=4, help="threads inside one rs_vectorize_masks call")
+    ap.add_argument("--geojson", action="store_true", help="also write <dataset>_detections_..._threshold.geojson (slow: Python feature dicts)")
     ap.add_argument("--max-tiles", type=int, default=0, help="debug: only the first N tiles of every dataset")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s", stream=sys.stderr)
@@ -135,34 +136,43 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     def predict_batch(ims: Sequence[Any]) -> List[Any]:
         return predictor.predict_batch(ims)
 
-    def finish(entries: Sequence[dict], outs: List[Any]) -> List[List[dict]]:
+    def finish(entries: Sequence[dict], outs: List[Any]) -> List[Any]:
+        # per tile: (GeoPackage rows, bbox[, GeoJSON features]) -- masks -> polygons -> RDP -> georeferenced blobs in C++
         res = []
         for e, o in zip(entries, outs):
-            ext, _ = tile_extent(meta, e["file_name"])
-            res.append(instances_to_features(o["instances"], os.path.basename(e["file_name"]), ext,
-                                             bool(rdp_cfg.get("enabled", False)), float(rdp_cfg.get("epsilon", 0.75)),
-                                             threads=args.vector_threads))
+            ext, epsg_t = tile_extent(meta, e["file_name"])
+            name = os.path.basename(e["file_name"])
+            rdp_on, eps = bool(rdp_cfg.get("enabled", False)), float(rdp_cfg.get("epsilon", 0.75))
+            rows, bbox = instances_to_gpkg_rows(o["instances"], name, ext, rdp_on, eps, srs_id=cur_srs["id"], threads=args.vector_threads)
+            feats = instances_to_features(o["instances"], name, ext, rdp_on, eps, threads=args.vector_threads) if args.geojson else None
+            res.append((rows, bbox, feats))
         return res
 
+    cur_srs = {"id": -1}
     for dataset, d in coco.items():
         images = d.get("images", [])
         if args.max_tiles:
             images = images[: args.max_tiles]
         t0 = time.time()
-        per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
-                               workers=args.host_workers)
-        if rank != 0:
-            continue
-        feats = [f for tile in per_tile for f in tile]
         epsg = None
         for e in images:
             _, epsg = tile_extent(meta, e["file_name"])
             if epsg:
                 break
+        cur_srs["id"] = int(epsg) if epsg else -1
+        per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
+                               workers=args.host_workers)
+        if rank != 0:
+            continue
         base = f"{dataset}_detections_at_{thr_tag(thr)}_threshold"
-        n = write_gpkg(base + ".gpkg", feats, table=base, epsg=epsg)
-        with open(base + ".geojson", "w") as f:
-            f.write(json.dumps({"type": "FeatureCollection", "features": feats}))   # dumps() = C encoder; dump() streams through the slow Python one
+        gw = GpkgWriter(base + ".gpkg", table=base, epsg=epsg)
+        for rows, bbox, _ in per_tile:
+            gw.add_rows(rows, bbox)
+        n = gw.close()
+        if args.geojson:
+            feats = [f for _, _, fs in per_tile for f in fs]
+            with open(base + ".geojson", "w") as f:
+                f.write(json.dumps({"type": "FeatureCollection", "features": feats}))   # dumps() = C encoder; dump() streams through the slow Python one
         dt = time.time() - t0
         log.info("%s: %d tiles -> %d features in %.1f s (%.1f tiles/s) -> %s.gpkg", dataset, len(images), n, dt,
                  len(images) / max(dt, 1e-9), base)

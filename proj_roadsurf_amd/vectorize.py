@@ -200,6 +200,59 @@ def vectorize_masks_native(packed: np.ndarray, h: int, w: int, rdp_epsilon: floa
     return out
 
 
+def instances_to_gpkg_rows(instances, image_name: str, extent: Optional[Sequence[float]] = None, rdp_enabled: bool = True,
+                           rdp_epsilon: float = 0.75, srs_id: int = -1, threads: int = 0):
+    """The fast path of the CLI: masks -> polygons -> RDP -> georeferenced GeoPackage geometry blobs, all in C++
+    (``rs_vectorize_masks`` + ``rs_vec_gpkg_blobs``); Python only pairs each blob with its instance's score and class.
+    Returns (rows [(blob, score, det_class, image)], bbox [minx, miny, maxx, maxy] or None).  Same polygons, vertices and bytes as
+    ``gpkg.gpkg_geom`` applied to ``instances_to_features`` (tests/test_vector_cli.py)."""
+    import ctypes as C
+    from .engine import load_library, RsError
+    n = len(instances)
+    if n == 0 or not instances.has("pred_masks"):
+        return [], None
+    lib = load_library()
+    lib.rs_vec_gpkg_blobs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.rs_vec_gpkg_blobs.restype = C.c_int64
+    h, w = instances.image_size
+    packed = getattr(instances, "_packed", None)
+    if packed is None:
+        packed = np.packbits(np.asarray(instances.pred_masks, dtype=bool), axis=2, bitorder="little")
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    r = lib.rs_vectorize_masks(packed.ctypes.data_as(C.c_void_p), n, h, w, float(rdp_epsilon if rdp_enabled else 0.0), int(threads))
+    if not r:
+        raise RsError("rs_vectorize_masks failed")
+    try:
+        c = [C.c_int64() for _ in range(4)]
+        lib.rs_vec_counts(r, *[C.byref(x) for x in c])
+        ni, npoly = int(c[0].value), int(c[1].value)
+        if npoly == 0:
+            return [], None
+        ipc = np.zeros(ni, np.int32)
+        lib.rs_vec_copy(r, ipc.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None)
+        xform = None
+        if extent is not None:
+            xmin, ymin, xmax, ymax = (float(v) for v in extent)
+            xform = np.ascontiguousarray(np.tile(np.array([xmin, ymax, (xmax - xmin) / w, (ymax - ymin) / h], np.float64), (ni, 1)))
+        xp = xform.ctypes.data_as(C.c_void_p) if xform is not None else None
+        need = int(lib.rs_vec_gpkg_blobs(r, xp, int(srs_id), None, 0, None, None))
+        buf = np.empty(need, np.uint8)
+        offs = np.zeros(npoly + 1, np.int64)
+        bbox = np.zeros(4, np.float64)
+        got = int(lib.rs_vec_gpkg_blobs(r, xp, int(srs_id), buf.ctypes.data_as(C.c_void_p), need, offs.ctypes.data_as(C.c_void_p), bbox.ctypes.data_as(C.c_void_p)))
+        if got != need:
+            raise RsError("rs_vec_gpkg_blobs failed")
+    finally:
+        lib.rs_vec_free(r)
+    raw = buf.tobytes()
+    o = offs.tolist()
+    scores = [float(s) for s in instances.scores]
+    classes = [int(k) for k in instances.pred_classes]
+    inst_of = np.repeat(np.arange(ni), ipc).tolist()
+    rows = [(raw[o[i]:o[i + 1]], scores[inst_of[i]], classes[inst_of[i]], image_name) for i in range(npoly)]
+    return rows, bbox.tolist()
+
+
 def instances_to_features(instances, image_name: str, extent: Optional[Sequence[float]] = None,
                           rdp_enabled: bool = True, rdp_epsilon: float = 0.75, native: bool = True, threads: int = 0) -> List[dict]:
     """GeoJSON-like features, one per polygon, with the columns the reference's post-stage reads

@@ -138,6 +138,42 @@ def test_native_vectorizer_in_features_path():
     assert a == b and len(a) >= n
 
 
+def test_native_gpkg_rows_equal_python_writer(tmp_path):
+    """instances_to_gpkg_rows (vectorise + RDP + georeference + GeoPackage blob, all C++) produces byte for byte the blobs that
+    gpkg_geom builds from instances_to_features, and GpkgWriter's file reads back as the same features."""
+    _native_lib()
+    from proj_roadsurf_amd.engine import Instances
+    from proj_roadsurf_amd.gpkg import GpkgWriter, gpkg_geom
+    from proj_roadsurf_amd.vectorize import instances_to_gpkg_rows
+    rng = np.random.default_rng(11)
+    h, w, n = 96, 120, 9
+    masks = np.stack([ndimage.gaussian_filter(rng.random((h, w)), 3 + i % 3) > 0.5 for i in range(n)])
+    masks[3] = False                                               # an empty mask: no polygon, no row
+    inst = Instances((h, w), rng.random((n, 4)).astype(np.float32), rng.random(n).astype(np.float32), np.arange(n) % 2,
+                     np.packbits(masks, axis=2, bitorder="little"), None)
+    for extent, srs in [((2600000.0, 1200000.0, 2600104.6, 1200083.7), 2056), (None, -1)]:
+        feats = instances_to_features(inst, "18_1_2.tif", extent, True, 0.75, native=False)
+        rows, bbox = instances_to_gpkg_rows(inst, "18_1_2.tif", extent, True, 0.75, srs_id=srs)
+        assert len(rows) == len(feats) > n - 1
+        for f, (blob, score, cls, image) in zip(feats, rows):
+            assert blob == gpkg_geom(f["geometry"]["coordinates"], srs)
+            assert (score, cls, image) == (f["properties"]["score"], f["properties"]["det_class"], "18_1_2.tif")
+        xs = [p[0] for f in feats for r in f["geometry"]["coordinates"] for p in r]
+        ys = [p[1] for f in feats for r in f["geometry"]["coordinates"] for p in r]
+        assert bbox == [min(xs), min(ys), max(xs), max(ys)]
+    p = str(tmp_path / "rows.gpkg")
+    gw = GpkgWriter(p, table="t", epsg=2056)
+    gw.add_rows(rows[:0], None)
+    rows2, bbox2 = instances_to_gpkg_rows(inst, "18_1_2.tif", (2600000.0, 1200000.0, 2600104.6, 1200083.7), True, 0.75, srs_id=2056)
+    gw.add_rows(rows2, bbox2)
+    assert gw.close() == len(rows2)
+    back = read_gpkg(p, "t")
+    want = instances_to_features(inst, "18_1_2.tif", (2600000.0, 1200000.0, 2600104.6, 1200083.7), True, 0.75, native=False)
+    assert [b["geometry"]["coordinates"] for b in back] == [f["geometry"]["coordinates"] for f in want] and back[0]["srs_id"] == 2056
+    empty = Instances((h, w), np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int64), np.zeros((0, h, (w + 7) // 8), np.uint8), None)
+    assert instances_to_gpkg_rows(empty, "x.tif") == ([], None)
+
+
 def test_features_georeference_and_gpkg_roundtrip(tmp_path):
     feats = instances_to_features(_Inst(), "18_1_2.tif", extent=(1000.0, 2000.0, 1080.0, 2080.0), rdp_enabled=True, rdp_epsilon=0.75)
     assert len(feats) == 1
@@ -189,7 +225,7 @@ def test_make_detections_cli_end_to_end(gpu_required, tmp_path):
     yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
     cwd = os.getcwd()
     try:
-        assert make_detections.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--batch", "2"]) == 0
+        assert make_detections.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--batch", "2", "--geojson"]) == 0
     finally:
         os.chdir(cwd)
     out = wd / "val_detections_at_0dot05_threshold.gpkg"
