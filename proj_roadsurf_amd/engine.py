@@ -247,6 +247,19 @@ class Engine:
         self._h = h
         self._alloc_out(self.max_batch)
 
+    @classmethod
+    def from_handle(cls, lib: C.CDLL, handle: int, spec: EngineSpec, tile_shape: Tuple[int, int, int], max_batch: int) -> "Engine":
+        """Wrap an engine owned by someone else (the trainer's forward engine: ``rs_trainer_engine``) for inference calls;
+        ``close`` frees only this wrapper's pinned host buffers."""
+        self = cls.__new__(cls)
+        self.lib, self.spec = lib, spec
+        self.tile_h, self.tile_w, self.tile_c = (int(x) for x in tile_shape)
+        self.max_batch, self.D = int(max_batch), spec.detections_per_image
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        self._alloc_out(self.max_batch)
+        return self
+
     # ------------------------------------------------------------------ plumbing
     def _pinned(self, shape: Tuple[int, ...], dtype) -> np.ndarray:
         """numpy array over pinned host memory (rs_host_alloc): device<->host copies run at PCIe speed and asynchronously."""
@@ -404,7 +417,8 @@ class Engine:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            self.lib.rs_engine_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.rs_engine_destroy(self._h)
             self._h = None
             for name in ("_count", "_boxes", "_scores", "_classes", "_masks", "_stage_tiles"):
                 setattr(self, name, None)             # views over the pinned memory freed below
@@ -728,6 +742,13 @@ class Trainer:
         """Carry master weights + momentum over from ``other`` (a trainer of another input size) and refold."""
         _check(self.lib, self.lib.rs_trainer_copy_state(self._h, other._h), "rs_trainer_copy_state")
 
+    def inference_engine(self) -> Engine:
+        """The trainer's forward engine as an inference ``Engine`` (same device buffers, current weights): validation detections
+        without a second copy of the network.  Valid until the trainer is closed; do not interleave with a training step."""
+        if getattr(self, "_infer", None) is None:
+            self._infer = Engine.from_handle(self.lib, int(self._eng.value), self.spec, (self.tile_h, self.tile_w, self.tile_c), self.batch)
+        return self._infer
+
     def allreduce_gradients(self) -> None:
         """Sum the flat gradient buffer over the ranks of the default process group (RCCL: the buffer is handed to
         torch.distributed in place through ``__cuda_array_interface__``; gloo: through a host copy) and set the divisor the SGD
@@ -786,6 +807,9 @@ class Trainer:
         return int(self.lib.rs_trainer_param_count(self._h))
 
     def close(self) -> None:
+        if getattr(self, "_infer", None) is not None:
+            self._infer.close()
+            self._infer = None
         if getattr(self, "_h", None):
             self.lib.rs_trainer_destroy(self._h)
             self._h = None

@@ -19,7 +19,8 @@ What follows the reference / detectron2 0.6 and where it is pinned:
 Documented deviations: MIN_SIZE_TRAIN's multi-scale "choice" (R:31-38) is drawn once per BATCH, not per image
 (identical at the reference's one image per GPU), fp16 activations/weights with fp32 master weights and static loss scaling instead of fp32 everywhere, the
 model-zoo URL of ``model_weights.model_zoo_checkpoint_url`` cannot be fetched offline (use ``model_weights.pth_file`` or
-``--synthetic-weights``), and the periodic COCO AP evaluation is not built (the validation loss every TEST.EVAL_PERIOD is).
+``--synthetic-weights``).  Every TEST.EVAL_PERIOD iterations the validation loss and the COCO bbox / segm AP (coco_eval.py, a
+restatement of pycocotools' COCOeval) of the `val` set are logged to metrics.json.
 """
 from __future__ import annotations
 
@@ -245,6 +246,32 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             tot, cnt = float(t[0]), int(t[1])
         return tot / max(cnt, 1)
 
+    def validation_ap() -> Dict[str, float]:
+        """COCOEvaluator on the val set (rank 0, bbox + segm AP; coco_eval.py) with the CURRENT weights: inference through the
+        trainer's own forward engine at the test size."""
+        if not val_recs or rank != 0:
+            return {}
+        from .coco_eval import evaluate
+        from .train_targets import rasterize_polygons_within_box
+        vt = ms.select(sizes[-1])
+        eng = vt.inference_engine()
+        gts, dts = [], []
+        for k in range(0, len(val_recs), per_rank):
+            chunk = val_recs[k:k + per_rank]
+            tiles = np.stack([read_tile(r["file_name"]) for r in chunk])
+            for r, inst in zip(chunk, eng.infer(tiles)):
+                h, w = tiles.shape[1:3]
+                g = {"boxes": r["boxes"], "classes": r["classes"]}
+                d = {"boxes": inst.pred_boxes, "classes": inst.pred_classes, "scores": inst.scores}
+                if spec.mask_on and h == w:
+                    g["masks"] = np.stack([rasterize_polygons_within_box(p, np.array([0.0, 0.0, w, h]), h) for p in r["polygons"]])
+                    d["masks"] = inst.pred_masks
+                gts.append(g); dts.append(d)
+        out = {f"bbox/{k}": v for k, v in evaluate(gts, dts, spec.num_classes, "bbox", spec.detections_per_image).items()}
+        if all("masks" in g for g in gts):
+            out.update({f"segm/{k}": v for k, v in evaluate(gts, dts, spec.num_classes, "segm", spec.detections_per_image).items()})
+        return {k: (None if v != v else v) for k, v in out.items()}           # NaN -> null in metrics.json
+
     t0 = time.time()
     for it in range(max_iter):
         size = int(sizes[int(size_rng.integers(len(sizes)))])
@@ -269,6 +296,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             rec = {"iteration": it, "total_loss": float(sum(losses.values())), "lr": lr, "time": (time.time() - t0) / (it + 1), **losses}
             if vloss is not None:
                 rec["validation_loss"] = vloss
+                rec.update(validation_ap())
             metrics.write(json.dumps(rec) + "\n")
             metrics.flush()
             log.info("iter %d  total_loss %.4f  %s  lr %.6f  %.3f s/iter", it, rec["total_loss"],

@@ -1,0 +1,93 @@
+"""Closed-form checks of proj_roadsurf_amd/coco_eval.py (pycocotools' COCOeval restated; parity unpinned)."""
+import numpy as np
+import pytest
+
+from proj_roadsurf_amd.coco_eval import box_iou, evaluate, mask_iou
+
+
+def _img(boxes, classes, scores=None, masks=None, crowd=None):
+    d = {"boxes": np.asarray(boxes, np.float64).reshape(-1, 4), "classes": np.asarray(classes, np.int64)}
+    if scores is not None:
+        d["scores"] = np.asarray(scores, np.float64)
+    if masks is not None:
+        d["masks"] = masks
+    if crowd is not None:
+        d["crowd"] = np.asarray(crowd, bool)
+    return d
+
+
+def test_perfect_detections_score_100():
+    g = [_img([[10, 10, 60, 60], [100, 100, 220, 200]], [0, 1]), _img([[5, 5, 25, 25]], [0])]
+    d = [_img(x["boxes"], x["classes"], scores=[0.9] * len(x["classes"])) for x in g]
+    r = evaluate(g, d, 2, "bbox")
+    assert r["AP"] == pytest.approx(100.0) and r["AP50"] == pytest.approx(100.0) and r["AP-class1"] == pytest.approx(100.0)
+    assert r["APs"] == pytest.approx(100.0) and r["APm"] == pytest.approx(100.0) and r["APl"] == pytest.approx(100.0)
+
+
+def test_precision_recall_staircase_known_answer():
+    """One class, 2 ground truths; detections by score: TP, FP, TP.  Precision envelope: 1.0 up to recall 0.5, 2/3 up to recall 1
+    -> AP@0.5 = (51 * 1.0 + 50 * 2/3) / 101."""
+    g = [_img([[0, 0, 10, 10], [20, 20, 30, 30]], [0, 0])]
+    d = [_img([[0, 0, 10, 10], [50, 50, 60, 60], [20, 20, 30, 30]], [0, 0, 0], scores=[0.9, 0.8, 0.7])]
+    r = evaluate(g, d, 1, "bbox")
+    assert r["AP50"] == pytest.approx((51 * 1.0 + 50 * 2 / 3) / 101 * 100)
+    assert r["AP"] == pytest.approx(r["AP50"])                     # IoU 1.0 matches pass every threshold
+    # the false positive ranked LAST costs nothing
+    d2 = [_img([[0, 0, 10, 10], [20, 20, 30, 30], [50, 50, 60, 60]], [0, 0, 0], scores=[0.9, 0.8, 0.1])]
+    assert evaluate(g, d2, 1, "bbox")["AP"] == pytest.approx(100.0)
+
+
+def test_iou_thresholds_and_localisation_quality():
+    """A detection with IoU 0.6 counts at thresholds 0.50, 0.55, 0.60 only: AP = 3/10 * 100."""
+    g = [_img([[0, 0, 10, 10]], [0])]
+    d = [_img([[0, 0, 10, 6]], [0], scores=[0.5])]                  # IoU = 60 / 100
+    r = evaluate(g, d, 1, "bbox")
+    assert r["AP50"] == pytest.approx(100.0) and r["AP75"] == pytest.approx(0.0) and r["AP"] == pytest.approx(30.0)
+
+
+def test_duplicate_detections_and_missed_ground_truth():
+    g = [_img([[0, 0, 10, 10], [40, 40, 60, 60]], [0, 0])]
+    d = [_img([[0, 0, 10, 10], [0, 0, 10, 10]], [0, 0], scores=[0.9, 0.8])]     # second is a duplicate -> FP; one gt missed
+    r = evaluate(g, d, 1, "bbox")
+    assert r["AP50"] == pytest.approx(51 / 101 * 100)               # precision 1 up to recall 0.5, nothing beyond
+
+
+def test_area_ranges_and_crowd_regions():
+    small, large = [0, 0, 20, 20], [100, 100, 300, 300]             # areas 400 (< 32^2) and 40000 (> 96^2)
+    g = [_img([small, large], [0, 0])]
+    d = [_img([small], [0], scores=[0.9])]
+    r = evaluate(g, d, 1, "bbox")
+    assert r["APs"] == pytest.approx(100.0) and r["APl"] == pytest.approx(0.0) and np.isnan(r["APm"])
+    # a detection inside a crowd region is ignored (neither TP nor FP); IoU with a crowd uses the detection area as union
+    g2 = [_img([[0, 0, 10, 10], [50, 50, 150, 150]], [0, 0], crowd=[False, True])]
+    d2 = [_img([[0, 0, 10, 10], [60, 60, 80, 80]], [0, 0], scores=[0.9, 0.8])]
+    assert box_iou(d2[0]["boxes"][1:], g2[0]["boxes"][1:], np.array([True]))[0, 0] == pytest.approx(1.0)
+    assert evaluate(g2, d2, 1, "bbox")["AP"] == pytest.approx(100.0)
+
+
+def test_segm_iou_and_evaluation():
+    H = W = 40
+    gm = np.zeros((1, H, W), bool); gm[0, 10:30, 10:30] = True
+    dm = np.zeros((2, H, W), bool); dm[0, 10:30, 10:20] = True; dm[1, 10:30, 10:30] = True
+    iou = mask_iou(dm, gm, np.array([False]))
+    assert iou[0, 0] == pytest.approx(0.5) and iou[1, 0] == pytest.approx(1.0)
+    g = [_img([[10, 10, 30, 30]], [0], masks=gm)]
+    d = [_img([[10, 10, 20, 30], [10, 10, 30, 30]], [0, 0], scores=[0.9, 0.8], masks=dm)]
+    r = evaluate(g, d, 1, "segm")
+    # threshold 0.50: the half mask (score 0.9) matches first, the full mask becomes a FP -> AP 100; above 0.5: FP then TP -> 0.5
+    assert r["AP50"] == pytest.approx(100.0) and r["AP75"] == pytest.approx(50.0)
+    assert r["AP"] == pytest.approx((100.0 + 9 * 50.0) / 10)
+
+
+def test_max_dets_and_empty_inputs():
+    g = [_img([[0, 0, 10, 10]], [0])]
+    boxes = [[100 + i, 100, 110 + i, 110] for i in range(5)] + [[0, 0, 10, 10]]
+    d = [_img(boxes, [0] * 6, scores=[0.9, 0.8, 0.7, 0.6, 0.5, 0.4])]
+    assert evaluate(g, d, 1, "bbox", max_dets=5)["AP"] == pytest.approx(0.0)          # the true positive is cut off
+    assert evaluate(g, d, 1, "bbox", max_dets=100)["AP50"] == pytest.approx(1 / 6 * 100)
+    r = evaluate([_img(np.zeros((0, 4)), [])], [_img(np.zeros((0, 4)), [], scores=[])], 1, "bbox")
+    assert np.isnan(r["AP"])
+    # segm with an image that has ground truth but no detection of the class (empty mask stacks)
+    gm = np.zeros((1, 8, 8), bool); gm[0, 2:6, 2:6] = True
+    r = evaluate([_img([[2, 2, 6, 6]], [0], masks=gm)], [_img(np.zeros((0, 4)), [], scores=[], masks=np.zeros((0, 8, 8), bool))], 1, "segm")
+    assert r["AP"] == pytest.approx(0.0)

@@ -454,6 +454,8 @@ def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
         assert lines[0]["lr"] == pytest.approx(0.002 * 0.001) and lines[3]["lr"] == pytest.approx(0.002) and lines[5]["lr"] == pytest.approx(0.001)
         assert [("validation_loss" in l) for l in lines] == [False, False, True, False, False, True]       # TEST.EVAL_PERIOD 3
         assert all(np.isfinite(l["validation_loss"]) and l["validation_loss"] > 0 for l in lines if "validation_loss" in l)
+        ev = lines[-1]
+        assert "bbox/AP" in ev and "segm/AP50" in ev and all(ev[k] is None or 0.0 <= ev[k] <= 100.0 for k in ev if k.startswith(("bbox/", "segm/")))
         assert (wd / "logs" / "model_0000002.pth").exists() and open(wd / "logs" / "last_checkpoint").read() == "model_final.pth"
         W1 = load_checkpoint(str(wd / "logs" / "model_final.pth"))
         spec = EngineSpec(num_classes=2)
@@ -576,5 +578,48 @@ def test_training_mode_proposals_match_oracle(gpu_required):
             assert int(cc[i]) == k + gt_boxes[i].shape[0]
             assert float(np.abs(cand[i, :k] - pb).max()) <= 1e-3
             assert np.array_equal(cand[i, k:k + gt_boxes[i].shape[0]], gt_boxes[i])
+    finally:
+        tr.close()
+
+
+def test_trainer_inference_engine_tracks_the_weights(gpu_required):
+    """After SGD steps the trainer's forward engine, used for validation inference, carries the CURRENT weights in every inference
+    operand (fp16 folds, fused heads, the fp32 mask predictor of the fused deconv kernel): its detections agree with a fresh engine
+    built from the exported checkpoint (which fuses the projection shortcuts, so activations differ by fp16 rounding)."""
+    from proj_roadsurf_amd.engine import Engine
+    from tests.util import match_detections
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=55)
+    tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=128.0)
+    try:
+        tr.set_sampling(256, 0.5, 64, 0.25)
+        gb = [np.array([[20.0, 30.0, 120.0, 160.0]], np.float32), np.array([[100.0, 100.0, 260.0, 280.0]], np.float32)]
+        polys = [[[np.array([b[0], b[1], b[2], b[1], b[2], b[3], b[0], b[3]], np.float64)] for b in bs] for bs in gb]
+        for it in range(3):
+            tr.train_step(tiles, gb, [np.array([0]), np.array([1])], polys, seed=it)
+            tr.apply_sgd(2e-3, 0.9, 1e-4)
+        W1 = tr.export_weights(Wn)
+        assert float(np.abs(W1["roi_heads.mask_head.predictor.weight"] - Wn["roi_heads.mask_head.predictor.weight"]).max()) > 0
+        got = tr.inference_engine().infer(tiles)
+        ref_eng = Engine(spec, W1, (256, 256, 3), max_batch=2)
+        try:
+            want = ref_eng.infer(tiles)
+        finally:
+            ref_eng.close()
+        old_eng = Engine(spec, Wn, (256, 256, 3), max_batch=2)
+        try:
+            old = old_eng.infer(tiles)
+        finally:
+            old_eng.close()
+        for a, b, o in zip(want, got, old):
+            assert len(a) > 0 and len(b) > 0
+            m = match_detections({"boxes": a.pred_boxes, "scores": a.scores, "classes": a.pred_classes, "masks": a.pred_masks},
+                                 {"boxes": b.pred_boxes, "scores": b.scores, "classes": b.pred_classes, "masks": b.pred_masks}, iou_thr=0.9)
+            assert m["frac_matched"] >= 0.85 and m["max_dscore"] <= 0.03 and m["agg_mask_iou"] >= 0.9, m
+            # ... and they are NOT the detections of the initial weights
+            m0 = match_detections({"boxes": o.pred_boxes, "scores": o.scores, "classes": o.pred_classes, "masks": o.pred_masks},
+                                  {"boxes": b.pred_boxes, "scores": b.scores, "classes": b.pred_classes, "masks": b.pred_masks}, iou_thr=0.9)
+            assert m0["frac_matched"] < m["frac_matched"] or m0["max_dscore"] > m["max_dscore"]
     finally:
         tr.close()
