@@ -192,7 +192,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
 
   // ---- store the partial tile: D[row = 4*(lane>>4) + e][col = lane&15] of block (i, j)
   if (wc == 1 && !second_valid) return;
-  float* out = p.partial + (long long)blockIdx.z * p.Cout * p.Kpad;
+  // one split: the tile IS the gradient (same arithmetic as wgrad_reduce_kernel with splits == 1, without its launch)
+  const bool direct = gridDim.z == 1 && p.KH * p.KW * p.Cin == p.Kpad;
+  float* out = direct ? p.grad : p.partial + (long long)blockIdx.z * p.Cout * p.Kpad;
   const int kc = k_col[wc];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -201,8 +203,18 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
       const int co = co0 + wr * 64 + i * 16 + (lane >> 4) * 4 + e;
       if (co >= p.Cout) continue;
       float* row = out + (long long)co * p.Kpad + kc + (lane & 15);
+      if (direct) {
+        const float sc = p.scale ? p.scale[co] : 1.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) row[j * 16] = acc[i][j][e];
+        for (int j = 0; j < 4; ++j) {
+          float v = 0.f + acc[i][j][e];
+          if (p.scale) v *= sc;
+          row[j * 16] = p.accumulate ? row[j * 16] + v : v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row[j * 16] = acc[i][j][e];
+      }
     }
   }
 }
@@ -243,6 +255,7 @@ int launch_conv_wgrad(const WgradParams& p, hipStream_t stream) {
   dim3 grid(cdiv(p.Cout, BM), cdiv(units, 2), p.splits);
   hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(NT), LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());
+  if (p.splits == 1 && units * 64 == p.Kpad) return RS_OK;       // stored by the kernel itself (no padding columns to define)
   const long long n_el = (long long)p.Cout * p.Kpad;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n_el, 256)), dim3(256), 0, stream, p.partial, p.splits, n_el, p.Kpad,
                      p.scale, p.grad, p.accumulate);

@@ -44,6 +44,18 @@ int launch_box_loss(const BoxLossParams& p, hipStream_t s);
 int launch_mask_loss(const MaskLossParams& p, hipStream_t s);
 int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, float lr, float momentum, float weight_decay,
                         float inv_loss_scale, int first_step, hipStream_t s);
+// one layer of the fold (master fp32 -> fp16 GEMM operands); Cout == 0 marks a bias copy (w32 -> fwd32, Cin floats, KH times)
+struct FoldDesc {
+  const float* w32;
+  const float* scale;
+  half_t* fwd;
+  half_t* bwd;
+  float* fwd32;
+  int Cout, Cin, KH, KW, Kpad, kc, KpadT;
+  unsigned block_start;     // first block of this entry in the table launch
+};
+unsigned fold_desc_blocks(const FoldDesc& d);
+int launch_fold_table(const FoldDesc* table_dev, int n_desc, unsigned total_blocks, hipStream_t s);
 int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
                         int kc, int KpadT, hipStream_t s);
 #define RS_BIAS_GRAD_SLICES 128   // scratch: RS_BIAS_GRAD_SLICES * cout floats

@@ -166,24 +166,42 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* w, float* buf,
 
 // w32: [Cout][Kpad] fp32 master, K = (kh,kw,ci); fwd: same layout fp16 with scale[co] folded; bwd: [Cin][KpadT] fp16,
 // column ((KH-1-kh)*KW + (KW-1-kw))*kc + co (kc = Cout rounded up to the 64-channel K step; the padding columns stay zero)
-__global__ __launch_bounds__(256) void fold_weights_kernel(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin,
-                                                          int KH, int KW, int Kpad, int kc, int KpadT) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long n = (long long)Cout * KH * KW * Cin;
-  if (i >= n) return;
-  const int ci = (int)(i % Cin);
-  long long t = i / Cin;
-  const int kw = (int)(t % KW); t /= KW;
-  const int kh = (int)(t % KH);
-  const int co = (int)(t / KH);
-  float v = w32[(long long)co * Kpad + (kh * KW + kw) * Cin + ci] * (scale ? scale[co] : 1.f);
+__device__ __forceinline__ void fold_element(const FoldDesc& d, long long i) {
+  const int ci = (int)(i % d.Cin);
+  long long t = i / d.Cin;
+  const int kw = (int)(t % d.KW); t /= d.KW;
+  const int kh = (int)(t % d.KH);
+  const int co = (int)(t / d.KH);
+  float v = d.w32[(long long)co * d.Kpad + (kh * d.KW + kw) * d.Cin + ci] * (d.scale ? d.scale[co] : 1.f);
   // keep the fp32 product as its own rounding step: hipcc otherwise selects v_fma_mixlo_f16 (product rounded ONCE, to
   // fp16), which differs from the host fold (numpy: fp32 multiply, then astype(float16)) on fp32-rounding ties -- measured
   // 5 of 73,728 weights one fp16 ulp apart
   asm volatile("" : "+v"(v));
   const half_t h = (half_t)v;
-  fwd[(long long)co * Kpad + (kh * KW + kw) * Cin + ci] = h;
-  if (bwd) bwd[(long long)ci * KpadT + ((KH - 1 - kh) * KW + (KW - 1 - kw)) * kc + co] = h;   // kc >= Cout: channel stride per tap
+  d.fwd[(long long)co * d.Kpad + (kh * d.KW + kw) * d.Cin + ci] = h;
+  if (d.bwd) d.bwd[(long long)ci * d.KpadT + ((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.kc + co] = h;   // kc >= Cout: channel stride per tap
+}
+__global__ __launch_bounds__(256) void fold_weights_kernel(const FoldDesc d) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < (long long)d.Cout * d.KH * d.KW * d.Cin) fold_element(d, i);
+}
+// every layer of a trainer in ONE launch: the block looks its layer up in the table (block_start ascending, n_desc <= a few
+// hundred: binary search), then folds 256 elements of it. A descriptor with Cout == 0 is a bias copy: fwd32[g*n + j] =
+// w32[j] for g < tile (the 2x2 deconv's forward bias is the master bias repeated per GEMM).
+__global__ __launch_bounds__(256) void fold_table_kernel(const FoldDesc* __restrict__ table, int n_desc) {
+  int lo = 0, hi = n_desc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_start <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const FoldDesc d = table[lo];
+  const long long i = (long long)(blockIdx.x - d.block_start) * 256 + threadIdx.x;
+  if (d.Cout == 0) {
+    const long long n = (long long)d.Cin * d.KH;           // Cin = length, KH = tile count
+    if (i < n) d.fwd32[i] = d.w32[i % d.Cin];
+    return;
+  }
+  if (i < (long long)d.Cout * d.KH * d.KW * d.Cin) fold_element(d, i);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -532,7 +550,20 @@ int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_
                         int kc, int KpadT, hipStream_t s) {
   RS_CHECK(w32 && fwd && Cout > 0 && Cin > 0 && kc >= Cout && (!bwd || KH * KW * kc <= KpadT), RS_ERR_ARG, "fold: bad arguments");
   const long long n = (long long)Cout * KH * KW * Cin;
-  hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, w32, scale, fwd, bwd, Cout, Cin, KH, KW, Kpad, kc, KpadT);
+  FoldDesc d = {};
+  d.w32 = w32; d.scale = scale; d.fwd = fwd; d.bwd = bwd;
+  d.Cout = Cout; d.Cin = Cin; d.KH = KH; d.KW = KW; d.Kpad = Kpad; d.kc = kc; d.KpadT = KpadT;
+  hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+unsigned fold_desc_blocks(const FoldDesc& d) {
+  const long long n = d.Cout == 0 ? (long long)d.Cin * d.KH : (long long)d.Cout * d.KH * d.KW * d.Cin;
+  return (unsigned)cdiv(n, 256);
+}
+int launch_fold_table(const FoldDesc* table_dev, int n_desc, unsigned total_blocks, hipStream_t s) {
+  RS_CHECK(table_dev && n_desc > 0 && total_blocks > 0, RS_ERR_ARG, "fold table: bad arguments");
+  hipLaunchKernelGGL(fold_table_kernel, dim3(total_blocks), dim3(256), 0, s, table_dev, n_desc);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
