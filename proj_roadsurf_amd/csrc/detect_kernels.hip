@@ -737,11 +737,15 @@ __global__ __launch_bounds__(256) void roi_align_win_kernel(const RoiAlignParams
 //   dF[y][x][c] += wy[ph][y] * wx[pw][x] * g[ph][pw][c] / count,
 // with float atomics into the fp32 gradient maps (as torchvision's roi_align_backward_kernel does with atomicAdd:
 // [EXT tv: csrc/ops/cuda/roi_align_kernel.cu]; summation order, hence the last bits, vary from run to run there too).
-// Same level assignment, tables, half-wave-per-bin / 8-channels-per-lane layout as the forward kernel.
+// Same level assignment and per-bin tables as the forward kernel; the work is laid out per CELL of the RoI's window
+// (gather over the bins that reach the cell, then one atomic per channel), see below.
 // ---------------------------------------------------------------------------------------------
+#define RS_ROI_CELLS 320   // rows/cols of a whole RoI window the gather form handles (14 bins x 22 samples + 2 at most)
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams p) {
   __shared__ float s_w[2][RS_ROI_PMAX][RS_ROI_WMAX];
   __shared__ int s_base[2][RS_ROI_PMAX], s_len[2][RS_ROI_PMAX];
+  __shared__ short s_lo[2][RS_ROI_CELLS], s_hi[2][RS_ROI_CELLS];
+  __shared__ int s_org[2], s_ext[2];
   const int entry = blockIdx.x;
   const int tid = threadIdx.x;
   int n_entries = p.S;
@@ -807,6 +811,71 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
   // kernel is ~6x slower (measured: 25.7 -> see DESIGN.md ms for 8 x 1024 RoIs).
   const int wv = tid >> 6, ln = tid & 63;
   float* dfl = dfeat - l32 * 8 + ln;              // undo the forward-style channel offset baked into dfeat
+
+  // ---- gather form: neighbouring bins' windows overlap (by 1-2 cells on each side), so per-bin scattering issues
+  // 1.5x (P=7, g=3) to 3.3x (P=14, g=2) more atomics than the RoI has cells.  Instead one wave per CELL of the RoI's whole
+  // window sums the few bins that reach it (gradient tile read through L1/L2) and issues ONE atomic per channel.
+  // s_lo/s_hi: per window row / column the range of bins that may cover it.
+  if (tid == 0 || tid == 32) {
+    const int ax = tid >> 5;
+    int org = 0x7fffffff, end = -1, bad = 0;
+    for (int b = 0; b < P; ++b) {
+      const int len = s_len[ax][b];
+      if (len < 0) { bad = 1; break; }
+      if (len == 0) continue;
+      org = min(org, s_base[ax][b]);
+      end = max(end, s_base[ax][b] + len);
+    }
+    if (end < 0) { org = 0; end = 0; }
+    if (end - org > RS_ROI_CELLS) bad = 1;
+    s_org[ax] = org;
+    s_ext[ax] = bad ? -1 : end - org;
+  }
+  __syncthreads();
+  const int eh = s_ext[0], ew = s_ext[1];
+  if (eh >= 0 && ew >= 0) {
+    for (int t = tid; t < eh + ew; t += 256) {
+      const int ax = t >= eh ? 1 : 0;
+      const int rel = ax ? t - eh : t;
+      const int y = s_org[ax] + rel;
+      int lo = P, hi = 0;
+      for (int b = 0; b < P; ++b) {
+        const int j = y - s_base[ax][b];
+        if (j >= 0 && j < s_len[ax][b] && s_w[ax][b][j] != 0.f) { lo = min(lo, b); hi = max(hi, b + 1); }
+      }
+      s_lo[ax][rel] = (short)lo;
+      s_hi[ax][rel] = (short)hi;
+    }
+    __syncthreads();
+    const int oy = s_org[0], ox = s_org[1];
+    for (int cell = wv; cell < eh * ew; cell += 4) {           // uniform per wave; no barrier below
+      const int ty = cell / ew, tx = cell - ty * ew;
+      const int plo = s_lo[0][ty], phi = s_hi[0][ty], qlo = s_lo[1][tx], qhi = s_hi[1][tx];
+      if (plo >= phi || qlo >= qhi) continue;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int ph = plo; ph < phi; ++ph) {
+        const int jy = oy + ty - s_base[0][ph];
+        if (jy < 0 || jy >= s_len[0][ph]) continue;
+        const float wy = s_w[0][ph][jy];
+        if (wy == 0.f) continue;
+        for (int pw = qlo; pw < qhi; ++pw) {
+          const int jx = ox + tx - s_base[1][pw];
+          if (jx < 0 || jx >= s_len[1][pw]) continue;
+          const float wgt = wy * s_w[1][pw][jx];
+          if (wgt == 0.f) continue;
+          const half_t* gp = gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + ln;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] += wgt * ((float)gp[c * 64] / count);
+        }
+      }
+      float* d = dfl + ((long long)(oy + ty) * (W + 2) + ox + tx) * 256;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) atomicAdd(d + c * 64, acc[c]);
+    }
+    return;
+  }
+
+  // ---- window larger than the tables (very elongated RoI): per-bin scatter
   for (int b0 = 0; b0 < P * P; b0 += 4) {
     const int b = b0 + wv;
     if (b >= P * P) break;                        // uniform per wave; no barrier below
