@@ -219,13 +219,28 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
   }
 }
 
-// grad[co][k] (+)= scale[co] * sum_z partial[z][co][k], z in ascending order
+// grad[co][k] (+)= scale[co] * sum_z partial[z][co][k].  A block owns 64 consecutive elements; wave g sums the planes
+// z = g, g+4, ... (four independent load chains per element instead of one `splits`-long one: the kernel is pure latency
+// at these sizes), then the four sums are added in the fixed order ((g0+g1)+g2)+g3 -- deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int splits, long long n_el, int Kpad,
                                                            const float* scale, float* grad, int accumulate) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_el) return;
+  __shared__ float part[4][64];
+  const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 64 + e;
   float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += partial[(long long)z * n_el + i];
+  if (i < n_el) {
+    int z = g;
+    for (; z + 12 < splits; z += 16) {
+      const float a = partial[(long long)z * n_el + i], b = partial[(long long)(z + 4) * n_el + i];
+      const float c = partial[(long long)(z + 8) * n_el + i], d = partial[(long long)(z + 12) * n_el + i];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; z < splits; z += 4) s += partial[(long long)z * n_el + i];
+  }
+  part[g][e] = s;
+  __syncthreads();
+  if (g != 0 || i >= n_el) return;
+  s = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
   if (scale) s *= scale[i / Kpad];
   grad[i] = accumulate ? grad[i] + s : s;
 }
@@ -257,7 +272,7 @@ int launch_conv_wgrad(const WgradParams& p, hipStream_t stream) {
   RS_HIP(hipGetLastError());
   if (p.splits == 1 && units * 64 == p.Kpad) return RS_OK;       // stored by the kernel itself (no padding columns to define)
   const long long n_el = (long long)p.Cout * p.Kpad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n_el, 256)), dim3(256), 0, stream, p.partial, p.splits, n_el, p.Kpad,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n_el, 64)), dim3(256), 0, stream, p.partial, p.splits, n_el, p.Kpad,
                      p.scale, p.grad, p.accumulate);
   RS_HIP(hipGetLastError());
   return RS_OK;

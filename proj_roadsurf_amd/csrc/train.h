@@ -58,7 +58,7 @@ unsigned fold_desc_blocks(const FoldDesc& d);
 int launch_fold_table(const FoldDesc* table_dev, int n_desc, unsigned total_blocks, hipStream_t s);
 int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
                         int kc, int KpadT, hipStream_t s);
-#define RS_BIAS_GRAD_SLICES 128   // scratch: RS_BIAS_GRAD_SLICES * cout floats
+#define RS_BIAS_GRAD_SLICES 1024  // scratch: RS_BIAS_GRAD_SLICES * cout floats
 int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s, const int* m_count,
                      int m_mul, float* scratch);
 int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s);

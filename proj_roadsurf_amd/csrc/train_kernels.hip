@@ -381,39 +381,74 @@ __global__ __launch_bounds__(1024) void subsample_kernel(const SubsampleParams p
 }
 
 // bias gradient: grad[c] = sum over rows of dy[row][c] (halo rows are zero, so the whole buffer can be summed).
-// Stage 1: workgroup (8 channels, row slice z) -> scratch[z][c], fixed order inside; stage 2 adds the slices in order
-// (bitwise reproducible, no atomics).
+// Stage 1: workgroup = one row slice over ALL channels: thread t owns the 8-channel group t % (C/8) of rows t / (C/8),
+// + 256/(C/8), ... of its slice, so a wave reads whole contiguous rows (C = 256: two rows per load instruction); fixed
+// order inside (per thread ascending rows, then the row groups in ascending order) -> scratch[z][c].  Stage 2 adds the
+// slices in order (bitwise reproducible, no atomics).
 __global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* scratch,
                                                        const int* m_count, int m_mul) {
-  __shared__ float red[256][8];
+  __shared__ float red[256][9];
   if (m_count) { const long long mc = (long long)(*m_count) * m_mul; if (mc < rows) rows = mc; }
-  const int c0 = blockIdx.x * 8;
-  const long long per = (rows + gridDim.y - 1) / gridDim.y;
-  const long long r0 = (long long)blockIdx.y * per;
-  long long r1 = r0 + per;
-  if (r1 > rows) r1 = rows;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long long r = r0 + threadIdx.x; r < r1; r += 256) {
-    const half8 v = *(const half8*)(dy + r * C + c0);
+  const int cgs = C >> 3;
+  for (int cg0 = 0; cg0 < cgs; cg0 += 256) {          // C <= 2048: one pass
+    const int ncg = min(256, cgs - cg0);
+    const int rpi = 256 / ncg;                        // rows per load round
+    const int cg = threadIdx.x % ncg, ro = threadIdx.x / ncg;
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * per;
+    long long r1 = r0 + per;
+    if (r1 > rows) r1 = rows;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ro < rpi) {
+      const half_t* src = dy + (long long)(cg0 + cg) * 8;
+      long long r = r0 + ro;
+      for (; r + 3 * rpi < r1; r += 4 * rpi) {
+        const half8 v0 = *(const half8*)(src + r * C), v1 = *(const half8*)(src + (r + rpi) * C);
+        const half8 v2 = *(const half8*)(src + (r + 2 * rpi) * C), v3 = *(const half8*)(src + (r + 3 * rpi) * C);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
-  }
+        for (int i = 0; i < 8; ++i) { acc[i] += (float)v0[i]; acc[i] += (float)v1[i]; acc[i] += (float)v2[i]; acc[i] += (float)v3[i]; }
+      }
+      for (; r < r1; r += rpi) {
+        const half8 v = *(const half8*)(src + r * C);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[i];
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) red[threadIdx.x][i] += red[threadIdx.x + s][i];
+        for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+      }
+    }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    // thread (cg, i): sum over the row groups in ascending order
+    for (int t = threadIdx.x; t < ncg * 8; t += 256) {
+      const int g = t >> 3, i = t & 7;
+      float sum = 0.f;
+      for (int q = 0; q < rpi; ++q) sum += red[q * ncg + g][i];
+      const int c = (cg0 + g) * 8 + i;
+      if (c < cout) scratch[(long long)blockIdx.x * cout + c] = sum;
+    }
   }
-  if (threadIdx.x < 8 && c0 + (int)threadIdx.x < cout) scratch[(long long)blockIdx.y * cout + c0 + threadIdx.x] = red[0][threadIdx.x];
 }
+// block = 16 channels x 16 slice groups: group g adds the slices z = g, g+16, ... in ascending order, then the 16 group sums
+// are added in ascending order (fixed order, hence reproducible)
 __global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float* scratch, int slices, int cout, float* grad, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cout) return;
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + e;
   float s = 0.f;
-  for (int z = 0; z < slices; ++z) s += scratch[(long long)z * cout + c];
+  if (c < cout) {
+    int z = g;
+    for (; z + 48 < slices; z += 64) {
+      const float a = scratch[(long long)z * cout + c], b = scratch[(long long)(z + 16) * cout + c];
+      const float d = scratch[(long long)(z + 32) * cout + c], f = scratch[(long long)(z + 48) * cout + c];
+      s += a; s += b; s += d; s += f;
+    }
+    for (; z < slices; z += 16) s += scratch[(long long)z * cout + c];
+  }
+  part[g][e] = s;
+  __syncthreads();
+  if (g != 0 || c >= cout) return;
+  s = part[0][e];
+  for (int q = 1; q < 16; ++q) s += part[q][e];
   grad[c] = accumulate ? grad[c] + s : s;
 }
 
@@ -587,11 +622,11 @@ int launch_subsample(const SubsampleParams& p, int N, hipStream_t s) {
 int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s, const int* m_count,
                      int m_mul, float* scratch) {
   RS_CHECK(dy && grad && scratch && rows > 0 && C % 8 == 0 && cout > 0 && cout <= C, RS_ERR_ARG, "bias_grad: bad arguments");
-  int slices = (int)(rows / 2048);               // >= 8 rows per thread and slice
+  int slices = (int)(rows * (C >> 3) / 4096);    // >= 16 rows per thread and slice
   if (slices < 1) slices = 1;
   if (slices > RS_BIAS_GRAD_SLICES) slices = RS_BIAS_GRAD_SLICES;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(cout, 8), slices), dim3(256), 0, s, dy, rows, C, cout, scratch, m_count, m_mul);
-  hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, s, scratch, slices, cout, grad, accumulate);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(slices), dim3(256), 0, s, dy, rows, C, cout, scratch, m_count, m_mul);
+  hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(cdiv(cout, 16)), dim3(256), 0, s, scratch, slices, cout, grad, accumulate);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
