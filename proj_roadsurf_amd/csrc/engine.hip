@@ -55,6 +55,7 @@ struct Stage {
   double last_flops = 0, last_bytes = 0;
   int variant = -2;      // conv tile variant of the last call (-2 = not a conv stage)
   bool narrow = false;   // latency-bound detection glue (few workgroups): runs on the engine's side stream
+  bool grad_side = false;   // trainer: weight / bias gradient, off the input-gradient chain (may run on the trainer's side stream)
   int phase = 0;         // 0 = preprocess..RPN proposals, 1 = box head..detections, 2 = mask head + paste
   hipEvent_t handoff = nullptr;   // recorded on the previous stage's stream when this stage switches streams
 };
