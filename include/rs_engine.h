@@ -300,6 +300,10 @@ int rs_trainer_roi_step(rs_trainer* t, int n, uint32_t seed);
  * rasterises the polygons on the host at the same point ([EXT d2: structures/masks.py PolygonMasks.crop_and_resize]). */
 int rs_trainer_mask_forward(rs_trainer* t, int n);
 int rs_trainer_mask_backward(rs_trainer* t, int n, const uint8_t* targets_host, int n_entries);
+/* Read-back of the RoIs sampled by the current rs_trainer_roi_step for the host-side mask targets: boxes [n][1024][4], gt index
+ * [n][1024], counts [n][2] (foreground, total).  Waits for the sampling only (own copy stream, event recorded in roi_step): the
+ * box head and an already enqueued rs_trainer_mask_forward keep running while the host rasterises. */
+int rs_trainer_fetch_rois(rs_trainer* t, int n, float* boxes_host, int32_t* gt_index_host, int32_t* counts_host);
 int rs_trainer_set_rpn_topk(rs_trainer* t, int pre_nms_topk_train, int post_nms_topk_train);
 /* Sampler sizes (defaults = the reference YAML: 256 @ 0.5 anchors, 1024 @ 0.25 RoIs per image). */
 int rs_trainer_set_sampling(rs_trainer* t, int rpn_batch, float rpn_positive_fraction, int roi_batch, float roi_positive_fraction);
@@ -366,6 +370,11 @@ int64_t rs_vec_gpkg_blobs(const rs_vec_result* r, const double* xform, int32_t s
  * each; out: [mask_size][mask_size] 0/1. */
 int rs_rasterize_polygons_within_box(const double* polys, const int32_t* poly_len, int n_polys, const double box[4], int mask_size,
                                      uint8_t* out);
+/* The same for every sampled foreground RoI of a training step in one call (host threads over the entries; threads <= 0: up
+ * to 16): instance g owns polygons inst_first[g] .. inst_first[g+1]-1, polygon q = poly_len[q] doubles at polys + poly_off[q];
+ * entry e rasterises instance entry_inst[e] inside boxes[e] (x1,y1,x2,y2 as read back from "roi_boxes") -> out[e][S*S]. */
+int rs_rasterize_entries(const double* polys, const int64_t* poly_off, const int32_t* poly_len, const int32_t* inst_first, int n_inst,
+                         const int32_t* entry_inst, const float* boxes, int n_entries, int mask_size, uint8_t* out, int threads);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@
 //     strictly greater than epsilon; a ring that would drop below 4 points keeps its original vertices.
 // Compiled with -ffp-contract=off so the float64 arithmetic matches numpy's (no fused multiply-add).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -361,10 +362,14 @@ int64_t rs_vec_gpkg_blobs(const rs_vec_result* r, const double* xform, int32_t s
 // ---------------------------------------------------------------------------------------------------------------
 static void rle_fr_poly(const double* xy, int k, int h, int w, std::vector<uint8_t>& colmajor) {
   const double scale = 5.0;
-  std::vector<int> x(k + 1), y(k + 1);
+  // scratch kept per thread: the training step rasterises thousands of RoI targets per batch, and allocating these afresh
+  // per polygon costs more than the arithmetic (and serialises host threads in the allocator)
+  static thread_local std::vector<int> x, y, u, v;
+  static thread_local std::vector<long long> pts, a, b;
+  x.assign(k + 1, 0); y.assign(k + 1, 0);
+  u.clear(); v.clear(); pts.clear(); b.clear();
   for (int j = 0; j < k; ++j) { x[j] = (int)(scale * xy[j * 2 + 0] + .5); y[j] = (int)(scale * xy[j * 2 + 1] + .5); }
   x[k] = x[0]; y[k] = y[0];
-  std::vector<int> u, v;
   for (int j = 0; j < k; ++j) {
     int xs = x[j], xe = x[j + 1], ys = y[j], ye = y[j + 1];
     const int dx = std::abs(xe - xs), dy = std::abs(ys - ye);
@@ -374,7 +379,6 @@ static void rle_fr_poly(const double* xy, int k, int h, int w, std::vector<uint8
     if (dx >= dy) for (int d = 0; d <= dx; ++d) { const int t = flip ? dx - d : d; u.push_back(t + xs); v.push_back((int)(ys + s * t + .5)); }
     else for (int d = 0; d <= dy; ++d) { const int t = flip ? dy - d : d; v.push_back(t + ys); u.push_back((int)(xs + s * t + .5)); }
   }
-  std::vector<long long> pts;
   for (size_t j = 1; j < u.size(); ++j) if (u[j] != u[j - 1]) {
     double xd = (double)(u[j] < u[j - 1] ? u[j] : u[j] - 1);
     xd = (xd + .5) / scale - .5;
@@ -387,7 +391,7 @@ static void rle_fr_poly(const double* xy, int k, int h, int w, std::vector<uint8
   }
   pts.push_back((long long)h * w);
   std::sort(pts.begin(), pts.end());
-  std::vector<long long> a(pts.size()), b;
+  a.assign(pts.size(), 0);
   a[0] = pts[0];
   for (size_t i = 1; i < pts.size(); ++i) a[i] = pts[i] - pts[i - 1];
   size_t j = 0;
@@ -412,8 +416,8 @@ int rs_rasterize_polygons_within_box(const double* polys, const int32_t* poly_le
   memset(out, 0, (size_t)S * S);
   const double w = box[2] - box[0], h = box[3] - box[1];
   const double ratio_h = S / std::max(h, 0.1), ratio_w = S / std::max(w, 0.1);
-  std::vector<double> p;
-  std::vector<uint8_t> cm;
+  static thread_local std::vector<double> p;
+  static thread_local std::vector<uint8_t> cm;
   size_t off = 0;
   for (int i = 0; i < n_polys; ++i) {
     const int len = poly_len[i];
@@ -431,6 +435,48 @@ int rs_rasterize_polygons_within_box(const double* polys, const int32_t* poly_le
       for (int yy = 0; yy < S; ++yy) out[(size_t)yy * S + xx] |= cm[(size_t)xx * S + yy];     // merge = union; RLE is column-major
   }
   return RS_OK;
+}
+
+// Batched form for the training step: instance g owns the polygons inst_first[g] .. inst_first[g+1]-1 (polygon q: poly_len[q]
+// doubles at polys + poly_off[q]); entry e = instance entry_inst[e] inside boxes[e] (float, as read back from the device).
+// One call per step instead of one per RoI; entries are independent, so they are spread over `threads` host threads.
+int rs_rasterize_entries(const double* polys, const int64_t* poly_off, const int32_t* poly_len, const int32_t* inst_first, int n_inst,
+                         const int32_t* entry_inst, const float* boxes, int n_entries, int mask_size, uint8_t* out, int threads) {
+  if (n_entries == 0) return RS_OK;
+  if (!polys || !poly_off || !poly_len || !inst_first || !entry_inst || !boxes || !out || n_inst <= 0 || n_entries < 0 || mask_size <= 0) return RS_ERR_ARG;
+  for (int e = 0; e < n_entries; ++e) if (entry_inst[e] < 0 || entry_inst[e] >= n_inst) return RS_ERR_ARG;
+  if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  threads = std::max(1, std::min(threads, (n_entries + 31) / 32));
+  const size_t SS = (size_t)mask_size * mask_size;
+  std::atomic<int> next(0), err(0);
+  auto work = [&]() {
+    std::vector<double> flat;
+    std::vector<int32_t> lens;
+    for (;;) {
+      const int e0 = next.fetch_add(16);
+      if (e0 >= n_entries) break;
+      for (int e = e0; e < std::min(n_entries, e0 + 16); ++e) {
+        const int g = entry_inst[e];
+        flat.clear(); lens.clear();
+        for (int q = inst_first[g]; q < inst_first[g + 1]; ++q) {
+          flat.insert(flat.end(), polys + poly_off[q], polys + poly_off[q] + poly_len[q]);
+          lens.push_back(poly_len[q]);
+        }
+        const double box[4] = {(double)boxes[4 * e], (double)boxes[4 * e + 1], (double)boxes[4 * e + 2], (double)boxes[4 * e + 3]};
+        static const double none = 0.0;
+        const int rc = rs_rasterize_polygons_within_box(flat.empty() ? &none : flat.data(), lens.empty() ? inst_first : lens.data(), (int)lens.size(),
+                                                        box, mask_size, out + (size_t)e * SS);
+        if (rc) err.store(rc);
+      }
+    }
+  };
+  if (threads == 1) work();
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back(work);
+    for (auto& th : pool) th.join();
+  }
+  return err.load();
 }
 
 }  // extern "C"

@@ -604,6 +604,7 @@ class Trainer:
         lib.rs_trainer_set_grad_divisor.argtypes = [vp, C.c_float]
         lib.rs_trainer_copy_state.argtypes = [vp, vp]
         lib.rs_trainer_grad_buffer.argtypes = [vp]
+        lib.rs_trainer_fetch_rois.argtypes = [vp, C.c_int, vp, vp, vp]
         lib.rs_trainer_grad_buffer.restype = vp
         lib.rs_trainer_mask_forward.argtypes = [vp, i32]
         lib.rs_trainer_mask_backward.argtypes = [vp, i32, vp, i32]
@@ -707,16 +708,21 @@ class Trainer:
     def mask_entries(self, gt_polygons: Sequence[Sequence[Sequence[np.ndarray]]], n: int) -> Tuple[np.ndarray, List[Tuple[int, int]]]:
         """Host part of the mask branch: gt masks of the sampled foreground RoIs (``PolygonMasks.crop_and_resize``).
         gt_polygons[image][gt index] = list of polygons ([x0,y0,...], network-input pixels).  Returns (targets, [(image, slot)])."""
-        from .train_targets import rasterize_polygons_within_box
-        cnt = self.tensor("roi_sampled_count")
-        boxes, gti = self.tensor("roi_boxes"), self.tensor("roi_gt_index")
+        from .train_targets import rasterize_entries
+        boxes = np.empty((n, 1024, 4), np.float32)
+        gti = np.empty((n, 1024), np.int32)
+        cnt = np.empty((n, 2), np.int32)
+        _check(self.lib, self.lib.rs_trainer_fetch_rois(self._h, n, boxes.ctypes.data_as(C.c_void_p), gti.ctypes.data_as(C.c_void_p),
+                                                        cnt.ctypes.data_as(C.c_void_p)), "rs_trainer_fetch_rois")
         side = 2 * self.spec.mask_pooler_resolution
-        out, where = [], []
-        for i in range(n):
-            for j in range(min(int(cnt[i, 0]), 256)):
-                out.append(rasterize_polygons_within_box(gt_polygons[i][int(gti[i, j])], boxes[i, j], side))
-                where.append((i, j))
-        return (np.stack(out) if out else np.zeros((0, side, side), bool)), where
+        first = np.zeros(n + 1, np.int64)                      # instance index of image i's gt j = first[i] + j
+        first[1:] = np.cumsum([len(gt_polygons[i]) for i in range(n)])
+        instances = [polys for i in range(n) for polys in gt_polygons[i]]
+        where = [(i, j) for i in range(n) for j in range(min(int(cnt[i, 0]), 256))]
+        if not where:
+            return np.zeros((0, side, side), bool), where
+        ii = np.array([w[0] for w in where]); jj = np.array([w[1] for w in where])
+        return rasterize_entries(instances, first[ii] + gti[ii, jj], boxes[ii, jj], side), where
 
     # ------------------------------------------------------------------ a whole step
     def train_step(self, tiles: np.ndarray, gt_boxes: Sequence[np.ndarray], gt_classes: Sequence[np.ndarray],

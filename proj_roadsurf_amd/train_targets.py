@@ -10,6 +10,35 @@ from typing import Sequence
 import numpy as np
 
 
+def rasterize_entries(instances: Sequence[Sequence[np.ndarray]], entry_instance: np.ndarray, boxes: np.ndarray, mask_size: int,
+                      threads: int = 0) -> np.ndarray:
+    """All mask targets of a step in one native call: instances[g] = polygons of gt instance g, entry e = instance
+    entry_instance[e] cropped to boxes[e] (float32 x1,y1,x2,y2).  Returns (n_entries, mask_size, mask_size) bool."""
+    from .engine import load_library, RsError
+    lib = load_library()
+    ne = int(len(entry_instance))
+    out = np.zeros((ne, mask_size, mask_size), np.uint8)
+    if ne == 0:
+        return out.astype(bool)
+    arrs = [np.asarray(p, np.float64).reshape(-1) for polys in instances for p in polys]
+    lens = np.array([a.size for a in arrs], np.int32)
+    off = np.zeros(len(arrs), np.int64)
+    if len(arrs) > 1:
+        off[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+    flat = np.ascontiguousarray(np.concatenate(arrs)) if arrs else np.zeros(1)
+    first = np.zeros(len(instances) + 1, np.int32)
+    first[1:] = np.cumsum([len(polys) for polys in instances])
+    ei = np.ascontiguousarray(np.asarray(entry_instance, np.int32))
+    bx = np.ascontiguousarray(np.asarray(boxes, np.float32).reshape(ne, 4))
+    lib.rs_rasterize_entries.restype = C.c_int
+    lib.rs_rasterize_entries.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    rc = lib.rs_rasterize_entries(flat.ctypes.data, off.ctypes.data, lens.ctypes.data, first.ctypes.data, len(instances), ei.ctypes.data,
+                                  bx.ctypes.data, ne, mask_size, out.ctypes.data, threads)
+    if rc != 0:
+        raise RsError(f"rs_rasterize_entries failed ({rc})")
+    return out.astype(bool)
+
+
 def rasterize_polygons_within_box(polygons: Sequence[np.ndarray], box: np.ndarray, mask_size: int) -> np.ndarray:
     """Polygons ([x0,y0,x1,y1,...] each, image coordinates) of one instance -> (mask_size, mask_size) bool target inside ``box``."""
     from .engine import load_library, RsError

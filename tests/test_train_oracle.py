@@ -164,3 +164,29 @@ def test_native_polygon_rasteriser_equals_oracle_restatement():
     sq = [np.array([10.0, 20, 50, 20, 50, 60, 10, 60])]
     assert native(sq, np.array([10.0, 20.0, 50.0, 60.0]), 28).all()
     assert not native(sq, np.array([100.0, 100.0, 120.0, 130.0]), 28).any()
+
+
+def test_batched_rasteriser_equals_the_per_roi_call():
+    """rs_rasterize_entries (one native call per training step, host threads over the entries) == rs_rasterize_polygons_within_box
+    per entry, bit for bit; multi-polygon instances, repeated instances, float32 boxes as read back from the device; also the
+    oracle restatement on a subset."""
+    import os
+    from proj_roadsurf_amd.engine import LIB_PATH
+    if not os.path.exists(LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    from proj_roadsurf_amd.train_targets import rasterize_entries, rasterize_polygons_within_box as native
+    rng = np.random.default_rng(11)
+    instances = [[(rng.random(2 * int(rng.integers(3, 12))) * 300).astype(np.float64) for _ in range(int(rng.integers(1, 4)))] for _ in range(17)]
+    ne = 300
+    ei = rng.integers(0, len(instances), ne)
+    xy = rng.random((ne, 2)) * 200
+    boxes = np.concatenate([xy, xy + rng.random((ne, 2)) * 150 + 1], 1).astype(np.float32)
+    for threads in (1, 3, 0):
+        got = rasterize_entries(instances, ei, boxes, 28, threads=threads)
+        assert got.shape == (ne, 28, 28) and got.dtype == bool
+        for e in range(ne):
+            assert np.array_equal(got[e], native(instances[int(ei[e])], boxes[e], 28)), (threads, e)
+    for e in range(0, ne, 25):
+        assert np.array_equal(got[e], T.rasterize_polygons_within_box(instances[int(ei[e])], boxes[e].astype(np.float64), 28)), e
+    assert rasterize_entries(instances, np.zeros(0, np.int32), np.zeros((0, 4), np.float32), 28).shape == (0, 28, 28)

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--overfit", type=int, default=0)
     ap.add_argument("--loss-scale", type=float, default=1024.0)
+    ap.add_argument("--gt-per-image", type=int, default=0, help="0: 3-8 boxes per tile; N: exactly N small boxes (every gt box is "
+                    "also a foreground RoI, so this sets the mask-branch load: host rasterisation + mask-head GEMMs)")
     args = ap.parse_args()
     from proj_roadsurf_amd.engine import Trainer
     from proj_roadsurf_amd.spec import EngineSpec
@@ -38,15 +40,15 @@ def main():
     s = 800.0 / T
     boxes, classes, polys = [], [], []
     for i in range(B):
-        k = int(rng.integers(3, 9))
+        k = args.gt_per_image or int(rng.integers(3, 9))
         xy = rng.uniform(20, T - 160, (k, 2))
-        wh = rng.uniform(30, 150, (k, 2))
+        wh = rng.uniform(30, 150, (k, 2)) if not args.gt_per_image else rng.uniform(15, 60, (k, 2))
         b = np.concatenate([xy, xy + wh], 1) * s
         boxes.append(b.astype(np.float32))
         classes.append(rng.integers(0, 2, k))
         polys.append([[np.array([x0, y0, x1, y0, x1, y1, x0, y1])] for x0, y0, x1, y1 in b.tolist()])
     tr = Trainer(spec, W, (T, T, 3), batch=B, loss_scale=args.loss_scale)
-    out = {"batch": B, "tile": T, "trainable_values_M": tr.param_count / 1e6}
+    out = {"batch": B, "tile": T, "trainable_values_M": tr.param_count / 1e6, "gt_per_image": args.gt_per_image or "3-8"}
     if args.overfit:
         curve = []
         for it in range(args.overfit):
@@ -68,7 +70,8 @@ def main():
             tr.apply_sgd(1e-5, 0.9, 1e-4)
         tr.sync()
         dt = time.perf_counter() - t0
-        out.update({"iters": args.iters, "s_per_iter": dt / args.iters, "images_per_s": B * args.iters / dt})
+        out.update({"iters": args.iters, "s_per_iter": dt / args.iters, "images_per_s": B * args.iters / dt,
+                    "mask_entries_last_step": int(tr.tensor("mask_total")[0]) if spec.mask_on else 0})
     print(json.dumps(out))
     tr.close()
 
