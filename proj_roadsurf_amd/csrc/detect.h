@@ -33,6 +33,8 @@ struct NmsParams {
   float thresh;
   int debug;                // timing experiments only: 1 = skip the scan, 2 = skip the mask build
   unsigned long long* scratch;   // cap > 1024: [segments][2048][32] suppression-mask words in global memory
+  int mode;                 // cap > 1024 only: 0 = mask build + scan in one workgroup, 1 = mask build only (gridDim.y workgroups share
+                            // a segment's rows), 2 = scan only (after a mode-1 launch)
 };
 
 struct RpnMergeParams {

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
   const float* boxes = p.boxes + (long long)s * p.cap * 4;
   const uint8_t* valid = p.valid ? p.valid + (long long)s * p.cap : nullptr;
   uint8_t* keep = p.keep + (long long)s * p.cap;
-  for (int i = tid; i < p.cap; i += 1024) keep[i] = 0;
+  if (!(CAP != 1024 && p.mode == 1)) for (int i = tid; i < p.cap; i += 1024) keep[i] = 0;
   if (tid < WPR) sremoved[tid] = 0ull;
   __syncthreads();
   for (int ti = tid; ti < n; ti += 1024) {
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
   // so that every task slot (row pair, word slot) carries the same load and all 16 waves stay busy.
   const int nh = (n + 1) >> 1;
   const int nhp = (nh + 63) & ~63;
-  for (int idx = tid; idx < (nw + 2) * nhp && p.debug != 2; idx += 1024) {
+  const bool build = p.debug != 2 && !(CAP != 1024 && p.mode == 2);
+  for (int idx = tid + blockIdx.y * 1024; idx < (nw + 2) * nhp && build; idx += 1024 * gridDim.y) {
     const int wq = idx / nhp, ip = idx - wq * nhp;
     if (ip >= nh) continue;
     const int first = nw - (ip >> 6);
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
     }
     mask[(long long)i * WPR + w] = bits;
   }
+  if (CAP != 1024 && p.mode == 1) return;                // mask build only: the scan is the next launch (mode 2)
   if (CAP != 1024) __threadfence();       // mask rows in global memory: visible to the scanning wave after the barrier
   __syncthreads();
   // Greedy scan, one wave, 64 boxes (one mask word) per step: the intra-chunk part is resolved on
@@ -1201,7 +1203,19 @@ int launch_nms(const NmsParams& p, int segments, hipStream_t s) {
   NmsParams q = p;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("RS_NMS_DEBUG"); dbg = e ? atoi(e) : 0; } q.debug = dbg; }
   if (p.cap <= 1024) hipLaunchKernelGGL(nms_kernel<1024>, dim3(segments), dim3(1024), lds, s, q);
-  else hipLaunchKernelGGL(nms_kernel<2048>, dim3(segments), dim3(1024), lds_big, s, q);
+  else {
+    // few segments (images x levels) and a quadratic mask build: with one workgroup per segment most of the chip idles, so the
+    // rows of a segment are shared by `parts` workgroups and the (serial, cheap) scan runs as a second launch
+    int parts = segments >= 256 ? 1 : (256 + segments - 1) / segments;
+    if (parts > 16) parts = 16;
+    if (parts == 1) { q.mode = 0; hipLaunchKernelGGL(nms_kernel<2048>, dim3(segments), dim3(1024), lds_big, s, q); }
+    else {
+      q.mode = 1;
+      hipLaunchKernelGGL(nms_kernel<2048>, dim3(segments, parts), dim3(1024), lds_big, s, q);
+      q.mode = 2;
+      hipLaunchKernelGGL(nms_kernel<2048>, dim3(segments), dim3(1024), lds_big, s, q);
+    }
+  }
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
