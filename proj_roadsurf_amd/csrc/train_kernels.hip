@@ -166,42 +166,63 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* w, float* buf,
 
 // w32: [Cout][Kpad] fp32 master, K = (kh,kw,ci); fwd: same layout fp16 with scale[co] folded; bwd: [Cin][KpadT] fp16,
 // column ((KH-1-kh)*KW + (KW-1-kw))*kc + co (kc = Cout rounded up to the 64-channel K step; the padding columns stay zero)
-__device__ __forceinline__ void fold_element(const FoldDesc& d, long long i) {
-  const int ci = (int)(i % d.Cin);
-  long long t = i / d.Cin;
-  const int kw = (int)(t % d.KW); t /= d.KW;
-  const int kh = (int)(t % d.KH);
-  const int co = (int)(t / d.KH);
-  float v = d.w32[(long long)co * d.Kpad + (kh * d.KW + kw) * d.Cin + ci] * (d.scale ? d.scale[co] : 1.f);
-  // keep the fp32 product as its own rounding step: hipcc otherwise selects v_fma_mixlo_f16 (product rounded ONCE, to
-  // fp16), which differs from the host fold (numpy: fp32 multiply, then astype(float16)) on fp32-rounding ties -- measured
-  // 5 of 73,728 weights one fp16 ulp apart
-  asm volatile("" : "+v"(v));
-  const half_t h = (half_t)v;
-  d.fwd[(long long)co * d.Kpad + (kh * d.KW + kw) * d.Cin + ci] = h;
-  if (d.bwd) d.bwd[(long long)ci * d.KpadT + ((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.kc + co] = h;   // kc >= Cout: channel stride per tap
+// One block = one 32 (co) x 32 (ci) tile of one tap: the master rows are read along ci, the forward operand written in the
+// same layout, and the tile goes through LDS so that the transposed copy is written along co (64-byte runs instead of one
+// 2-byte element per row: the scattered form cost 0.31 ms per step for the 44 M weights, this one is bandwidth-bound).
+__device__ __forceinline__ void fold_tile(const FoldDesc& d, unsigned blk, half_t (*tile)[34]) {
+  const int cit = (d.Cin + 31) >> 5, taps = d.KH * d.KW;
+  const int ct = (int)(blk % cit);
+  const unsigned r = blk / cit;
+  const int tap = (int)(r % taps), cot = (int)(r / taps);
+  const int kh = tap / d.KW, kw = tap - kh * d.KW;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = cot * 32 + ty + j * 8, ci = ct * 32 + tx;
+    half_t h = (half_t)0.f;
+    if (co < d.Cout && ci < d.Cin) {
+      const long long idx = (long long)co * d.Kpad + tap * d.Cin + ci;
+      float v = d.w32[idx] * (d.scale ? d.scale[co] : 1.f);
+      // keep the fp32 product as its own rounding step: hipcc otherwise selects v_fma_mixlo_f16 (product rounded ONCE, to
+      // fp16), which differs from the host fold (numpy: fp32 multiply, then astype(float16)) on fp32-rounding ties -- measured
+      // 5 of 73,728 weights one fp16 ulp apart
+      asm volatile("" : "+v"(v));
+      h = (half_t)v;
+      d.fwd[idx] = h;
+    }
+    tile[ty + j * 8][tx] = h;
+  }
+  if (!d.bwd) return;                       // block-uniform
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ci = ct * 32 + ty + j * 8, co = cot * 32 + tx;
+    if (co < d.Cout && ci < d.Cin)          // kc >= Cout: channel stride per tap
+      d.bwd[(long long)ci * d.KpadT + ((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.kc + co] = tile[tx][ty + j * 8];
+  }
 }
 __global__ __launch_bounds__(256) void fold_weights_kernel(const FoldDesc d) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < (long long)d.Cout * d.KH * d.KW * d.Cin) fold_element(d, i);
+  __shared__ half_t tile[32][34];
+  fold_tile(d, blockIdx.x, tile);
 }
 // every layer of a trainer in ONE launch: the block looks its layer up in the table (block_start ascending, n_desc <= a few
-// hundred: binary search), then folds 256 elements of it. A descriptor with Cout == 0 is a bias copy: fwd32[g*n + j] =
-// w32[j] for g < tile (the 2x2 deconv's forward bias is the master bias repeated per GEMM).
+// hundred: binary search), then folds one tile of it. A descriptor with Cout == 0 is a bias copy: fwd32[g*n + j] =
+// w32[j] for g < tile (the 2x2 deconv's forward bias is the master bias repeated per GEMM), 256 elements per block.
 __global__ __launch_bounds__(256) void fold_table_kernel(const FoldDesc* __restrict__ table, int n_desc) {
+  __shared__ half_t tile[32][34];
   int lo = 0, hi = n_desc - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (table[mid].block_start <= blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const FoldDesc d = table[lo];
-  const long long i = (long long)(blockIdx.x - d.block_start) * 256 + threadIdx.x;
   if (d.Cout == 0) {
+    const long long i = (long long)(blockIdx.x - d.block_start) * 256 + threadIdx.x;
     const long long n = (long long)d.Cin * d.KH;           // Cin = length, KH = tile count
     if (i < n) d.fwd32[i] = d.w32[i % d.Cin];
     return;
   }
-  if (i < (long long)d.Cout * d.KH * d.KW * d.Cin) fold_element(d, i);
+  fold_tile(d, blockIdx.x - d.block_start, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -584,17 +605,16 @@ int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, fl
 int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_t* bwd, int Cout, int Cin, int KH, int KW, int Kpad,
                         int kc, int KpadT, hipStream_t s) {
   RS_CHECK(w32 && fwd && Cout > 0 && Cin > 0 && kc >= Cout && (!bwd || KH * KW * kc <= KpadT), RS_ERR_ARG, "fold: bad arguments");
-  const long long n = (long long)Cout * KH * KW * Cin;
   FoldDesc d = {};
   d.w32 = w32; d.scale = scale; d.fwd = fwd; d.bwd = bwd;
   d.Cout = Cout; d.Cin = Cin; d.KH = KH; d.KW = KW; d.Kpad = Kpad; d.kc = kc; d.KpadT = KpadT;
-  hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(fold_weights_kernel, dim3(fold_desc_blocks(d)), dim3(256), 0, s, d);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
 unsigned fold_desc_blocks(const FoldDesc& d) {
-  const long long n = d.Cout == 0 ? (long long)d.Cin * d.KH : (long long)d.Cout * d.KH * d.KW * d.Cin;
-  return (unsigned)cdiv(n, 256);
+  if (d.Cout == 0) return (unsigned)cdiv((long long)d.Cin * d.KH, 256);
+  return (unsigned)(cdiv(d.Cout, 32) * d.KH * d.KW * cdiv(d.Cin, 32));
 }
 int launch_fold_table(const FoldDesc* table_dev, int n_desc, unsigned total_blocks, hipStream_t s) {
   RS_CHECK(table_dev && n_desc > 0 && total_blocks > 0, RS_ERR_ARG, "fold table: bad arguments");
