@@ -250,7 +250,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
 int wgrad_splits(const WgradParams& p) {
   const long long out_tiles = (long long)cdiv(p.Cout, BM) * cdiv(p.KH * p.KW * (p.Cin >> 6), 2);
   const int steps = cdiv(p.M, BK);
-  long long s = cdiv(1024, out_tiles);          // aim at ~4 workgroups per CU
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("RS_WGRAD_TARGET"); target = e ? atoi(e) : 512; if (target < 1 || target > 1024) target = 1024; }   // the trainer sizes its scratch for <= 1024
+  long long s = cdiv(target, out_tiles);        // ~2 workgroups per CU: more splits only add partial-tile traffic (measured 1024 -> 512: -2 % step time)
   if (s > steps / 4) s = steps / 4;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
