@@ -88,6 +88,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--host-workers", type=int, default=4, help="threads for tile decode / vectorisation around the GPU call")
     ap.add_argument("--vector-threads", type=int, default=4, help="threads inside one rs_vectorize_masks call")
     ap.add_argument("--geojson", action="store_true", help="also write <dataset>_detections_..._threshold.geojson (slow: Python feature dicts)")
+    ap.add_argument("--tagged-samples", type=int, default=10,
+                    help="tagged preview PNGs per dataset in sample_tagged_img_subfolder (0 = none)")
     ap.add_argument("--max-tiles", type=int, default=0, help="debug: only the first N tiles of every dataset")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s", stream=sys.stderr)
@@ -176,6 +178,19 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         dt = time.time() - t0
         log.info("%s: %d tiles -> %d features in %.1f s (%.1f tiles/s) -> %s.gpkg", dataset, len(images), n, dt,
                  len(images) / max(dt, 1e-9), base)
+        sub = cfg.get("sample_tagged_img_subfolder")
+        if sub and args.tagged_samples > 0:
+            # the reference tags the first images of every dataset with their predictions (R:config/config_obj_detec.yaml:77)
+            from .tagging import draw_instances
+            os.makedirs(sub, exist_ok=True)
+            names = [c["name"] for c in sorted(d.get("categories", []), key=lambda c: c["id"])]
+            for e in images[: args.tagged_samples]:
+                im = read_tile(e["file_name"])
+                inst = predictor(im)["instances"]
+                rgb = im[:, :, ::-1][:, :, :3]              # read_tile hands the file's bands over in reverse (cv2) order
+                png = os.path.join(sub, f"{dataset}_det_{os.path.splitext(os.path.basename(e['file_name']))[0]}.png")
+                draw_instances(rgb, inst.pred_boxes, inst.pred_classes, inst.scores, inst.pred_masks, names or None).save(png)
+            log.info("%s: %d tagged sample images -> %s/", dataset, min(len(images), args.tagged_samples), sub)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -150,6 +150,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log-period", type=int, default=20)
+    ap.add_argument("--tagged-samples", type=int, default=3, help="tagged ground-truth PNGs per dataset in sample_tagged_img_subfolder (0 = none)")
     ap.add_argument("--val-max-images", type=int, default=0, help="cap on the validation images per evaluation (0 = all)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s", stream=sys.stderr)
@@ -174,6 +175,28 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     recs, cats = load_coco_training_set(cfg["COCO_files"]["trn"])
     if not recs:
         raise SystemExit("no annotated training images")
+    sub = cfg.get("sample_tagged_img_subfolder")
+    if sub and rank == 0 and args.tagged_samples > 0:
+        # the reference saves a few images of every registered dataset with their ground truth drawn in
+        # (R:config/config_obj_detec.yaml:65, detectron2's Visualizer.draw_dataset_dict there; plain PIL here)
+        from .make_detections import read_tile as _read
+        from .tagging import draw_annotations
+        os.makedirs(sub, exist_ok=True)
+        pick = np.random.default_rng(args.seed)
+        for dataset, path in cfg["COCO_files"].items():
+            if not os.path.exists(path):
+                continue
+            drecs, dcats = (recs, cats) if dataset == "trn" else load_coco_training_set(path)
+            with open(path) as f:
+                names = [c["name"] for c in sorted(json.load(f).get("categories", []), key=lambda c: c["id"])]
+            for i in sorted(pick.choice(len(drecs), size=min(args.tagged_samples, len(drecs)), replace=False).tolist()) if drecs else []:
+                r = drecs[i]
+                anns = [{"bbox": [b[0], b[1], b[2] - b[0], b[3] - b[1]], "category_id": int(k), "segmentation": [q.tolist() for q in ps]}
+                        for b, k, ps in zip(r["boxes"].tolist(), r["classes"].tolist(), r["polygons"])]
+                rgb = _read(r["file_name"])[:, :, ::-1][:, :, :3]
+                png = os.path.join(sub, f"{dataset}_tagged_{os.path.splitext(os.path.basename(r['file_name']))[0]}.png")
+                draw_annotations(rgb, anns, {k: k for k in range(len(dcats))}, names or None).save(png)
+        log.info("tagged sample training images -> %s/", sub)
     sv = load_solver(cfg["detectron2_config_file"])
     max_iter = args.max_iter or sv["max_iter"]
     mw = cfg.get("model_weights", {}) or {}

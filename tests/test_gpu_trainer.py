@@ -457,6 +457,8 @@ def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
         ev = lines[-1]
         assert "bbox/AP" in ev and "segm/AP50" in ev and all(ev[k] is None or 0.0 <= ev[k] <= 100.0 for k in ev if k.startswith(("bbox/", "segm/")))
         assert (wd / "logs" / "model_0000002.pth").exists() and open(wd / "logs" / "last_checkpoint").read() == "model_final.pth"
+        tagged = sorted(os.listdir(wd / "sample_training_images"))          # ground-truth previews (R:config/config_obj_detec.yaml:65)
+        assert tagged and all(t.endswith(".png") and t.split("_")[0] in ("trn", "val", "tst") for t in tagged)
         W1 = load_checkpoint(str(wd / "logs" / "model_final.pth"))
         spec = EngineSpec(num_classes=2)
         W0 = synthetic_weights(spec, seed=0)

@@ -239,3 +239,8 @@ def test_make_detections_cli_end_to_end(gpu_required, tmp_path):
         assert 1000.0 * i - 1e-6 <= min(xs) and max(xs) <= 1000.0 * i + 52.0 + 1e-6       # georeferenced into its own tile
     gj = json.load(open(wd / "val_detections_at_0dot05_threshold.geojson"))
     assert len(gj["features"]) == len(feats)
+    # tagged previews of the first images (sample_tagged_img_subfolder, R:config/config_obj_detec.yaml:77)
+    pngs = sorted(os.listdir(wd / "sample_detection_images"))
+    assert pngs and all(p.startswith("val_det_") and p.endswith(".png") for p in pngs)
+    from PIL import Image
+    assert Image.open(wd / "sample_detection_images" / pngs[0]).size == (128, 128) or Image.open(wd / "sample_detection_images" / pngs[0]).size[0] > 0
