@@ -15,8 +15,11 @@
 //   * swizzle: LDS slot s of row r holds source chunk s ^ key(r), key(r) = ((r>>1)&1)<<1 | ((r>>3)&1)<<2 -- the 8 rows
 //     a 32-lane half touches in one transposed read ({0..3, 8..11} or {4..7, 12..15} of a 16-row group) land on 8
 //     disjoint 8-bank spans (checked by simulation, tools/ubench/lds_tr_banks.py).
-//   * workgroup tile: 128 output channels x 128 K columns (= two (tap, 64-channel slice) pairs), 4 waves 2x2, wave
-//     tile 64x64; K step = 64 pixels, double buffered.
+//   * workgroup tile: CB x 64 output channels x 128 K columns (= two (tap, 64-channel slice) pairs), wave tile 64x64, K step
+//     = 64 pixels.  CB = 2 (Cout <= 128): 4 waves, double buffered, two workgroups per CU.  CB = 4: 8 waves, 256 x 128,
+//     THREE stages of 48 KB with the loads issued two steps ahead (counted vmcnt): a 64-pixel step is only ~0.25 us of MFMA
+//     work per wave, less than an L2 round trip, so the double-buffered form waits for memory every step (630-690 TFLOP/s on
+//     the 3x3 256->256 shapes), and the wider tile moves 25 % fewer L2 bytes per FLOP.
 //   * the pixel range is split over gridDim.z; every split writes its own fp32 partial tile and wgrad_reduce_kernel
 //     adds the partials in a fixed order (bitwise reproducible; no float atomics), applies the per-output-channel
 //     FrozenBN scale (the trainable tensor is the UNFOLDED weight) and accumulates into the gradient.
@@ -27,10 +30,17 @@ namespace {
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BK = 64, NT = 256;   // 128 channels x 128 K columns per workgroup
+constexpr int BK = 64;
 constexpr int SUB = BK * 128;                 // one [64 px][64 ch] sub-tile: 8 KB
-constexpr int STAGE = 4 * SUB;                // dY lo, dY hi, X half 0, X half 1
-constexpr int LDS_BYTES = 2 * STAGE;          // 64 KB
+template <int CB> struct WgCfg {
+  static constexpr int BM = CB * 64, NT = CB * 128, WAVES = CB * 2;
+  static constexpr int SUBS = CB + 2;                       // dY blocks 0..CB-1, X half 0, X half 1
+  static constexpr int STAGE = SUBS * SUB;
+  static constexpr int NST = CB == 4 ? 3 : 2;
+  static constexpr int LDS_BYTES = NST * STAGE;             // 64 KB (CB 2) / 144 KB (CB 4)
+  static constexpr int PCS = 8 / WAVES;                     // 8-row pieces of a sub-tile staged per wave
+  static constexpr int LOADS = PCS * SUBS;                  // LDS-DMA pieces a lane issues per stage
+};
 
 __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -38,7 +48,10 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
 }
 __device__ __forceinline__ int row_key(int r) { return (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2); }
 
-__global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
+template <int CB>
+__global__ __launch_bounds__(WgCfg<CB>::NT) void conv_wgrad_kernel(const WgradParams p) {
+  using C = WgCfg<CB>;
+  constexpr int BM = C::BM, STAGE = C::STAGE, NST = C::NST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -73,13 +86,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
   int s1 = s0 + per;
   if (s1 > steps_total) s1 = steps_total;
 
-  // ---- staging: a sub-tile is 8 pieces of 8 rows; wave w stages pieces 2w, 2w+1 of each of the 4 sub-tiles
+  // ---- staging: a sub-tile is 8 pieces of 8 rows; wave w stages pieces w*PCS .. of each of the CB + 2 sub-tiles
   const int lrow = lane >> 3, lchk = lane & 7;
   auto stage = [&](int buf, int step) {
     char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int pc = 0; pc < 2; ++pc) {
-      const int piece = wave * 2 + pc;
+    for (int pc = 0; pc < C::PCS; ++pc) {
+      const int piece = wave * C::PCS + pc;
       const int r = piece * 8 + lrow;                          // row inside the 64-pixel K step
       const int m = step * BK + r;
       const int src_chunk = (lchk ^ row_key(r)) * 8;
@@ -97,12 +110,10 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
       }
       char* dst = base + piece * 1024;
       // channel chunks past the gradient buffer's row (narrow heads: 16 outputs stored 64 wide) read the zero row
-      const half_t* gy0 = (co0 + src_chunk < p.dy_Cs) ? gy : p.zeros + src_chunk;
-      const half_t* gy1 = (co0 + 64 + src_chunk < p.dy_Cs) ? gy + 64 : p.zeros + src_chunk;
-      glds16(gy0, dst);
-      glds16(gy1, dst + SUB);
-      glds16(gx + (m < M ? x_off[0] : 0), dst + 2 * SUB);
-      glds16(gx + (m < M ? x_off[1] : 0), dst + 3 * SUB);
+#pragma unroll
+      for (int h = 0; h < CB; ++h) glds16((co0 + h * 64 + src_chunk < p.dy_Cs) ? gy + h * 64 : p.zeros + src_chunk, dst + h * SUB);
+      glds16(gx + (m < M ? x_off[0] : 0), dst + CB * SUB);
+      glds16(gx + (m < M ? x_off[1] : 0), dst + (CB + 1) * SUB);
     }
   };
 
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
     const int c = 2 * cb + (pp >> 1);
     return (unsigned)(r * 128 + ((c ^ row_key(r)) << 4) + 8 * (pp & 1));
   };
-  unsigned a_addr[4][2][2], b_addr[4][2][2];     // [block][ks][hh]; wave's dY sub-tile = wr, X sub-tile = 2 + wc
+  unsigned a_addr[4][2][2], b_addr[4][2][2];     // [block][ks][hh]; wave's dY sub-tile = wr, X sub-tile = CB + wc
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         a_addr[i][ks][hh] = lds0 + wr * SUB + tr_addr(i, ks, hh);
-        b_addr[i][ks][hh] = lds0 + (2 + wc) * SUB + tr_addr(i, ks, hh);
+        b_addr[i][ks][hh] = lds0 + (CB + wc) * SUB + tr_addr(i, ks, hh);
       }
 
   f32x4 acc[4][4];
@@ -137,11 +148,18 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
 #define RS_TR(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
   if (s0 < s1) {
     stage(0, s0);
+    if (NST == 3 && s0 + 1 < s1) stage(1, s0 + 1);
+    int buf = 0;
     for (int s = s0; s < s1; ++s) {
-      const int buf = (s - s0) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (s + 1 < s1) stage(buf ^ 1, s + 1);
+      // step s has landed: everything but the (NST - 2) younger stages' pieces
+      if (NST == 3 && s + 1 < s1) {
+        static_assert(CB != 4 || C::LOADS == 6, "vmcnt immediate below");
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();                                         // ... for every wave; and everyone is done reading step s-1
+      if (s + NST - 1 < s1) stage(buf == 0 ? NST - 1 : buf - 1, s + NST - 1);   // into the buffer step s-1 used
       const unsigned bo = (unsigned)(buf * STAGE);
       // the 16 transposed reads of the first 32-pixel half and 12 of the second are issued before the first MFMA (lgkmcnt is a
       // 4-bit counter: at most 15 may be left in flight); the first 16 MFMAs wait only for the older 16, so the second half's
@@ -186,6 +204,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradParams p) {
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
+      buf = buf + 1 == NST ? 0 : buf + 1;
     }
   }
 #undef RS_TR
@@ -247,12 +266,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
 
 }  // namespace
 
+// 256-wide tile (CB 4) where it pays: more than 128 output channels, at least 4 K-column tiles, and a pixel range per
+// workgroup long enough to amortise its deeper pipeline (measured on the layer shapes of the batch-8 step,
+// tools/ubench/wgrad_shapes.py: +14 % on the 3x3 256->256 maps of p2/p3, -8 % on the short 1x1 bottleneck shapes).
+static inline int wgrad_cb(const WgradParams& p) {
+  const int units = p.KH * p.KW * (p.Cin >> 6);
+  if (p.Cout <= 128 || units < 8) return 2;
+  const long long out_tiles = (long long)cdiv(p.Cout, 256) * cdiv(units, 2);
+  const int steps = cdiv(p.M, BK);
+  long long s = 512 / out_tiles;
+  if (s > steps / 4) s = steps / 4;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return steps / s >= 8 ? 4 : 2;
+}
+
 int wgrad_splits(const WgradParams& p) {
-  const long long out_tiles = (long long)cdiv(p.Cout, BM) * cdiv(p.KH * p.KW * (p.Cin >> 6), 2);
+  const int cb = wgrad_cb(p);
+  const long long out_tiles = (long long)cdiv(p.Cout, cb * 64) * cdiv(p.KH * p.KW * (p.Cin >> 6), 2);
   const int steps = cdiv(p.M, BK);
   static int target = -1;
   if (target < 0) { const char* e = getenv("RS_WGRAD_TARGET"); target = e ? atoi(e) : 512; if (target < 1 || target > 1024) target = 1024; }   // the trainer sizes its scratch for <= 1024
-  long long s = cdiv(target, out_tiles);        // ~2 workgroups per CU: more splits only add partial-tile traffic (measured 1024 -> 512: -2 % step time)
+  // ~2 workgroups per CU: more splits only add partial-tile traffic (measured 1024 -> 512: -2 % step time).  The 256-wide
+  // tile runs one workgroup per CU: round DOWN so that the grid is at most two full rounds of the 256 CUs.
+  long long s = cb == 4 ? (target < 512 ? target : 512) / out_tiles : cdiv(target, out_tiles);
   if (s > steps / 4) s = steps / 4;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
@@ -265,12 +302,17 @@ int launch_conv_wgrad(const WgradParams& p, hipStream_t stream) {
   RS_CHECK(p.KH * p.KW * p.Cin <= p.Kpad && p.splits >= 1, RS_ERR_ARG, "wgrad: K exceeds Kpad");
   static bool done = false;
   if (!done) {
-    RS_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<2>::LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<4>::LDS_BYTES));
     done = true;
   }
   const int units = p.KH * p.KW * (p.Cin >> 6);
-  dim3 grid(cdiv(p.Cout, BM), cdiv(units, 2), p.splits);
-  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(NT), LDS_BYTES, stream, p);
+  static int force_cb = -1;
+  if (force_cb < 0) { const char* e = getenv("RS_WGRAD_CB"); force_cb = e ? atoi(e) : 0; }
+  const int cb = force_cb == 2 || force_cb == 4 ? force_cb : wgrad_cb(p);
+  dim3 grid(cdiv(p.Cout, cb * 64), cdiv(units, 2), p.splits);
+  if (cb == 4) hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(WgCfg<4>::NT), WgCfg<4>::LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(WgCfg<2>::NT), WgCfg<2>::LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());
   if (p.splits == 1 && units * 64 == p.Kpad) return RS_OK;       // stored by the kernel itself (no padding columns to define)
   const long long n_el = (long long)p.Cout * p.Kpad;
