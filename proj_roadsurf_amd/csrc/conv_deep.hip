@@ -28,7 +28,8 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int DBG>
+// TRAIN: instantiation with the backward-epilogue options down / res32 / mask (conv_igemm.hip), compiled out of the inference kernel
+template <int DBG, bool TRAIN = false>
 __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -242,6 +243,37 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
         for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
       }
     }
+    if (TRAIN && p.down) {        // backward of the nearest 2x upsample: add the 2x2 block of the finer gradient map
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        const long long dpix = (long long)(n * p.down_Hp + 2 * y + (dd >> 1) + p.down_pad) * p.down_Wp + 2 * x + (dd & 1) + p.down_pad;
+        const half_t* dp = p.down + dpix * p.down_Cs + crow;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const half4 h = *(const half4*)(dp + i * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+        }
+      }
+    }
+    if (TRAIN && p.res32) {
+      const float* rp = p.res32 + opix * p.out_Cs + crow;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const f32x4 h = *(const f32x4*)(rp + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i * 4 + r] += h[r];
+      }
+    }
+    if (TRAIN && p.mask) {        // ReLU backward
+      const half_t* mp = p.mask + opix * p.out_Cs + crow;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const half4 h = *(const half4*)(mp + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i * 4 + r] = (float)h[r] > 0.f ? v[i * 4 + r] : 0.f;
+      }
+    }
     if (p.relu) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
@@ -276,6 +308,7 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
   static bool done = false;
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 #ifdef RS_DEEP_CEILING
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -297,7 +330,9 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
   if (dbg == 3) { hipLaunchKernelGGL(conv_deep_kernel<3>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
 #endif
   (void)dbg;
-  hipLaunchKernelGGL(conv_deep_kernel<0>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
+  RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
+  if (p.down || p.res32 || p.mask) hipLaunchKernelGGL((conv_deep_kernel<0, true>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL(conv_deep_kernel<0>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

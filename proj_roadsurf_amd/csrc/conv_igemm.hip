@@ -557,7 +557,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     g_last_conv_variant = 11;
     return launch_conv_stag(p, stream);
   }
-  RS_CHECK(!(train_opts && (v == 6 || v == 11 || v == 12 || p.mode != 0)), RS_ERR_UNSUPPORTED, "conv: training epilogue options need a conv_igemm variant, mode 0");
+  RS_CHECK(!(train_opts && (v == 6 || v == 11 || p.mode != 0 || (v == 12 && p.out_stride > 1))), RS_ERR_UNSUPPORTED, "conv: training epilogue options need a conv_igemm variant or conv_deep (no scatter), mode 0");
   if (v == 12) {                        // 256x256 with 3 activation stages / 2 weight stages (conv_deep.hip)
     RS_CHECK(!p.in2, RS_ERR_UNSUPPORTED, "conv: variant 12 has no second K source");
     g_last_conv_variant = 12;
@@ -581,7 +581,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
       if (stag && use_glds > 0 && !p.in2 && !train_opts) { g_last_conv_variant = 11; return launch_conv_stag(p, stream); }
       static int deep = -1;
       if (deep < 0) { const char* e = getenv("RS_CONV_DEEP"); deep = e ? atoi(e) : 1; }
-      if (deep && use_glds > 0 && !p.in2 && !train_opts) { g_last_conv_variant = 12; return launch_conv_deep(p, stream); }
+      if (deep && use_glds > 0 && !p.in2 && p.out_stride <= 1) { g_last_conv_variant = 12; return launch_conv_deep(p, stream); }   // incl. the backward epilogue (down / res32 / mask)
       v = 4;
     }
     else if (rows % 256 == 0 && nk <= 4 && p.M >= 100000) v = 10;           // HBM-bound 1x1 expansions on big maps: 64x256, rows read once

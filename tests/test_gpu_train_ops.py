@@ -129,7 +129,8 @@ def run_dgrad(dy, w, hi, wi, stride, pad, res=None, res32=None, mask=None, down=
 
 @pytest.mark.parametrize("cin,cout,k,stride,hw,variant", [
     (256, 256, 3, 1, (25, 27), -1),     # 3x3 (FPN output, RPN conv, mask fcn, bottleneck conv2)
-    (256, 256, 3, 1, (25, 27), 4),      # 256x256 tile of conv_igemm (conv_deep has no training epilogue)
+    (256, 256, 3, 1, (25, 27), 4),      # 256x256 tile of conv_igemm
+    (256, 256, 3, 1, (25, 27), 12),     # conv_deep with the backward epilogue (the big 3x3 input gradients of a real step)
     (512, 128, 1, 1, (26, 30), -1),     # bottleneck conv1
     (128, 512, 1, 1, (26, 30), -1),     # bottleneck conv3
     (512, 256, 1, 2, (26, 30), -1),     # stride-2 1x1 (res4.0.conv1 / shortcut): scattered store
@@ -175,9 +176,10 @@ def test_conv_dgrad_fpn_topdown_backward(gpu_required):
     inner = torch.randn(n, c, h, w, generator=g).requires_grad_(True)
     L = (F.conv2d(inner, wt, padding=1) * dP).sum() + (F.interpolate(inner, scale_factor=2.0, mode="nearest") * d_finer).sum()
     L.backward()
-    got = run_dgrad(dP, wt, h, w, 1, 1, down=d_finer)
-    err = float((got - inner.grad).abs().max())
-    assert err <= 3e-3 * max(1.0, float(inner.grad.abs().max())), err
+    for variant in (-1, 12):                 # automatic tile choice; conv_deep's backward epilogue
+        got = run_dgrad(dP, wt, h, w, 1, 1, down=d_finer, variant=variant)
+        err = float((got - inner.grad).abs().max())
+        assert err <= 3e-3 * max(1.0, float(inner.grad.abs().max())), (variant, err)
 
 
 @pytest.mark.parametrize("P", [7, 14])
