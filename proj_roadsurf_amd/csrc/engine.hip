@@ -802,11 +802,17 @@ int rs_engine::assign_phases() {
   static const char* kNarrow[] = {"rpn.select_decode", "rpn.nms", "rpn.merge", "box.candidates", "box.nms",
                                   "box.merge_postprocess", "mask.compact"};
   int phase = 0;
+  const char* rn = getenv("RS_NARROW_ROIALIGN");
+  const bool roi_narrow = rn ? atoi(rn) != 0 : true;
   for (Stage& st : stages) {
     if (st.name.rfind("box.", 0) == 0 && phase < 1) phase = 1;
     if (st.name.rfind("mask.", 0) == 0 && st.name != "mask.compact" && phase < 2) phase = 2;
     st.phase = phase;
     for (const char* nm : kNarrow) if (side && st.name == nm) st.narrow = true;
+    // RoIAlign is gather-bound (L1/L2 request rate), not MFMA-bound: on the side stream it shares the chip with the other
+    // lane's convolutions instead of queueing behind them (RS_NARROW_ROIALIGN=0 keeps it on the wide stream)
+    if (side && roi_narrow && (st.name == "box.roi_align" || st.name == "mask.roi_align")) st.narrow = true;
+    // (measured and left on the wide stream: mask.paste, preprocess, box.predictor, mask.bias_sigmoid -- 0 to -1 %)
   }
   if (!side) return RS_OK;
   RS_HIP(hipStreamCreateWithFlags(&narrow, hipStreamNonBlocking));
