@@ -803,14 +803,15 @@ int rs_engine::assign_phases() {
                                   "box.merge_postprocess", "mask.compact"};
   int phase = 0;
   const char* rn = getenv("RS_NARROW_ROIALIGN");
-  const bool roi_narrow = rn ? atoi(rn) != 0 : true;
+  const bool roi_narrow = rn ? atoi(rn) != 0 : false;
   for (Stage& st : stages) {
     if (st.name.rfind("box.", 0) == 0 && phase < 1) phase = 1;
     if (st.name.rfind("mask.", 0) == 0 && st.name != "mask.compact" && phase < 2) phase = 2;
     st.phase = phase;
     for (const char* nm : kNarrow) if (side && st.name == nm) st.narrow = true;
-    // RoIAlign is gather-bound (L1/L2 request rate), not MFMA-bound: on the side stream it shares the chip with the other
-    // lane's convolutions instead of queueing behind them (RS_NARROW_ROIALIGN=0 keeps it on the wide stream)
+    // RoIAlign is gather-bound (L1/L2 request rate), not MFMA-bound: with RS_NARROW_ROIALIGN=1 it runs on the side stream and
+    // shares the chip with the other lane's convolutions (+1 % tiles/s measured).  Off by default: the convolutions it
+    // overlaps run ~12 % longer each, which blurs the per-kernel roofline measurement for a 1 % gain.
     if (side && roi_narrow && (st.name == "box.roi_align" || st.name == "mask.roi_align")) st.narrow = true;
     // (measured and left on the wide stream: mask.paste, preprocess, box.predictor, mask.bias_sigmoid -- 0 to -1 %)
   }
