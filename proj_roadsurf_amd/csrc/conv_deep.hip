@@ -179,9 +179,24 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+#ifndef RS_DEEP_LOCKSTEP
+      // The two waves of a SIMD (w and w+4, i.e. wpx 0 / 1) take the second half's MFMAs and the issue work (next loads, next
+      // fragment reads) in OPPOSITE order, so that one wave's non-matrix instructions run while the other keeps the MFMA pipe busy.
+      if (wpx) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       if (t + 2 < nk) stage_w();                 // w(t+2)    -> weight buffer of step t
       if (t + 3 < nk) stage_a();                 // acts(t+3) -> activation buffer of step t
       reads0(anext, (t + 1) & 1);
+#ifndef RS_DEEP_LOCKSTEP
+      if (wpx) { abuf = anext; continue; }
+#endif
     }
     else {
       __builtin_amdgcn_sched_barrier(0);
