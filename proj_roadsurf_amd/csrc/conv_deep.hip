@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
     char* abase = smem + (an % 3) * ASTAGE;
     ++an;
     if (DBG & 1) return;   // ceiling experiment: no global traffic
+    if (DBG & 8) return;   // ... no activation traffic only
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) glds16(aptr[ps] + off, abase + (ps * 64 + wave * 8) * 128);
   };
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
     char* wbase = smem + W_BASE + (wn & 1) * WSTAGE;
     ++wn;
     if (DBG & 1) return;
+    if (DBG & 4) return;   // ... no weight traffic only
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) glds16(wptr[ps] + koff, wbase + (ps * 64 + wave * 8) * 128);
   };
@@ -327,12 +329,18 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
 #ifdef RS_DEEP_CEILING
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 #endif
     done = true;
   }
   // Ceiling experiments (built only with -DRS_DEEP_CEILING; results are WRONG by construction): DBG bit 0 = no global
-  // traffic, bit 1 = every step reads LDS stage 0.  Measured round 1, fpn_output2 (755 GFLOP): full kernel 0.644 ms,
-  // without global traffic 0.534 ms -> the LDS+MFMA+epilogue schedule alone caps this kernel at ~1.41 PFLOP/s.
+  // traffic, bit 1 = every step reads LDS stage 0, 4 = no weight traffic only, 8 = no activation traffic only.  Measured
+  // on fpn_output2 (755 GFLOP, tools/ubench/conv_time.py): full kernel 0.621 ms (1.22 PFLOP/s); without weight loads 0.570,
+  // without activation loads 0.552, without any 0.520 -> the LDS + MFMA + epilogue schedule alone caps this kernel at
+  // ~1.45 PFLOP/s, and the remaining 16 % is split about evenly between the weight pieces (issued ONE step ahead, from
+  // L2) and the activation pieces (two steps ahead, from HBM / MALL): 160 KB of LDS leave no room for a deeper prefetch
+  // at this tile size.
 #ifdef RS_DEEP_CEILING
   static const int dbg = [] { const char* e = getenv("RS_DEEP_DBG"); return e ? atoi(e) : 0; }();
 #else
@@ -343,6 +351,8 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
 #ifdef RS_DEEP_CEILING
   if (dbg == 1) { hipLaunchKernelGGL(conv_deep_kernel<1>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
   if (dbg == 3) { hipLaunchKernelGGL(conv_deep_kernel<3>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
+  if (dbg == 4) { hipLaunchKernelGGL(conv_deep_kernel<4>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
+  if (dbg == 8) { hipLaunchKernelGGL(conv_deep_kernel<8>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
 #endif
   (void)dbg;
   RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
