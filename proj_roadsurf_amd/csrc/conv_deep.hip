@@ -138,10 +138,12 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   RS_DSR(xf[0], xa, 0); RS_DSR(xf[1], xa, 2048); RS_DSR(xf[2], xa, 4096); RS_DSR(xf[3], xa, 6144);  \
   RS_DSR(xf[4], xa, 8192); RS_DSR(xf[5], xa, 10240); RS_DSR(xf[6], xa, 12288); RS_DSR(xf[7], xa, 14336);
   auto reads0 = [&](int ab, int wb) {
+    if (DBG & 16) return;  // ceiling experiment: no fragment reads (MFMAs on whatever the registers hold)
     const unsigned wa = wa0 + ((DBG & 2) ? 0 : wb) * WSTAGE, xa = xa0 + ((DBG & 2) ? 0 : ab) * ASTAGE;
     RS_READS(wf0, xf0, wa, xa)
   };
   auto reads1 = [&](int ab, int wb) {
+    if (DBG & 16) return;
     const unsigned wa = wa1 + ((DBG & 2) ? 0 : wb) * WSTAGE, xa = xa1 + ((DBG & 2) ? 0 : ab) * ASTAGE;
     RS_READS(wf1, xf1, wa, xa)
   };
@@ -331,16 +333,20 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<17>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 #endif
     done = true;
   }
   // Ceiling experiments (built only with -DRS_DEEP_CEILING; results are WRONG by construction): DBG bit 0 = no global
-  // traffic, bit 1 = every step reads LDS stage 0, 4 = no weight traffic only, 8 = no activation traffic only.  Measured
-  // on fpn_output2 (755 GFLOP, tools/ubench/conv_time.py): full kernel 0.621 ms (1.22 PFLOP/s); without weight loads 0.570,
-  // without activation loads 0.552, without any 0.520 -> the LDS + MFMA + epilogue schedule alone caps this kernel at
-  // ~1.45 PFLOP/s, and the remaining 16 % is split about evenly between the weight pieces (issued ONE step ahead, from
-  // L2) and the activation pieces (two steps ahead, from HBM / MALL): 160 KB of LDS leave no room for a deeper prefetch
-  // at this tile size.
+  // traffic, bit 1 = every step reads LDS stage 0, 4 = no weight traffic only, 8 = no activation traffic only, 16 = no
+  // fragment reads.  Measured on fpn_output2 (755 GFLOP, tools/ubench/conv_time.py, one box): full kernel 0.635 ms
+  // (1.19 PFLOP/s); without weight loads 0.578, without activation loads 0.562, without any global traffic 0.532
+  // (1.42 PFLOP/s); without global traffic AND without the ds_read_b128 fragment reads 0.422 (1.79 PFLOP/s).  So of the
+  // kernel's time 66 % is the MFMA loop with its barriers and epilogue, 17 % the LDS fragment reads (192 KB per K step
+  // and workgroup: their issue and VGPR write-back are not free next to the MFMAs even though the LDS array is only
+  // ~40 % busy), 16 % global traffic, split about evenly between the weight pieces (issued ONE step ahead, from L2) and
+  // the activation pieces (two steps ahead, from HBM / MALL): 160 KB of LDS leave no room for a deeper prefetch at
+  // this tile size.
 #ifdef RS_DEEP_CEILING
   static const int dbg = [] { const char* e = getenv("RS_DEEP_DBG"); return e ? atoi(e) : 0; }();
 #else
@@ -353,6 +359,7 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
   if (dbg == 3) { hipLaunchKernelGGL(conv_deep_kernel<3>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
   if (dbg == 4) { hipLaunchKernelGGL(conv_deep_kernel<4>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
   if (dbg == 8) { hipLaunchKernelGGL(conv_deep_kernel<8>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
+  if (dbg == 17) { hipLaunchKernelGGL(conv_deep_kernel<17>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
 #endif
   (void)dbg;
   RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
