@@ -307,7 +307,11 @@ int rs_trainer_fetch_rois(rs_trainer* t, int n, float* boxes_host, int32_t* gt_i
 int rs_trainer_set_rpn_topk(rs_trainer* t, int pre_nms_topk_train, int post_nms_topk_train);
 /* Sampler sizes (defaults = the reference YAML: 256 @ 0.5 anchors, 1024 @ 0.25 RoIs per image). */
 int rs_trainer_set_sampling(rs_trainer* t, int rpn_batch, float rpn_positive_fraction, int roi_batch, float roi_positive_fraction);
+/* SGD with momentum on the flat buffers + refold.  The gradient is first checked for inf / nan (fp16 loss scale too large for
+ * this batch): then the step is skipped on the device -- weights and momentum unchanged -- and the tensor "grad_overflow" [1]
+ * reads 1; lower the scale with rs_trainer_set_loss_scale before the next forward (GradScaler semantics, no host sync here). */
 int rs_trainer_apply_sgd(rs_trainer* t, float lr, float momentum, float weight_decay);
+int rs_trainer_set_loss_scale(rs_trainer* t, float loss_scale);
 int rs_trainer_sync(rs_trainer* t);
 int rs_trainer_tensor(rs_trainer* t, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo);
 int rs_trainer_tensor_count(rs_trainer* t);

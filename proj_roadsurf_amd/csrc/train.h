@@ -43,7 +43,8 @@ int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s);
 int launch_box_loss(const BoxLossParams& p, hipStream_t s);
 int launch_mask_loss(const MaskLossParams& p, hipStream_t s);
 int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, float lr, float momentum, float weight_decay,
-                        float inv_loss_scale, int first_step, hipStream_t s);
+                        float inv_loss_scale, int first_step, hipStream_t s, const int* skip = nullptr);
+int launch_grad_nonfinite(const float* grad, long long n, int* flag, hipStream_t s);   // flag = 1 if any inf / nan
 // one layer of the fold (master fp32 -> fp16 GEMM operands); Cout == 0 marks a bias copy (w32 -> fwd32, Cin floats, KH times)
 struct FoldDesc {
   const float* w32;

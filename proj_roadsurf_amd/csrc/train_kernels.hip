@@ -153,15 +153,34 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const MaskLossParams p) 
   block_sum_to(l, p.loss_out);
 }
 
+// skip: optional device flag (gradient overflow found by grad_nonfinite_kernel): when set the step is not applied -- neither the
+// weights nor the momentum buffer change (what torch.cuda.amp.GradScaler.step does with an inf/nan gradient)
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* w, float* buf, const float* grad, long long n, float lr, float momentum,
-                                                          float weight_decay, float inv_loss_scale, int first_step) {
+                                                          float weight_decay, float inv_loss_scale, int first_step, const int* skip) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (skip && *skip) return;
   float g = grad[i] * inv_loss_scale;
   g = g + weight_decay * w[i];
   const float b = first_step ? g : momentum * buf[i] + g;       // torch: the buffer starts as a clone of the first gradient
   buf[i] = b;
   w[i] = w[i] - lr * b;
+}
+
+// fp16 loss scaling: the activation gradients are fp16, so a too large scale shows up as inf / nan in the fp32 weight gradients
+// (an inf activation gradient poisons every weight gradient downstream of it).  One flag for the whole flat buffer.
+__global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* grad, long long n, int* flag) {
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  bool bad = false;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const f32x4 v = *(const f32x4*)(grad + i);
+      bad = bad || !(fabsf(v[0]) <= 3.0e38f) || !(fabsf(v[1]) <= 3.0e38f) || !(fabsf(v[2]) <= 3.0e38f) || !(fabsf(v[3]) <= 3.0e38f);
+    } else {
+      for (long long j = i; j < n; ++j) bad = bad || !(fabsf(grad[j]) <= 3.0e38f);
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 // w32: [Cout][Kpad] fp32 master, K = (kh,kw,ci); fwd: same layout fp16 with scale[co] folded; bwd: [Cin][KpadT] fp16,
@@ -595,10 +614,17 @@ int launch_mask_loss(const MaskLossParams& p, hipStream_t s) {
   return RS_OK;
 }
 int launch_sgd_momentum(float* w, float* buf, const float* grad, long long n, float lr, float momentum, float weight_decay,
-                        float inv_loss_scale, int first_step, hipStream_t s) {
+                        float inv_loss_scale, int first_step, hipStream_t s, const int* skip) {
   RS_CHECK(w && buf && grad && n > 0, RS_ERR_ARG, "sgd: bad arguments");
   hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, w, buf, grad, n, lr, momentum, weight_decay,
-                     inv_loss_scale, first_step);
+                     inv_loss_scale, first_step, skip);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_grad_nonfinite(const float* grad, long long n, int* flag, hipStream_t s) {
+  RS_CHECK(grad && flag && n > 0, RS_ERR_ARG, "grad check: bad arguments");
+  RS_HIP(hipMemsetAsync(flag, 0, 4, s));
+  hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(2048), dim3(256), 0, s, grad, n, flag);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

@@ -604,6 +604,7 @@ class Trainer:
         lib.rs_trainer_set_grad_divisor.argtypes = [vp, C.c_float]
         lib.rs_trainer_copy_state.argtypes = [vp, vp]
         lib.rs_trainer_grad_buffer.argtypes = [vp]
+        lib.rs_trainer_set_loss_scale.argtypes = [vp, C.c_float]
         lib.rs_trainer_fetch_rois.argtypes = [vp, C.c_int, vp, vp, vp]
         lib.rs_trainer_grad_buffer.restype = vp
         lib.rs_trainer_mask_forward.argtypes = [vp, i32]
@@ -805,6 +806,17 @@ class Trainer:
     def apply_sgd(self, lr: float, momentum: float = 0.9, weight_decay: float = 1e-4) -> None:
         _check(self.lib, self.lib.rs_trainer_apply_sgd(self._h, lr, momentum, weight_decay), "rs_trainer_apply_sgd")
 
+    def overflowed(self) -> bool:
+        """True if the last ``apply_sgd`` found inf / nan in the gradient and therefore skipped the step (fp16 loss scale too
+        large for that batch).  Synchronises the trainer's stream."""
+        return bool(int(self.tensor("grad_overflow")[0]))
+
+    def set_loss_scale(self, loss_scale: float) -> None:
+        """fp16 loss scale of the following steps; call it after ``apply_sgd`` (the gradient buffer carries the scale it was
+        computed with)."""
+        _check(self.lib, self.lib.rs_trainer_set_loss_scale(self._h, float(loss_scale)), "rs_trainer_set_loss_scale")
+        self.loss_scale = float(loss_scale)
+
     def sync(self) -> None:
         _check(self.lib, self.lib.rs_trainer_sync(self._h), "rs_trainer_sync")
 
@@ -845,6 +857,11 @@ class MultiScaleTrainer:
         self._sampling = tuple(a)
         for t in self._t.values():
             t.set_sampling(*a)
+
+    def set_loss_scale(self, loss_scale: float) -> None:
+        self.loss_scale = float(loss_scale)
+        for t in self._t.values():
+            t.set_loss_scale(loss_scale)
 
     def select(self, size: int) -> Trainer:
         """The trainer for shortest-edge ``size``, holding the up-to-date optimiser state."""

@@ -147,7 +147,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("config_file", help="YAML with a 'train_model.py' section (R:config/config_obj_detec.yaml)")
     ap.add_argument("--synthetic-weights", action="store_true", help="start from seeded synthetic weights (no checkpoint available offline)")
     ap.add_argument("--max-iter", type=int, default=0, help="override SOLVER.MAX_ITER (smoke runs)")
-    ap.add_argument("--loss-scale", type=float, default=1024.0)
+    ap.add_argument("--loss-scale", type=float, default=1024.0, help="initial fp16 loss scale (halved when a step overflows)")
+    ap.add_argument("--scale-window", type=int, default=2000, help="clean steps after which the loss scale doubles (0 = never)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log-period", type=int, default=20)
     ap.add_argument("--tagged-samples", type=int, default=3, help="tagged ground-truth PNGs per dataset in sample_tagged_img_subfolder (0 = none)")
@@ -296,6 +297,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         return {k: (None if v != v else v) for k, v in out.items()}           # NaN -> null in metrics.json
 
     t0 = time.time()
+    last_trainer, skipped_steps, clean_steps = None, 0, 0
     for it in range(max_iter):
         size = int(sizes[int(size_rng.integers(len(sizes)))])
         trainer = ms.select(size)
@@ -309,14 +311,32 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             t, b, c, p = map_record(rec, tile, net_hw, sv["flip"] == "horizontal" and flips.random() < 0.5)
             tiles.append(t); boxes.append(b); classes.append(c); polys.append(p)
         losses = trainer.train_step(np.stack(tiles), boxes, classes, polys, seed=args.seed * 1000003 + it * world + rank)
+        # dynamic fp16 loss scale (GradScaler's policy): the previous step's overflow flag is read here, after this step's own
+        # synchronisation, so it costs no extra stall; a skipped step halves the scale, `--scale-window` clean steps double it.
+        # The flag is taken after the all-reduce, so every rank sees the same value and the scales stay in step.
+        new_scale = None
+        if last_trainer is not None and last_trainer.overflowed():
+            skipped_steps += 1
+            clean_steps = 0
+            new_scale = max(ms.loss_scale / 2.0, 1.0)
+            log.warning("iteration %d: gradient overflow, step skipped; loss scale %g -> %g", it - 1, ms.loss_scale, new_scale)
+        else:
+            clean_steps += 1
+            if args.scale_window > 0 and clean_steps >= args.scale_window and ms.loss_scale < 65536.0:
+                clean_steps = 0
+                new_scale = ms.loss_scale * 2.0
         trainer.allreduce_gradients()
         lr = lr_at(sv, it)
         trainer.apply_sgd(lr, sv["momentum"], sv["weight_decay"])
+        last_trainer = trainer
+        if new_scale is not None:
+            ms.set_loss_scale(new_scale)          # after the step: the gradient buffer carried the old scale
         if not all(np.isfinite(v) for v in losses.values()):
             raise SystemExit(f"iteration {it}: non-finite loss {losses} (lower --loss-scale)")
         vloss = validation_loss(it) if (sv["eval_period"] > 0 and ((it + 1) % sv["eval_period"] == 0 or it == max_iter - 1)) else None
         if rank == 0 and ((it + 1) % args.log_period == 0 or it == max_iter - 1 or vloss is not None):
-            rec = {"iteration": it, "total_loss": float(sum(losses.values())), "lr": lr, "time": (time.time() - t0) / (it + 1), **losses}
+            rec = {"iteration": it, "total_loss": float(sum(losses.values())), "lr": lr, "time": (time.time() - t0) / (it + 1), **losses,
+                   "loss_scale": ms.loss_scale, "skipped_steps": skipped_steps}
             if vloss is not None:
                 rec["validation_loss"] = vloss
                 rec.update(validation_ap())

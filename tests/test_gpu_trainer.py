@@ -663,3 +663,33 @@ def test_side_stream_gradients_equal_single_stream(gpu_required, monkeypatch):
     for g in grads(1):
         rel = float(np.linalg.norm(g - ref) / np.linalg.norm(ref))
         assert rel <= 1e-3, rel
+
+
+def test_overflowing_gradient_skips_the_step(gpu_required):
+    """fp16 loss scaling: with an absurd scale the activation gradients overflow, the flat gradient holds inf / nan, and
+    rs_trainer_apply_sgd must leave weights and momentum untouched and raise "grad_overflow" (GradScaler semantics); after
+    rs_trainer_set_loss_scale the same batch steps normally."""
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=91)
+    gb = [np.array([[20.0, 30.0, 120.0, 160.0]], np.float32), np.array([[100.0, 100.0, 260.0, 280.0]], np.float32)]
+    gc = [np.array([0]), np.array([1])]
+    polys = [[[np.array([b[0], b[1], b[2], b[1], b[2], b[3], b[0], b[3]], np.float64)] for b in bs] for bs in gb]
+    tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=1e9)
+    try:
+        name = "roi_heads.box_head.fc2.weight"
+        losses = tr.train_step(tiles, gb, gc, polys, seed=1)
+        assert all(np.isfinite(v) for v in losses.values())           # the loss VALUES are fp32 and unscaled
+        tr.apply_sgd(1e-3, 0.9, 1e-4)
+        assert tr.overflowed()
+        W1 = tr.export_weights(Wn)
+        assert np.array_equal(W1[name], Wn[name])                      # step skipped
+        tr.set_loss_scale(256.0)
+        tr.train_step(tiles, gb, gc, polys, seed=1)
+        tr.apply_sgd(1e-3, 0.9, 1e-4)
+        assert not tr.overflowed()
+        W2 = tr.export_weights(Wn)
+        d = float(np.abs(W2[name] - Wn[name]).max())
+        assert 0 < d < 0.1
+    finally:
+        tr.close()
