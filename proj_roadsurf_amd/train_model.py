@@ -298,9 +298,11 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
 
     t0 = time.time()
     last_trainer, skipped_steps, clean_steps = None, 0, 0
-    for it in range(max_iter):
+    def load_batch(_it: int):
+        """One batch of the DatasetMapper (size draw, sampler, decode, flip, scale): runs on a loader thread one iteration ahead
+        of the GPU step.  Only this function touches the sampler and the two RNGs, and batches are requested in order, so the
+        stream of batches is the same as without the thread."""
         size = int(sizes[int(size_rng.integers(len(sizes)))])
-        trainer = ms.select(size)
         net_hw = ms.net_shape(size)
         tiles, boxes, classes, polys = [], [], [], []
         for _ in range(per_rank):
@@ -310,7 +312,17 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 raise SystemExit(f"{rec['file_name']}: tile shape {tile.shape} != {first.shape} (one shape per run)")
             t, b, c, p = map_record(rec, tile, net_hw, sv["flip"] == "horizontal" and flips.random() < 0.5)
             tiles.append(t); boxes.append(b); classes.append(c); polys.append(p)
-        losses = trainer.train_step(np.stack(tiles), boxes, classes, polys, seed=args.seed * 1000003 + it * world + rank)
+        return size, np.stack(tiles), boxes, classes, polys
+
+    from concurrent.futures import ThreadPoolExecutor
+    loader = ThreadPoolExecutor(max_workers=1)
+    pending = loader.submit(load_batch, 0)
+    for it in range(max_iter):
+        size, tile_batch, boxes, classes, polys = pending.result()
+        if it + 1 < max_iter:
+            pending = loader.submit(load_batch, it + 1)      # decoded while this iteration's step runs on the GPU
+        trainer = ms.select(size)
+        losses = trainer.train_step(tile_batch, boxes, classes, polys, seed=args.seed * 1000003 + it * world + rank)
         # dynamic fp16 loss scale (GradScaler's policy): the previous step's overflow flag is read here, after this step's own
         # synchronisation, so it costs no extra stall; a skipped step halves the scale, `--scale-window` clean steps double it.
         # The flag is taken after the all-reduce, so every rank sees the same value and the scales stay in step.
@@ -347,6 +359,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         if (it + 1) % sv["checkpoint_period"] == 0 and it + 1 < max_iter:
             save(f"model_{it:07d}.pth", it)
     save("model_final.pth", max_iter - 1)
+    loader.shutdown(wait=True)
     ms.close()
     if metrics:
         metrics.close()
