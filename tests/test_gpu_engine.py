@@ -426,3 +426,45 @@ def test_fp32_mode_single_class(gpu_required):
                       precision="fp32")
     tiles = synthetic_tiles(2, 192, 192, 3, seed=51)
     _run_strict(spec, tiles, "k1")
+
+
+def test_no_detections_and_mixed_batches(gpu_required):
+    """Edge cases of the detection bookkeeping: a score threshold nothing passes (zero detections on every tile: the mask head's
+    GEMMs run over a device-side count of 0), then a batch in which only SOME tiles have detections (compacted mask-head list with
+    empty images in the middle), each compared with the same tile run alone."""
+    spec_hi = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300,
+                         score_thresh_test=0.9999)
+    W = synthetic_weights(spec_hi, seed=0)
+    tiles = synthetic_tiles(3, 256, 256, 3, seed=77)
+    eng = Engine(spec_hi, W, (256, 256, 3), max_batch=4)
+    try:
+        out = eng.infer(tiles)
+        assert [len(o) for o in out] == [0, 0, 0]
+        for o in out:
+            assert o.pred_boxes.shape == (0, 4) and o.scores.shape == (0,) and o.pred_classes.shape == (0,)
+            assert o.pred_masks.shape == (0, 256, 256)
+        assert [len(o) for o in eng.infer(tiles[:1])] == [0]                       # and the engine is still usable
+    finally:
+        eng.close()
+    # a threshold between the tiles' best scores: some images keep detections, others none
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    eng = Engine(spec, W, (256, 256, 3), max_batch=4)
+    try:
+        best = sorted(float(o.scores.max()) for o in eng.infer(tiles))
+    finally:
+        eng.close()
+    thr = 0.5 * (best[0] + best[1]) if best[1] > best[0] else best[0] * 0.999
+    spec_mid = spec.replace(score_thresh_test=float(thr))
+    eng = Engine(spec_mid, W, (256, 256, 3), max_batch=4)
+    try:
+        batch = eng.infer(tiles)
+        counts = [len(o) for o in batch]
+        assert min(counts) == 0 or best[1] == best[0]
+        assert max(counts) > 0
+        for i in range(3):
+            alone = eng.infer(tiles[i:i + 1])[0]
+            assert len(alone) == counts[i]
+            assert np.array_equal(alone.pred_boxes, batch[i].pred_boxes) and np.array_equal(alone.scores, batch[i].scores)
+            assert np.array_equal(alone._packed, batch[i]._packed)
+    finally:
+        eng.close()
