@@ -693,3 +693,31 @@ def test_overflowing_gradient_skips_the_step(gpu_required):
         assert 0 < d < 0.1
     finally:
         tr.close()
+
+
+def test_batch_with_an_image_without_ground_truth(gpu_required):
+    """An image whose annotations are all gone (detectron2 keeps such images when they survive FILTER_EMPTY_ANNOTATIONS, e.g.
+    validation tiles): every anchor / proposal of it is background, no mask entries; the losses stay finite and the step runs."""
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=12)
+    gb = [np.zeros((0, 4), np.float32), np.array([[100.0, 100.0, 260.0, 280.0]], np.float32)]
+    gc = [np.zeros(0, np.int64), np.array([1])]
+    polys = [[], [[np.array([100.0, 100.0, 260.0, 100.0, 260.0, 280.0, 100.0, 280.0])]]]
+    tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=256.0)
+    try:
+        tr.set_sampling(256, 0.5, 64, 0.25)
+        losses = tr.train_step(tiles, gb, gc, polys, seed=3)
+        assert all(np.isfinite(v) and v >= 0 for v in losses.values()), losses
+        cnt = tr.tensor("roi_sampled_count")
+        assert int(cnt[0, 0]) == 0 and int(cnt[1, 0]) >= 1            # no foreground RoI on the empty image
+        tr.apply_sgd(1e-3, 0.9, 1e-4)
+        assert not tr.overflowed()
+        # both images empty: only the background terms remain
+        losses = tr.train_step(tiles, [gb[0], gb[0]], [gc[0], gc[0]], [[], []], seed=4)
+        assert all(np.isfinite(v) for v in losses.values()), losses
+        assert losses["loss_mask"] == 0.0 and losses["loss_box_reg"] == 0.0 and losses["loss_rpn_loc"] == 0.0
+        tr.apply_sgd(1e-3, 0.9, 1e-4)
+        assert not tr.overflowed()
+    finally:
+        tr.close()
