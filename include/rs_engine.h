@@ -141,6 +141,8 @@ int rs_engine_stage_count(rs_engine* e);
 int rs_engine_stage_info(rs_engine* e, int i, char* name_out, double* ms_total, int* calls, double* flops, double* bytes);
 /* Kernel symbol (tile variant) the stage's last call launched, "" for non-GEMM stages. name_out: >= 96 bytes. */
 int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out);
+/* Tile-variant number of the stage's last call (-2 = not a GEMM stage, -1 = fp32 kernel; numbering: rs_op_conv_variant). */
+int rs_engine_stage_variant(rs_engine* e, int i);
 
 /* Intermediate tensors by name (parity tests): device pointer, dtype (1 f16, 2 f32, 3 i32, 4 u8),
  * up to 5 dims (dims[ndim..] = 1) and the spatial halo of NHWC activations. */
@@ -158,13 +160,19 @@ int rs_engine_net_shape(rs_engine* e, int* resized_h, int* resized_w, int* padde
  * out: [n][ho+2*out_halo][wo+2*out_halo][cout] fp16, or fp32 when out_f32.
  * residual (optional) has the geometry of out; upsample_add (optional) is
  * [n][ho/2+2*out_halo][wo/2+2*out_halo][cout] and is added at (y/2, x/2).
- * variant: -1 auto, 0 = 128x128 tile, 1 = 256x64, 2 = 256x16 (fp32 out), 3 = 256x128, 4 = 256x256,
- * 6 = experimental software-pipelined 256x256. use_glds: 1 = direct
+ * variant: -1 auto, 0 = 128x128 tile, 1 = 256x64, 2 = 256x16 (fp32 out), 3 = 256x128, 4 = 256x256, 7 = 64x128,
+ * 8 = 128x64, 9 = 32x128, 10 = 64x256, 12 = conv_deep 256x256 (pixels x channels).  use_glds: 1 = direct
  * global->LDS staging (production), 0 = register staging (cross-check). */
 int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual,
                  const void* upsample_add, int n, int hi, int wi, int cin, int in_halo, int kh, int kw,
                  int stride, int pad, int cout, int kpad, int out_halo, int relu, int out_f32, int deconv2x,
                  int variant, int use_glds, void* stream);
+
+/* The tile variant launch_conv would pick for a conv / linear layer of this shape (no launch, no GPU needed): m = batch *
+ * Ho * Wo output pixels, k x k taps over cin channels (+ cin2 channels of a second 1x1 K source, 0 = none), cout channels,
+ * deconv2x as in rs_op_conv2d.  The choice depends on m, i.e. on the batch size: tests enumerate it per layer and batch
+ * (tests/test_host_cpu.py::test_conv_variant_table).  Also returns the number of LDS K-step buffers in *stages_out. */
+int rs_op_conv_variant(int m, int cin, int k, int cout, int cin2, int deconv2x, int out_f32, int* stages_out);
 
 /* Diagnostic builds only (csrc compiled with -DRS_CLOCK_PROBE, tools/ubench/clock_probe.py): device buffer of 2 int64 per
  * workgroup that rs_op_conv2d's 256x256 deep-prefetch kernel fills with {shader clocks, 100 MHz ticks} spent in its K loop.
@@ -264,12 +272,14 @@ int rs_op_sgd_momentum(float* w, float* momentum_buf, const float* grad, int64_t
 int rs_op_fold_weights(const float* w32, const float* scale, void* w_fwd, void* w_bwd, int cout, int cin, int kh, int kw, int kpad,
                        int kpad_t, void* stream);
 
-/* ------------------------------------------------------------------ training engine (in progress)
+/* ------------------------------------------------------------------ training engine
  * Owns a forward engine (same blob, packed with train=True: fp32 master weights `<layer>.m32`, FrozenBN scales `<layer>.s`),
  * one flat fp32 master / gradient / momentum buffer in the forward GEMM layout, a gradient buffer per activation, and the
- * backward stage list.  Round 1 covers the trunk: rs_trainer_forward_trunk (preprocess .. FPN), rs_trainer_backward_trunk
- * (FPN + res5..res3 from the gradients of p2..p6, tensors "d:p2".."d:p6"), rs_trainer_apply_sgd (torch.optim.SGD step on
- * every trainable tensor + refold of the fp16 operands).  What detectron2 reaches through autograd + SimpleTrainer.run_step
+ * backward stage list.  One step = rs_trainer_set_targets, rs_trainer_forward_trunk (preprocess .. FPN), rs_trainer_rpn_forward,
+ * rs_trainer_roi_step (box head: sampling, losses, backward), rs_trainer_mask_forward / _mask_backward, rs_trainer_rpn_step
+ * (RPN losses + backward), rs_trainer_backward_trunk (FPN + res5..res3 from the gradients of p2..p6), rs_trainer_apply_sgd
+ * (torch.optim.SGD step on every trainable tensor + refold of the fp16 operands): what detectron2 reaches through autograd +
+ * SimpleTrainer.run_step
  * ([EXT d2: engine/train_loop.py]).  Tensors: "d:<forward tensor>" activation gradients (fp16, times loss_scale),
  * "g:<layer>.w|.b" gradients and "m:<layer>.w|.b" master weights (fp32, forward layout). */
 typedef struct rs_trainer rs_trainer;
@@ -327,6 +337,20 @@ int rs_trainer_set_grad_divisor(rs_trainer* t, float divisor);
 void* rs_trainer_master_buffer(rs_trainer* t);
 int64_t rs_trainer_param_count(rs_trainer* t);
 void* rs_trainer_grad_buffer(rs_trainer* t);
+/* Bucketed, overlapped gradient all-reduce (what DistributedDataParallel's bucketing does with autograd hooks).  The flat
+ * gradient buffer is cut into contiguous buckets listed in the order a step COMPLETES them: "heads" (box / mask / RPN heads,
+ * complete after rs_trainer_rpn_step), "fpn", "res5", "res4", "res3" (completed one after the other inside
+ * rs_trainer_backward_trunk).  rs_trainer_bucket_info: offset / count in floats from rs_trainer_grad_buffer.
+ * rs_trainer_bucket_wait(i, stream): work enqueued on `stream` afterwards (the collective of bucket i) runs behind the
+ * kernels that produce bucket i's gradients of the step enqueued so far -- a device-side wait, the caller does not block, so
+ * bucket i's all-reduce overlaps the rest of the backward pass.  rs_trainer_bucket_sync(i): the host-side form (collectives
+ * through host memory).  rs_trainer_wait_stream(stream): the trainer's own stream waits for everything enqueued on `stream` so
+ * far; call it after the last collective and before rs_trainer_apply_sgd. */
+int rs_trainer_bucket_count(rs_trainer* t);
+int rs_trainer_bucket_info(rs_trainer* t, int i, char* name_out /* >= 96 bytes */, int64_t* offset, int64_t* count);
+int rs_trainer_bucket_wait(rs_trainer* t, int i, void* stream);
+int rs_trainer_bucket_sync(rs_trainer* t, int i);
+int rs_trainer_wait_stream(rs_trainer* t, void* stream);
 
 /* -------- host-only helpers (no GPU needed) -------- */
 /* detectron2 ResizeShortestEdge.get_output_shape. */

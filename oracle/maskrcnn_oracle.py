@@ -476,6 +476,77 @@ def roi_align_one(feat: Tensor, roi: Tensor, out_size: int, spatial_scale: float
     return acc / float(count)
 
 
+def roi_align_batched(feat: Tensor, rois: Tensor, out_size: int, spatial_scale: float, chunk: int = 128) -> Tensor:
+    """``roi_align_one`` for MANY rois of one feature map, vectorised over the rois that share a sampling grid
+    (gh, gw).  Same fp32 operation order per output element (coordinates, bilinear weights, the
+    w1*v1 + w2*v2 + w3*v3 + w4*v4 sum, accumulation over (iy, ix), division by the count), so the result is
+    bit-identical to the per-roi form (tests/test_oracle_kat.py::test_roi_align_batched_equals_per_roi).
+    feat (C,H,W) fp32, rois (R,4) -> (R,C,P,P)."""
+    C, H, Wd = feat.shape
+    R = int(rois.shape[0])
+    P = out_size
+    out = torch.zeros((R, C, P, P), dtype=torch.float32)
+    if R == 0:
+        return out
+    f32 = np.float32
+    sc = f32(spatial_scale)
+    b = rois.numpy().astype(np.float32)
+    start_w = (b[:, 0] * sc - f32(0.5)).astype(np.float32)
+    start_h = (b[:, 1] * sc - f32(0.5)).astype(np.float32)
+    end_w = (b[:, 2] * sc - f32(0.5)).astype(np.float32)
+    end_h = (b[:, 3] * sc - f32(0.5)).astype(np.float32)
+    roi_w = (end_w - start_w).astype(np.float32)
+    roi_h = (end_h - start_h).astype(np.float32)
+    bin_h = (roi_h / f32(P)).astype(np.float32)
+    bin_w = (roi_w / f32(P)).astype(np.float32)
+    gh_all = np.ceil(bin_h.astype(np.float64)).astype(np.int64)
+    gw_all = np.ceil(bin_w.astype(np.float64)).astype(np.int64)
+    ph = np.arange(P, dtype=np.float32)
+
+    def prep(v: np.ndarray, size: int):
+        oob = (v < -1.0) | (v > size)
+        v = np.where(v <= 0, f32(0), v).astype(np.float32)
+        lo = v.astype(np.int32)
+        at_edge = lo >= size - 1
+        hi = np.where(at_edge, size - 1, lo + 1)
+        lo = np.where(at_edge, size - 1, lo)
+        v = np.where(at_edge, lo.astype(np.float32), v)
+        l = (v - lo.astype(np.float32)).astype(np.float32)
+        hh = (f32(1) - l).astype(np.float32)
+        return oob, lo, hi, l, hh
+
+    for gh, gw in sorted(set(zip(gh_all.tolist(), gw_all.tolist()))):
+        if gh <= 0 or gw <= 0:
+            continue
+        sel_all = np.where((gh_all == gh) & (gw_all == gw))[0]
+        count = f32(max(gh * gw, 1))
+        iy = np.arange(gh, dtype=np.float32)
+        ix = np.arange(gw, dtype=np.float32)
+        for c0 in range(0, len(sel_all), chunk):
+            sel = sel_all[c0:c0 + chunk]
+            bh, bw = bin_h[sel][:, None, None], bin_w[sel][:, None, None]
+            ys = ((start_h[sel][:, None, None] + ph[None, :, None] * bh) + ((iy[None, None, :] + f32(0.5)) * bh) / f32(gh)).astype(np.float32)
+            xs = ((start_w[sel][:, None, None] + ph[None, :, None] * bw) + ((ix[None, None, :] + f32(0.5)) * bw) / f32(gw)).astype(np.float32)
+            oy, ylo, yhi, ly, hy = prep(ys, H)         # (r, P, gh)
+            ox, xlo, xhi, lx, hx = prep(xs, Wd)        # (r, P, gw)
+            acc = torch.zeros((C, len(sel), P, P), dtype=torch.float32)
+            T = torch.from_numpy
+            for a in range(gh):
+                yl, yh = T(ylo[:, :, a]).long()[:, :, None], T(yhi[:, :, a]).long()[:, :, None]      # (r, P, 1)
+                for bb in range(gw):
+                    xl, xh = T(xlo[:, :, bb]).long()[:, None, :], T(xhi[:, :, bb]).long()[:, None, :]  # (r, 1, P)
+                    w1 = T((hy[:, :, a][:, :, None] * hx[:, :, bb][:, None, :]).astype(np.float32))
+                    w2 = T((hy[:, :, a][:, :, None] * lx[:, :, bb][:, None, :]).astype(np.float32))
+                    w3 = T((ly[:, :, a][:, :, None] * hx[:, :, bb][:, None, :]).astype(np.float32))
+                    w4 = T((ly[:, :, a][:, :, None] * lx[:, :, bb][:, None, :]).astype(np.float32))
+                    val = w1 * feat[:, yl, xl] + w2 * feat[:, yl, xh] + w3 * feat[:, yh, xl] + w4 * feat[:, yh, xh]
+                    oob = T(oy[:, :, a][:, :, None] | ox[:, :, bb][:, None, :])
+                    val = torch.where(oob[None], torch.zeros_like(val), val)
+                    acc = acc + val
+            out[torch.from_numpy(sel)] = (acc / float(count)).permute(1, 0, 2, 3)
+    return out
+
+
 def roi_pooler(feats: Sequence[Tensor], scales: Sequence[float], boxes_per_image: Sequence[Tensor],
                out_size: int, min_level: int = 2, max_level: int = 5) -> Tensor:
     """``ROIPooler.forward`` (R:172-174 box, R:219-221 mask): level assignment then per-level
@@ -485,12 +556,15 @@ def roi_pooler(feats: Sequence[Tensor], scales: Sequence[float], boxes_per_image
         if boxes.shape[0] == 0:
             continue
         lv = assign_levels(boxes, min_level, max_level)
-        for r in range(boxes.shape[0]):
-            l = int(lv[r])
-            outs.append(roi_align_one(feats[l][n], boxes[r], out_size, scales[l]))
+        res = torch.zeros((boxes.shape[0], feats[0].shape[1], out_size, out_size), dtype=torch.float32)
+        for l in range(len(feats)):
+            idx = torch.nonzero(lv == l).flatten()
+            if idx.numel():
+                res[idx] = roi_align_batched(feats[l][n], boxes[idx], out_size, scales[l])
+        outs.append(res)
     if not outs:
         return torch.zeros((0, feats[0].shape[1], out_size, out_size), dtype=torch.float32)
-    return torch.stack(outs)
+    return torch.cat(outs)
 
 
 # =====================================================================================

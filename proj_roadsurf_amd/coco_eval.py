@@ -82,17 +82,16 @@ def _evaluate_img(ious: np.ndarray, d_scores: np.ndarray, d_area: np.ndarray, g_
     return d_scores[dorder], dtm, dt_ig, int((~g_ignore).sum())
 
 
-def evaluate(gts: Sequence[Dict], dets: Sequence[Dict], num_classes: int, iou_type: str = "bbox", max_dets: int = 100) -> Dict[str, float]:
-    """gts[i] / dets[i] describe image i: {"boxes" (k,4) XYXY, "classes" (k,), ["masks" (k,H,W) bool], ["crowd" (k,) bool]} and
-    {"boxes", "classes", "scores", ["masks"]}.  Returns COCO's AP, AP50, AP75, APs, APm, APl (in percent, NaN where undefined)
-    and the per-category AP."""
+def match_images(gts: Sequence[Dict], dets: Sequence[Dict], num_classes: int, iou_type: str = "bbox", max_dets: int = 100) -> List[Dict]:
+    """First half of COCOeval (``evaluateImg`` for every image, category and area range).  Returns one dict per image,
+    ``{(category, area name): (scores, matched (T,D), ignored (T,D), n non-ignored gt)}`` -- a few hundred bytes per image, so
+    ranks of a data-parallel job evaluate their own share of the validation set (mask IoUs included) and only these
+    records travel to rank 0 for ``accumulate``."""
     assert iou_type in ("bbox", "segm") and len(gts) == len(dets)
-    res: Dict[str, float] = {}
-    per_cat_ap: List[float] = []
-    prec = {a: np.full((len(IOU_THRS), len(REC_THRS), num_classes), -1.0) for a in AREA_RNG}
-    for c in range(num_classes):
-        per_img = {a: [] for a in AREA_RNG}
-        for g, d in zip(gts, dets):
+    out: List[Dict] = []
+    for g, d in zip(gts, dets):
+        rec: Dict = {}
+        for c in range(num_classes):
             gm, dm = np.asarray(g["classes"]) == c, np.asarray(d["classes"]) == c
             if not gm.any() and not dm.any():
                 continue
@@ -111,15 +110,26 @@ def evaluate(gts: Sequence[Dict], dets: Sequence[Dict], num_classes: int, iou_ty
             if "area" in g:
                 g_area = np.asarray(g["area"], np.float64)[gm]
             for a, rng in AREA_RNG.items():
-                per_img[a].append(_evaluate_img(ious, sc, d_area, g_area, crowd, rng, max_dets))
+                rec[(c, a)] = _evaluate_img(ious, sc, d_area, g_area, crowd, rng, max_dets)
+        out.append(rec)
+    return out
+
+
+def accumulate(per_image: Sequence[Dict], num_classes: int) -> Dict[str, float]:
+    """Second half of COCOeval (``accumulate`` + ``summarize``) over the per-image records of ``match_images``, in image
+    order.  Returns COCO's AP, AP50, AP75, APs, APm, APl (in percent, NaN where undefined) and the per-category AP."""
+    res: Dict[str, float] = {}
+    prec = {a: np.full((len(IOU_THRS), len(REC_THRS), num_classes), -1.0) for a in AREA_RNG}
+    for c in range(num_classes):
         for a in AREA_RNG:
-            if not per_img[a]:
+            ents = [r[(c, a)] for r in per_image if (c, a) in r]
+            if not ents:
                 continue
-            scores = np.concatenate([e[0] for e in per_img[a]])
+            scores = np.concatenate([e[0] for e in ents])
             order = np.argsort(-scores, kind="mergesort")
-            dtm = np.concatenate([e[1] for e in per_img[a]], axis=1)[:, order]
-            dt_ig = np.concatenate([e[2] for e in per_img[a]], axis=1)[:, order]
-            npig = sum(e[3] for e in per_img[a])
+            dtm = np.concatenate([e[1] for e in ents], axis=1)[:, order]
+            dt_ig = np.concatenate([e[2] for e in ents], axis=1)[:, order]
+            npig = sum(e[3] for e in ents)
             if npig == 0:
                 continue
             tps = np.cumsum(dtm & ~dt_ig, axis=1, dtype=np.float64)
@@ -149,3 +159,9 @@ def evaluate(gts: Sequence[Dict], dets: Sequence[Dict], num_classes: int, iou_ty
     for c in range(num_classes):
         res[f"AP-class{c}"] = mean_valid(prec["all"][:, :, c])
     return res
+
+
+def evaluate(gts: Sequence[Dict], dets: Sequence[Dict], num_classes: int, iou_type: str = "bbox", max_dets: int = 100) -> Dict[str, float]:
+    """gts[i] / dets[i] describe image i: {"boxes" (k,4) XYXY, "classes" (k,), ["masks" (k,H,W) bool], ["crowd" (k,) bool]} and
+    {"boxes", "classes", "scores", ["masks"]}.  ``accumulate(match_images(...))``."""
+    return accumulate(match_images(gts, dets, num_classes, iou_type, max_dets), num_classes)

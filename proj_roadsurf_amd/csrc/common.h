@@ -37,6 +37,34 @@ void rs_set_error(const char* fmt, ...);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Debug / experiment switches.  Every RS_* environment variable the library understands is read in ONE place
+// (engine.hip: rs_debug_reload(), run by rs_engine_create / rs_trainer_create and on first use); production sets none
+// of them and the defaults below ARE the shipped configuration.  tools/ubench/* and a few tests flip them.
+struct RsDebug {
+  int conv_single_stage_nk = 4;   // RS_CONV_SINGLE_STAGE_NK  K steps up to which a conv runs with ONE LDS buffer
+  int conv_persist = 0;           // RS_CONV_PERSIST          1: shallow-K layers persistent, 2: all (measured: not faster)
+  int conv_tuned = 1;             // RS_CONV_TUNED            0: first-round tile rule (128x128 / 256x64 only)
+  int conv_deep = 1;              // RS_CONV_DEEP             0: conv_igemm 256x256 instead of conv_deep
+  int stem_small_tile = 1;        // RS_STEM_SMALL_TILE       0: 256x64 stem tile
+  int deep_dbg = 0;               // RS_DEEP_DBG              -DRS_DEEP_CEILING builds only
+  int deconv_variant = 10;        // RS_DECONV_VARIANT        tile of the fused deconv + predictor
+  int fuse_mask_predictor = 1;    // RS_FUSE_MASK_PREDICTOR
+  int side_stream = 1;            // RS_SIDE_STREAM           detection glue on a side stream
+  int narrow_roialign = 0;        // RS_NARROW_ROIALIGN
+  int use_glds = 1;               // RS_USE_GLDS              0: register staging instead of LDS-DMA
+  int fuse_shortcut = 1;          // RS_FUSE_SHORTCUT
+  int use_graph = 0;              // RS_USE_GRAPH
+  int train_roi_side = -1;        // RS_TRAIN_ROI_SIDE        -1: trainer default
+  int train_side = -1;            // RS_TRAIN_SIDE            -1: trainer default (on)
+  int wgrad_target = 512;         // RS_WGRAD_TARGET
+  int wgrad_cb = 0;               // RS_WGRAD_CB
+  int select_debug = 0;           // RS_SELECT_DEBUG
+  int nms_debug = 0;              // RS_NMS_DEBUG
+  int roi_window = 1;             // RS_ROI_WINDOW
+};
+const RsDebug& rs_debug();
+void rs_debug_reload();
+
 // ------------------------------------------------------------------ conv / GEMM
 // Activations are NHWC fp16 with a zero halo: a tensor of logical size (N,H,W,C) is stored as
 // [N][H+2*pad][W+2*pad][Cs] and only the interior is ever written, so 3x3/7x7 convolutions need
@@ -89,6 +117,7 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant /* -1 auto */, int use_glds);
+int conv_choose_variant(ConvParams& p, int force_variant, int use_glds);   // the dispatch rule (also sets p.stages / p.persist)
 extern thread_local int g_last_conv_variant;
 
 // ------------------------------------------------------------------ training: weight gradient (conv_wgrad.hip)
@@ -133,7 +162,5 @@ int launch_maxpool(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho,
 int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
-int launch_conv_f32(const ConvParams& p, hipStream_t stream);
-int launch_conv_pipe(const ConvParams& p, hipStream_t stream);
-int launch_conv_stag(const ConvParams& p, hipStream_t stream);
+int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu = 0);   // ref_f32.hip: fp32 MFMA (or the VALU cross-check)
 int launch_conv_deep(const ConvParams& p, hipStream_t stream);

@@ -348,7 +348,7 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
   // the activation pieces (two steps ahead, from HBM / MALL): 160 KB of LDS leave no room for a deeper prefetch at
   // this tile size.
 #ifdef RS_DEEP_CEILING
-  static const int dbg = [] { const char* e = getenv("RS_DEEP_DBG"); return e ? atoi(e) : 0; }();
+  const int dbg = rs_debug().deep_dbg;
 #else
   constexpr int dbg = 0;
 #endif

@@ -503,37 +503,53 @@ int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
 // the engine tags its stages with it so that bench.py can attribute time and FLOPs per kernel symbol.
 thread_local int g_last_conv_variant = -2;
 
-// variant: 0 = 128x128, 1 = 256x64, 2 = 256x16 (small heads), 3 = 256x128, 4 = 256x256, -1 = choose
+// Tile variants: 0 = 128x128, 1 = 256x64, 2 = 256x16 fp32-out (small heads), 3 = 256x128, 4 = 256x256 (conv_igemm),
+// 5 = small-Cin stem (reported only), 7 = 64x128, 8 = 128x64, 9 = 32x128, 10 = 64x256, 12 = conv_deep 256x256.
+//
+// conv_choose_variant() is the WHOLE dispatch rule -- a pure function of the layer shape (M = batch * Ho * Wo, so of the
+// batch size too) and of the debug switches; launch_conv() only validates and launches what it returns.  It is exported as
+// rs_op_conv_variant so that tests can enumerate the choice per layer and batch size without a GPU
+// (tests/test_host_cpu.py::test_conv_variant_table).  Choices come from the offline sweep over every layer shape of the
+// batch-16 forward (tools/ubench/tune_conv.py, profiles/r01/conv_tile_sweep.txt).
+int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
+  const RsDebug& D = rs_debug();
+  const int nk2 = p.in2 ? (p.Cin2 >> 6) : 0;   // K steps of the second source
+  const bool smallc = p.Cin < 64;
+  const int nk = smallc ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6) + nk2;
+  if (p.stages == 0) {
+    // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second LDS buffer; a
+    // single buffer halves the LDS footprint so 4 workgroups fit per CU and their loads/epilogues overlap each other.
+    // (RS_CONV_PERSIST >= 1: persistent + double buffered instead -- correct, measured not faster: 0.221 vs 0.225 ms on
+    // res2 conv3, slower on conv1; these layers sit at ~3.3 TB/s either way.)
+    const bool shallow = nk <= D.conv_single_stage_nk;
+    if (D.conv_persist >= 1 && shallow && p.mode != 2) { p.stages = 2; p.persist = 2; }
+    else { p.stages = shallow ? 1 : 2; p.persist = D.conv_persist >= 2 && p.mode != 2 ? -1 : 0; }
+  }
+  if (force_variant >= 0) return force_variant;
+  const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
+  const int nkd = smallc ? 0 : nk;
+  const long long tiles0 = (long long)cdiv(p.M, 128) * (rows / 128 > 0 ? rows / 128 : 1);
+  const long long tiles4 = (long long)cdiv(p.M, 256) * (rows / 256 > 0 ? rows / 256 : 1);
+  if (rows <= 16) return 2;
+  if (!D.conv_tuned || p.mode != 0 || smallc) return rows % 128 == 0 ? 0 : 1;
+  if (rows % 128 != 0) return 8;                                          // Cout = 64: 128x64 beats 256x64 everywhere
+  if (rows % 256 == 0 && nkd >= 8 && tiles4 >= 240)                       // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
+    return (D.conv_deep && use_glds > 0 && !p.in2 && p.out_stride <= 1) ? 12 : 4;   // conv_deep incl. the backward epilogue (down / res32 / mask)
+  if (rows % 256 == 0 && nkd <= 4 && p.M >= 100000) return 10;            // HBM-bound 1x1 expansions on big maps: 64x256, rows read once
+  if (nkd <= 4 || tiles0 < 1250) return 7;                                // few tiles or shallow K: 64x128 keeps more workgroups in flight
+  return 0;
+}
+
 int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, int use_glds) {
-  if (use_glds < 0) {                   // fp32 validation mode (ref_f32.hip)
-    RS_CHECK(!p_in.in2, RS_ERR_UNSUPPORTED, "conv: the fp32 validation kernel has no second K source");
-    RS_CHECK(!(p_in.down || p_in.res32 || p_in.mask || p_in.out_stride > 1), RS_ERR_UNSUPPORTED, "conv: the fp32 validation kernel has no training epilogue options");
+  if (use_glds < 0) {                   // fp32 reference-precision mode (ref_f32.hip)
+    RS_CHECK(!p_in.in2, RS_ERR_UNSUPPORTED, "conv: the fp32 kernel has no second K source");
+    RS_CHECK(!(p_in.down || p_in.res32 || p_in.mask || p_in.out_stride > 1), RS_ERR_UNSUPPORTED, "conv: the fp32 kernel has no training epilogue options");
     g_last_conv_variant = -1;
-    return launch_conv_f32(p_in, stream);
+    return launch_conv_f32(p_in, stream, use_glds == -2);      // -2: the VALU cross-check kernel
   }
   ConvParams p = p_in;
-  const int nk2 = p.in2 ? (p.Cin2 >> 6) : 0;   // K steps of the second source
-  const bool train_opts = p.down || p.res32 || p.mask || p.out_stride > 1;   // only conv_igemm_kernel implements these
-  {
-    // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second
-    // LDS buffer; a single buffer halves the LDS footprint so 4 workgroups fit per CU and their
-    // loads/epilogues overlap each other instead.
-    static int nk_single = -1;
-    if (nk_single < 0) { const char* e = getenv("RS_CONV_SINGLE_STAGE_NK"); nk_single = e ? atoi(e) : 4; }
-    const int nk = p.Cin < 64 ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6) + nk2;
-    // RS_CONV_PERSIST: 0 = one workgroup per tile everywhere (single LDS buffer for shallow K);
-    // (default 0: measured, the persistent form is correct but not faster -- 0.221 vs 0.225 ms on res2 conv3, slower on
-    //  conv1 -- these layers sit at ~3.3 TB/s either way) 1 = shallow-K layers run persistent + double buffered so that the next tile's operands load
-    // during the current tile's epilogue; 2 = every layer persistent.
-    static int persist = -1;
-    if (persist < 0) { const char* e = getenv("RS_CONV_PERSIST"); persist = e ? atoi(e) : 0; }
-    if (p.stages == 0) {
-      const bool shallow = nk <= nk_single;
-      if (persist >= 1 && shallow && p.mode != 2) { p.stages = 2; p.persist = 2; }
-      else { p.stages = shallow ? 1 : 2; p.persist = persist >= 2 && p.mode != 2 ? -1 : 0; }
-    }
-
-  }
+  const int nk2 = p.in2 ? (p.Cin2 >> 6) : 0;
+  const bool train_opts = p.down || p.res32 || p.mask || p.out_stride > 1;   // only conv_igemm_kernel / conv_deep implement these
   RS_CHECK(p.M > 0, RS_ERR_ARG, "conv: M=%d", p.M);
   RS_CHECK(p.Kpad % 64 == 0, RS_ERR_ARG, "conv: Kpad %d not a multiple of 64", p.Kpad);
   const bool smallc = p.Cin < 64;
@@ -543,59 +559,21 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     RS_CHECK(p.Cin % 64 == 0, RS_ERR_ARG, "conv: Cin %d not a multiple of 64", p.Cin);
     RS_CHECK(p.KH * p.KW * p.Cin + nk2 * 64 <= p.Kpad, RS_ERR_ARG, "conv: K exceeds Kpad");
   }
-  if (p.in2) {
-    RS_CHECK(!smallc && p.mode == 0 && p.Cin2 % 64 == 0 && p.Cin2 > 0 && p.stride2 >= 1, RS_ERR_ARG, "conv: bad second K source (Cin2 %d)", p.Cin2);
-    RS_CHECK(force_variant != 6 && force_variant != 11, RS_ERR_UNSUPPORTED, "conv: variants 6/11 have no second K source");
-  }
+  if (p.in2) RS_CHECK(!smallc && p.mode == 0 && p.Cin2 % 64 == 0 && p.Cin2 > 0 && p.stride2 >= 1, RS_ERR_ARG, "conv: bad second K source (Cin2 %d)", p.Cin2);
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
-  int v = force_variant;
-  if (v == 6) {                         // experimental software-pipelined 256x256 kernel, on request only
-    g_last_conv_variant = 6;
-    return launch_conv_pipe(p, stream);
-  }
-  if (v == 11) {                        // staggered two-group 256x256 kernel (conv_stag.hip)
-    g_last_conv_variant = 11;
-    return launch_conv_stag(p, stream);
-  }
-  RS_CHECK(!(train_opts && (v == 6 || v == 11 || p.mode != 0 || (v == 12 && p.out_stride > 1))), RS_ERR_UNSUPPORTED, "conv: training epilogue options need a conv_igemm variant or conv_deep (no scatter), mode 0");
+  const int v = conv_choose_variant(p, force_variant, use_glds);
+  RS_CHECK(!(train_opts && (p.mode != 0 || (v == 12 && p.out_stride > 1))), RS_ERR_UNSUPPORTED, "conv: training epilogue options need mode 0 (and no scatter on conv_deep)");
   if (v == 12) {                        // 256x256 with 3 activation stages / 2 weight stages (conv_deep.hip)
     RS_CHECK(!p.in2, RS_ERR_UNSUPPORTED, "conv: variant 12 has no second K source");
     g_last_conv_variant = 12;
     return launch_conv_deep(p, stream);
-  }
-  if (v < 0) {
-    // Tile choice from the offline sweep over every layer shape of the batch-16 forward
-    // (tools/ubench/tune_conv.py, profiles/r01/conv_tile_sweep.txt).  RS_CONV_TUNED=0 restores the
-    // first-round rule (128x128 / 256x64 only).
-    static int tuned = -1;
-    if (tuned < 0) { const char* e = getenv("RS_CONV_TUNED"); tuned = e ? atoi(e) : 1; }
-    const int nk = smallc ? 0 : p.KH * p.KW * (p.Cin >> 6) + nk2;
-    const long long tiles0 = (long long)cdiv(p.M, 128) * (rows / 128 > 0 ? rows / 128 : 1);
-    const long long tiles4 = (long long)cdiv(p.M, 256) * (rows / 256 > 0 ? rows / 256 : 1);
-    if (rows <= 16) v = 2;
-    else if (!tuned || p.mode != 0 || smallc) v = rows % 128 == 0 ? 0 : 1;
-    else if (rows % 128 != 0) v = 8;                                        // Cout = 64: 128x64 beats 256x64 everywhere
-    else if (rows % 256 == 0 && nk >= 8 && tiles4 >= 240) {                 // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
-      static int stag = -1;
-      if (stag < 0) { const char* e = getenv("RS_CONV_STAGGER"); stag = e ? atoi(e) : 0; }
-      if (stag && use_glds > 0 && !p.in2 && !train_opts) { g_last_conv_variant = 11; return launch_conv_stag(p, stream); }
-      static int deep = -1;
-      if (deep < 0) { const char* e = getenv("RS_CONV_DEEP"); deep = e ? atoi(e) : 1; }
-      if (deep && use_glds > 0 && !p.in2 && p.out_stride <= 1) { g_last_conv_variant = 12; return launch_conv_deep(p, stream); }   // incl. the backward epilogue (down / res32 / mask)
-      v = 4;
-    }
-    else if (rows % 256 == 0 && nk <= 4 && p.M >= 100000) v = 10;           // HBM-bound 1x1 expansions on big maps: 64x256, rows read once
-    else if (nk <= 4 || tiles0 < 1250) v = 7;                               // few tiles or shallow K: 64x128 keeps more workgroups in flight
-    else v = 0;
   }
   RS_CHECK(!(p.mode != 0 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
   RS_CHECK(!(p.mode == 2 && !(p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && (v == 0 || v == 10))), RS_ERR_ARG, "fused mask predictor needs its pointers and the 128x128 or 64x256 tile");
   g_last_conv_variant = smallc ? 5 : v;
   if (smallc) {
     RS_CHECK(v == 1, RS_ERR_ARG, "conv: small-Cin path is built for the 256x64 tile only (Cout=%d)", p.Cout);
-    static int stem_small = -1;
-    if (stem_small < 0) { const char* e = getenv("RS_STEM_SMALL_TILE"); stem_small = e ? atoi(e) : 1; }
-    if (stem_small) return launch_variant<4, 1, 4, 2, true, false>(p, stream, use_glds);     // 128x64
+    if (rs_debug().stem_small_tile) return launch_variant<4, 1, 4, 2, true, false>(p, stream, use_glds);     // 128x64
     return launch_variant<4, 1, 4, 4, true, false>(p, stream, use_glds);
   }
   switch (v) {
@@ -608,16 +586,16 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
     case 2:
       RS_CHECK(rows % 16 == 0 && p.out_f32, RS_ERR_ARG, "conv: variant 2 is the 16-channel-tile fp32-out head kernel");
       return launch_variant<4, 1, 1, 4, false, true>(p, stream, use_glds);
-    case 7:   // experiment: 64 px x 128 ch tile (wave tile 32x64): half the accumulators, more workgroups per CU
+    case 7:   // 64 px x 128 ch tile (wave tile 32x64): half the accumulators, more workgroups per CU
       RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 7 needs Cout %% 128 == 0");
       return launch_variant<2, 2, 4, 2, false, false>(p, stream, use_glds);
-    case 9:   // experiment: 32 px x 128 ch tile (wave tile 16x64)
+    case 9:   // 32 px x 128 ch tile (wave tile 16x64)
       RS_CHECK(rows % 128 == 0, RS_ERR_ARG, "conv: variant 9 needs Cout %% 128 == 0");
       return launch_variant<2, 2, 4, 1, false, false>(p, stream, use_glds);
-    case 10:  // experiment: 64 px x 256 ch tile, 8 waves (wave tile 32x64): every activation row read once
+    case 10:  // 64 px x 256 ch tile, 8 waves (wave tile 32x64): every activation row read once
       RS_CHECK(rows % 256 == 0, RS_ERR_ARG, "conv: variant 10 needs Cout %% 256 == 0");
       return launch_variant<2, 4, 4, 2, false, false>(p, stream, use_glds);
-    case 8:   // experiment: 128 px x 64 ch tile (wave tile 32x64, 4 px-waves)
+    case 8:   // 128 px x 64 ch tile (wave tile 32x64, 4 px-waves)
       RS_CHECK(rows % 64 == 0, RS_ERR_ARG, "conv: variant 8 needs Cout %% 64 == 0");
       return launch_variant<4, 1, 4, 2, false, false>(p, stream, use_glds);
     case 3:

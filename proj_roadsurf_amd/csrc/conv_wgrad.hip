@@ -285,8 +285,8 @@ int wgrad_splits(const WgradParams& p) {
   const int cb = wgrad_cb(p);
   const long long out_tiles = (long long)cdiv(p.Cout, cb * 64) * cdiv(p.KH * p.KW * (p.Cin >> 6), 2);
   const int steps = cdiv(p.M, BK);
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("RS_WGRAD_TARGET"); target = e ? atoi(e) : 512; if (target < 1 || target > 1024) target = 1024; }   // the trainer sizes its scratch for <= 1024
+  int target = rs_debug().wgrad_target;
+  if (target < 1 || target > 1024) target = 1024;   // the trainer sizes its scratch for <= 1024
   // ~2 workgroups per CU: more splits only add partial-tile traffic (measured 1024 -> 512: -2 % step time).  The 256-wide
   // tile runs one workgroup per CU: round DOWN so that the grid is at most two full rounds of the 256 CUs.
   long long s = cb == 4 ? (target < 512 ? target : 512) / out_tiles : cdiv(target, out_tiles);
@@ -307,8 +307,7 @@ int launch_conv_wgrad(const WgradParams& p, hipStream_t stream) {
     done = true;
   }
   const int units = p.KH * p.KW * (p.Cin >> 6);
-  static int force_cb = -1;
-  if (force_cb < 0) { const char* e = getenv("RS_WGRAD_CB"); force_cb = e ? atoi(e) : 0; }
+  const int force_cb = rs_debug().wgrad_cb;
   const int cb = force_cb == 2 || force_cb == 4 ? force_cb : wgrad_cb(p);
   dim3 grid(cdiv(p.Cout, cb * 64), cdiv(units, 2), p.splits);
   if (cb == 4) hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(WgCfg<4>::NT), WgCfg<4>::LDS_BYTES, stream, p);

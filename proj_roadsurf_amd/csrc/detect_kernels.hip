@@ -1183,7 +1183,7 @@ int launch_rpn_select(const RpnParams& p, hipStream_t s) {
   RS_CHECK((cap == 1024 || cap == 2048) && p.topk <= cap && p.A <= RS_MAX_ANCHORS && p.L <= RS_MAX_LEVELS, RS_ERR_UNSUPPORTED,
            "rpn: topk %d / capacity %d / A %d / L %d out of range", p.topk, cap, p.A, p.L);
   RpnParams q = p;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("RS_SELECT_DEBUG"); dbg = e ? atoi(e) : 0; } q.debug = dbg; }
+  q.debug = rs_debug().select_debug;
   if (cap == 1024) hipLaunchKernelGGL(rpn_select_kernel<1024>, dim3(p.L, p.N), dim3(1024), 0, s, q);
   else hipLaunchKernelGGL(rpn_select_kernel<2048>, dim3(p.L, p.N), dim3(1024), 0, s, q);
   RS_HIP(hipGetLastError());
@@ -1201,7 +1201,7 @@ int launch_nms(const NmsParams& p, int segments, hipStream_t s) {
   }
   RS_CHECK(p.cap > 0 && p.cap <= 2048 && (p.cap <= 1024 || p.scratch), RS_ERR_ARG, "nms: capacity %d (more than 1024 boxes need NmsParams::scratch)", p.cap);
   NmsParams q = p;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("RS_NMS_DEBUG"); dbg = e ? atoi(e) : 0; } q.debug = dbg; }
+  q.debug = rs_debug().nms_debug;
   if (p.cap <= 1024) hipLaunchKernelGGL(nms_kernel<1024>, dim3(segments), dim3(1024), lds, s, q);
   else {
     // few segments (images x levels) and a quadratic mask build: with one workgroup per segment most of the chip idles, so the
@@ -1238,7 +1238,7 @@ int launch_rpn_merge(const RpnMergeParams& p, int N, hipStream_t s) {
 int launch_roi_align(const RoiAlignParams& p, hipStream_t s) {
   RS_CHECK(p.C == 256, RS_ERR_UNSUPPORTED, "roi_align: C must be 256 (got %d)", p.C);
   RS_CHECK(p.S > 0, RS_ERR_ARG, "roi_align: S");
-  static const int use_win = [] { const char* g = getenv("RS_ROI_WINDOW"); return g ? atoi(g) : 1; }();
+  const int use_win = rs_debug().roi_window;
   if (!p.f32 && use_win && p.P <= RS_ROI_PMAX) hipLaunchKernelGGL(roi_align_win_kernel, dim3(p.S), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(roi_align_kernel, dim3(p.S), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());

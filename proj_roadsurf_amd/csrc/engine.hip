@@ -19,6 +19,27 @@
 // ------------------------------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
 static bool g_trainer_unfused_shortcut = false;   // set by rs_trainer_create while it builds its forward engine
+
+// ---------------------------------------------------------------- debug switches: the one place that reads the environment
+static RsDebug g_debug;
+static bool g_debug_loaded = false;
+void rs_debug_reload() {
+  RsDebug d;
+  auto rd = [](const char* name, int* v) { const char* e = getenv(name); if (e && *e) *v = atoi(e); };
+  rd("RS_CONV_SINGLE_STAGE_NK", &d.conv_single_stage_nk); rd("RS_CONV_PERSIST", &d.conv_persist); rd("RS_CONV_TUNED", &d.conv_tuned);
+  rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
+  rd("RS_DECONV_VARIANT", &d.deconv_variant); rd("RS_FUSE_MASK_PREDICTOR", &d.fuse_mask_predictor); rd("RS_SIDE_STREAM", &d.side_stream);
+  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut);
+  rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
+  rd("RS_TRAIN_SIDE", &d.train_side); rd("RS_WGRAD_TARGET", &d.wgrad_target); rd("RS_WGRAD_CB", &d.wgrad_cb);
+  rd("RS_SELECT_DEBUG", &d.select_debug); rd("RS_NMS_DEBUG", &d.nms_debug); rd("RS_ROI_WINDOW", &d.roi_window);
+  g_debug = d;
+  g_debug_loaded = true;
+}
+const RsDebug& rs_debug() {
+  if (!g_debug_loaded) rs_debug_reload();
+  return g_debug;
+}
 void rs_set_error(const char* fmt, ...) {
   va_list a;
   va_start(a, fmt);
@@ -56,6 +77,7 @@ struct Stage {
   int variant = -2;      // conv tile variant of the last call (-2 = not a conv stage)
   bool narrow = false;   // latency-bound detection glue (few workgroups): runs on the engine's side stream
   bool grad_side = false;   // trainer: weight / bias gradient, off the input-gradient chain (may run on the trainer's side stream)
+  int bucket = -1;          // trainer: gradient bucket this stage writes into (rs_trainer::buckets), -1 = none
   int phase = 0;         // 0 = preprocess..RPN proposals, 1 = box head..detections, 2 = mask head + paste
   hipEvent_t handoff = nullptr;   // recorded on the previous stage's stream when this stage switches streams
 };
@@ -298,7 +320,10 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
   Stage st;
   st.name = name;
   st.flops_per_image = 2.0 * m_per_image * ((double)k * k * cin_real + (in2 ? in2->C : 0)) * out.C;
-  st.bytes_per_image = 2.0 * ((double)in.H * in.W * in.C * units_per_tile + (double)m_per_image * out.C * (1 + (res ? 1 : 0)) +
+  // algorithmic bytes: the input pixels the convolution actually reads (a stride-s 1x1 touches every s-th pixel of every
+  // s-th row only), the output once, the residual once, the second K source at the output's pixel count
+  const double in_px = k >= stride ? (double)in.H * in.W : (double)out.H * out.W * k * k;
+  st.bytes_per_image = 2.0 * (in_px * in.C * units_per_tile + (double)m_per_image * out.C * (1 + (res ? 1 : 0)) +
                               (in2 ? (double)m_per_image * in2->C : 0.0));
   const int glds = use_glds;
   st.fn = [p, m_per_image, glds](int n, hipStream_t s) mutable {
@@ -714,8 +739,7 @@ int rs_engine::build() {
     const BlobEntry* pb = find("roi_heads.mask_head.predictor.b");
     RS_CHECK(dw && db && dw->dims[0] == 1024, RS_ERR_BLOB, "deconv weights missing / wrong rows");
     RS_CHECK(pw && pb && pw->dtype == DT_F32, RS_ERR_BLOB, "mask predictor weights missing");
-    const char* fe = getenv("RS_FUSE_MASK_PREDICTOR");
-    const bool fuse = f32 ? false : (fe ? atoi(fe) != 0 : true);
+    const bool fuse = f32 ? false : rs_debug().fuse_mask_predictor != 0;
     ConvParams dp;
     memset(&dp, 0, sizeof dp);
     dp.in = curm.p; dp.w = (const half_t*)dw->dev; dp.bias = (const float*)db->dev;
@@ -738,9 +762,7 @@ int rs_engine::build() {
       st.fn = [dp, per_roi, Dc, glds, probs, zero_per_tile](int n, hipStream_t s) mutable {
         RS_HIP(hipMemsetAsync(probs, 0, zero_per_tile * n, s));
         dp.M = n * Dc * per_roi;
-        static int dv = -1;
-        if (dv < 0) { const char* e = getenv("RS_DECONV_VARIANT"); dv = e ? atoi(e) : 10; }
-        return launch_conv(dp, s, dv, glds);      // 64x256 tile: one workgroup holds all 256 channels of a (dy,dx) group
+        return launch_conv(dp, s, rs_debug().deconv_variant, glds);      // 64x256 tile: one workgroup holds all 256 channels of a (dy,dx) group
       };
       stages.push_back(st);
       MaskPredictParams mp;
@@ -797,13 +819,11 @@ int rs_engine::build() {
 // alone it changes nothing (the hand-off events keep the order), but two engines that share the wide stream can
 // then hide one batch's glue behind the other batch's convolutions (rs_engine_infer_phase).
 int rs_engine::assign_phases() {
-  const char* g = getenv("RS_SIDE_STREAM");
-  const bool side = (g ? atoi(g) : 1) != 0 && !use_graph;
+  const bool side = rs_debug().side_stream != 0 && !use_graph;
   static const char* kNarrow[] = {"rpn.select_decode", "rpn.nms", "rpn.merge", "box.candidates", "box.nms",
                                   "box.merge_postprocess", "mask.compact"};
   int phase = 0;
-  const char* rn = getenv("RS_NARROW_ROIALIGN");
-  const bool roi_narrow = rn ? atoi(rn) != 0 : false;
+  const bool roi_narrow = rs_debug().narrow_roialign != 0;
   for (Stage& st : stages) {
     if (st.name.rfind("box.", 0) == 0 && phase < 1) phase = 1;
     if (st.name.rfind("mask.", 0) == 0 && st.name != "mask.compact" && phase < 2) phase = 2;
@@ -958,15 +978,13 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   e->spec = *spec;
   e->device = device_ordinal;
   e->max_batch = max_batch; e->tile_h = tile_h; e->tile_w = tile_w; e->tile_c = tile_c;
-  const char* g = getenv("RS_USE_GLDS");
-  e->use_glds = g ? atoi(g) : 1;
+  rs_debug_reload();
+  e->use_glds = rs_debug().use_glds;
   e->f32 = spec->precision == 1;
   if (e->f32) e->use_glds = -1;
-  const char* fs = getenv("RS_FUSE_SHORTCUT");
-  e->fuse_shortcut = fs ? atoi(fs) : 1;
+  e->fuse_shortcut = rs_debug().fuse_shortcut;
   if (g_trainer_unfused_shortcut) e->fuse_shortcut = 0;   // the training engine differentiates conv3 and the shortcut separately
-  const char* gg = getenv("RS_USE_GRAPH");
-  e->use_graph = gg ? atoi(gg) : 0;   // measured: replay == eager (11.54 ms/step either way), so off by default
+  e->use_graph = rs_debug().use_graph;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
   else {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -1135,15 +1153,33 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
   RS_CHECK(e && i >= 0 && i < (int)e->stages.size() && name_out, RS_ERR_ARG, "stage index");
   static const char* names[] = {"conv_igemm_kernel<2,2,4,4> 128x128", "conv_igemm_kernel<4,1,4,4> 256x64", "conv_igemm_kernel<4,1,1,4> 256x16 f32-out",
                                 "conv_igemm_kernel<4,2,4,4> 256x128", "conv_igemm_kernel<2,4,4,8> 256x256", "conv_igemm_kernel<4,1,4,4,smallC> 256x64 stem",
-                                "conv_pipe_kernel 256x256 (4-stage LDS ring, register-double-buffered fragments)",
+                                "(retired)",
                                 "conv_igemm_kernel<2,2,4,2> 64x128", "conv_igemm_kernel<4,1,4,2> 128x64", "conv_igemm_kernel<2,2,4,1> 32x128",
-                                "conv_igemm_kernel<2,4,4,2> 64x256", "conv_stag_kernel 256x256 (two wave groups one phase apart)",
+                                "conv_igemm_kernel<2,4,4,2> 64x256", "(retired)",
                                 "conv_deep_kernel 256x256 (3 activation + 2 weight LDS stages)"};
   const int v = e->stages[i].variant;
   const char* s = v == -1 ? "conv_f32_kernel" : (v >= 0 && v <= 12 ? names[v] : "");
   strncpy(name_out, s, 95);
   name_out[95] = 0;
   return RS_OK;
+}
+
+int rs_engine_stage_variant(rs_engine* e, int i) {
+  if (!e || i < 0 || i >= (int)e->stages.size()) return -2;
+  return e->stages[i].variant;
+}
+
+int rs_op_conv_variant(int m, int cin, int k, int cout, int cin2, int deconv2x, int out_f32, int* stages_out) {
+  ConvParams p;
+  memset(&p, 0, sizeof p);
+  p.M = m; p.Cin = cin; p.KH = p.KW = k; p.Cout = cout; p.mode = deconv2x ? 1 : 0; p.out_f32 = out_f32;
+  p.Kpad = (k * k * (cin < 64 ? 8 : cin) + cin2 + 63) / 64 * 64;
+  if (cin < 64 && k == 7) p.Kpad = 256;       // the stem's padded tap rows (weights.py STEM_KW_PAD)
+  static const half_t dummy = (half_t)0;
+  if (cin2 > 0) { p.in2 = &dummy; p.Cin2 = cin2; }
+  const int v = conv_choose_variant(p, -1, 1);
+  if (stages_out) *stages_out = p.stages;
+  return cin < 64 ? 5 : v;
 }
 
 int rs_engine_tensor(rs_engine* e, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo) {
@@ -1205,7 +1241,7 @@ static int op_conv2d(const void* in, const void* w, const float* bias, void* out
     p.in2_off = in2_halo; p.stride2 = stride2; p.Cin2 = cin2;
   }
   int* koff_dev = nullptr;
-  if (cin < 64) {
+  if (cin < 64 && use_glds >= 0) {
     RS_CHECK(cin == 8, RS_ERR_UNSUPPORTED, "small-Cin path needs cin == 8");
     std::vector<int> koff(kpad / 8, 0);
     for (int t = 0; t < kh * kw && t < (int)koff.size(); ++t) koff[t] = ((t / kw) * p.in_Wp + (t % kw)) * cin;

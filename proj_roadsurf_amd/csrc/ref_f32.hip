@@ -1,19 +1,220 @@
-// fp32 VALIDATION path of the conv/GEMM stages (rs_spec.precision == 1).
+// Reference-precision (fp32) path of the conv / linear stages (rs_spec.precision == 1) on the matrix cores.
 //
-// The production path computes every conv/linear layer with fp16 operands on MFMA.  Detection
-// pipelines amplify tiny feature differences through discrete decisions (top-k, greedy NMS,
-// thresholds), so end-to-end agreement with the fp32 oracle is statistical in fp16.  This file is
-// the same layer semantics (NHWC + zero halo, bias / residual / FPN upsample-add / ReLU epilogue,
-// 2x2 transposed conv as 4 GEMMs, device-side row count) in plain fp32 FMAs, used only to show that
-// the engine's LOGIC reproduces the oracle end to end (tests/test_gpu_engine.py::test_fp32_mode_*).
-// It is not a CPU fallback and not tuned: 64x64 LDS-tiled SGEMM, ~10 TFLOP/s.
+// The reference computes everything in fp32 (no AMP key in R:config/detectron2_config_3bands.yaml; SURVEY.md §8
+// preamble).  The production path uses fp16 operands; this file is the SAME layer semantics (NHWC + zero halo, bias /
+// residual / FPN top-down add / ReLU epilogue, 2x2 transposed conv as 4 GEMMs + pixel shuffle, device-side row count)
+// with fp32 activations and weights on `v_mfma_f32_16x16x4_f32`: exact fp32 (each product rounded once, fp32
+// accumulate -- bitwise a k-ordered fmaf chain, /opt/skills/guides/cdna_hip_programming.md "FP32-input MFMA"), at the
+// fp32 matrix rate (157 TFLOP/s peak = 1/16 of the fp16 rate).  It is the like-for-like mode against the reference's
+// arithmetic and the strict-parity mode of the tests (tests/test_gpu_engine.py::test_fp32_mode_*,
+// ::test_config1_batch16_of_512_tiles); it is not a CPU fallback.
+//
+// Formulation = conv_igemm.hip's: D[channel][pixel] = sum_k W[channel][k] * X[pixel][k]; weights are the MFMA A
+// operand, activations the B operand, so a lane ends up with 4*MI consecutive output channels of one pixel and stores
+// 16-byte pieces straight from registers.  Both operands are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4)
+// into 128-byte rows = one 32-float K step, XOR-swizzled on the source chunk index and on the ds_read_b128 (the byte-level
+// access pattern of the fp16 kernel, so the same conflict-free keys apply), double buffered.
+// K order inside a 32-float step: lane (row i, quarter q) reads floats 4q..4q+3 and 16+4q..16+4q+3 of its row with two
+// ds_read_b128; MFMA number t of a half uses register t of every lane, i.e. k = {t, 4+t, 8+t, 12+t}: a fixed permutation
+// of the summation order, the same for every output element (results do not depend on tile shape or batch size).
+// The old VALU kernel (64x64 LDS-tiled SGEMM, ~10 TFLOP/s) is kept as `conv_f32_valu_kernel` for operands that do not
+// meet the MFMA kernel's shape rules (none on this network) and as the cross-check of tests/test_gpu_conv.py.
 #include "common.h"
 
 namespace {
 
+__device__ __forceinline__ void glds16f(const float* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int WPX, int WCH, int MI, int NJ>
+struct TileF {
+  static constexpr int NW = WPX * WCH;
+  static constexpr int NT = NW * 64;
+  static constexpr int BM = WPX * NJ * 16;   // pixels
+  static constexpr int BN = WCH * MI * 16;   // channels
+  static constexpr int STAGE = (BM + BN) * 128;
+  static constexpr int LDS = 2 * STAGE;
+};
+
+template <int WPX, int WCH, int MI, int NJ>
+__global__ __launch_bounds__(WPX* WCH * 64) void conv_f32_mfma_kernel(const ConvParams p) {
+  using T = TileF<WPX, WCH, MI, NJ>;
+  constexpr int NW = T::NW, BM = T::BM, BN = T::BN;
+  constexpr int PA = BM / (NW * 8);
+  constexpr int PW = (BN + NW * 8 - 1) / (NW * 8);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wpx = wave / WCH, wch = wave % WCH;
+
+  int M = p.M;
+  if (p.m_count) {
+    long long mc = (long long)(*p.m_count) * p.m_mul;
+    if (mc < M) M = (int)mc;
+  }
+  const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
+  const int tiles_n = (rows + BN - 1) / BN;
+  const int ntiles = tiles_n * ((M + BM - 1) / BM);
+  const int q = blockIdx.x;
+  if (q >= ntiles) return;
+  int m0, n0;
+  {
+    const int qn = ntiles >> 3, r = ntiles & 7, x = q & 7;      // XCD-aware order, see conv_igemm.hip
+    const int L = (x < r ? x * (qn + 1) : r * (qn + 1) + (x - r) * qn) + (q >> 3);
+    n0 = (L % tiles_n) * BN;
+    m0 = (L / tiles_n) * BM;
+  }
+  const float* in = (const float*)p.in;
+  const float* w = (const float*)p.w;
+  const int lrow = lane >> 3, lchk = lane & 7;
+  const float* aptr[PA];
+  const float* wptr[PW];
+#pragma unroll
+  for (int ps = 0; ps < PA; ++ps) {
+    int m = m0 + ps * NW * 8 + wave * 8 + lrow;
+    if (m >= M) m = M - 1;
+    const int x2 = m % p.Wo, t = m / p.Wo, y = t % p.Ho, n = t / p.Ho;
+    const long long base = ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x2 * p.stride + p.in_off) * p.in_Cs;
+    aptr[ps] = in + base + (lchk ^ lrow) * 4;
+  }
+#pragma unroll
+  for (int ps = 0; ps < PW; ++ps) {
+    const int row = ps * NW * 8 + wave * 8 + lrow;
+    const int key = (row & 3) | (((row / (4 * MI)) & 1) << 2);
+    int rr = row < BN ? row : BN - 1;
+    if (n0 + rr >= rows) rr = rows - 1 - n0;
+    wptr[ps] = w + (long long)(n0 + rr) * p.Kpad + (lchk ^ key) * 4;
+  }
+  // K steps of 32 floats.  Cin >= 32: (32-channel slice outer, taps inner) like the fp16 kernel.  The stem (Cin = 4, tap
+  // rows padded to KW = 8 -> 32 contiguous floats per kernel row): one step per kernel row.
+  const bool rowmode = p.Cin < 32;
+  const int nk = rowmode ? (p.Kpad >> 5) : p.KH * p.KW * (p.Cin >> 5);
+  int kh = 0, kw = 0, c0 = 0, w_koff = 0, tstep = 0;
+  auto next_off = [&]() {
+    if (rowmode) {
+      const int off = tstep * p.in_Wp * p.in_Cs;
+      w_koff = tstep * 32;
+      ++tstep;
+      return off;
+    }
+    const int off = (kh * p.in_Wp + kw) * p.in_Cs + c0;
+    w_koff = (kh * p.KW + kw) * p.Cin + c0;
+    if (++kw == p.KW) { kw = 0; if (++kh == p.KH) { kh = 0; c0 += 32; } }
+    return off;
+  };
+  auto stage = [&](int buf, int a_off) {
+    char* abase = smem + buf * T::STAGE;
+    char* wbase = abase + BM * 128;
+#pragma unroll
+    for (int ps = 0; ps < PA; ++ps) glds16f(aptr[ps] + a_off, abase + (ps * NW * 8 + wave * 8) * 128);
+#pragma unroll
+    for (int ps = 0; ps < PW; ++ps)
+      if (ps * NW * 8 + wave * 8 < BN) glds16f(wptr[ps] + w_koff, wbase + (ps * NW * 8 + wave * 8) * 128);
+  };
+
+  const int fi = lane & 15, fq = lane >> 4, fkey = lane & 7;
+  int w_off[MI], x_off[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) w_off[i] = BM * 128 + (wch * MI * 16 + (fi >> 2) * 4 * MI + i * 4 + (fi & 3)) * 128;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) x_off[j] = (wpx * NJ * 16 + j * 16 + fi) * 128;
+  const int c_off[2] = {(fq ^ fkey) * 16, ((4 + fq) ^ fkey) * 16};
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, next_off());
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nk) stage((t + 1) & 1, next_off());
+    const char* sb = smem + (t & 1) * T::STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 wf[MI], xf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) wf[i] = *(const f32x4*)(sb + w_off[i] + c_off[s]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xf[j] = *(const f32x4*)(sb + x_off[j] + c_off[s]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][r], xf[j][r], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds channels crow .. crow+4*MI-1 of pixel (j, fi)
+  const int crow = n0 + wch * MI * 16 + fq * 4 * MI;
+  if (crow >= rows) return;
+  int g = 0, cb = crow;
+  if (p.mode != 0) { g = crow / p.Cout; cb = crow % p.Cout; }
+  float bias[4 * MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
+    bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int m = m0 + wpx * NJ * 16 + j * 16 + fi;
+    if (m >= M) continue;
+    const int x = m % p.Wo, t = m / p.Wo, y = t % p.Ho, n = t / p.Ho;
+    int oy = y, ox = x;
+    if (p.mode != 0) { oy = 2 * y + (g >> 1); ox = 2 * x + (g & 1); }
+    const long long opix = (long long)(n * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad;
+    float* op = (float*)p.out + opix * p.out_Cs + cb;
+    const float* rp = p.res ? (const float*)p.res + opix * p.out_Cs + cb : nullptr;
+    const float* up = nullptr;
+    if (p.up) {
+      const long long upix = (long long)(n * p.up_Hp + (y >> 1) + p.up_pad) * p.up_Wp + (x >> 1) + p.up_pad;
+      up = (const float*)p.up + upix * p.up_Cs + cb;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias[i * 4 + r];
+      if (rp) { const f32x4 h = *(const f32x4*)(rp + i * 4); v += h; }
+      if (up) { const f32x4 h = *(const f32x4*)(up + i * 4); v += h; }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      }
+      *(f32x4*)(op + i * 4) = v;
+    }
+  }
+}
+
+template <int WPX, int WCH, int MI, int NJ>
+int launch_f32_variant(const ConvParams& p, hipStream_t stream) {
+  using T = TileF<WPX, WCH, MI, NJ>;
+  const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
+  const long long nblk = (long long)cdiv(rows, T::BN) * cdiv(p.M, T::BM);
+  RS_CHECK(nblk > 0 && nblk < (1ll << 31), RS_ERR_ARG, "conv_f32: bad grid %lld", nblk);
+  const void* k = (const void*)conv_f32_mfma_kernel<WPX, WCH, MI, NJ>;
+  static bool attr = false;
+  if (!attr) {
+    RS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS));
+    attr = true;
+  }
+  ConvParams pc = p;
+  void* args[] = {&pc};
+  RS_HIP(hipLaunchKernel(k, dim3((unsigned)nblk), dim3(T::NT), args, T::LDS, stream));
+  return RS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ VALU cross-check kernel
 constexpr int TM = 64, TN = 64, TK = 16;
 
-__global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_f32_valu_kernel(const ConvParams p) {
   __shared__ float As[TK][TM + 4];   // [k][pixel]
   __shared__ float Ws[TK][TN + 4];   // [k][channel]
   const int tid = threadIdx.x;
@@ -106,13 +307,23 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
 
 }  // namespace
 
-// ConvParams with every tensor pointer (in, w, out, res, up) referring to fp32 data.
-int launch_conv_f32(const ConvParams& p, hipStream_t stream) {
+// ConvParams with every tensor pointer (in, w, out, res, up) referring to fp32 data.  force_valu: the VALU cross-check kernel.
+int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu) {
   RS_CHECK(p.M > 0 && p.mode != 2, RS_ERR_ARG, "conv_f32: bad arguments");
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
+  // shape rules of the MFMA kernel: 128-byte K steps (Cin % 32 == 0, or the stem's 32-float kernel rows), 16-byte aligned
+  // channel groups on both sides
+  const bool rowmode = p.Cin < 32 && p.Cin * p.KW == 32 && p.in_Cs == p.Cin && p.Kpad % 32 == 0;
+  const bool mfma_ok = !force_valu && (p.Cin % 32 == 0 || rowmode) && p.Kpad % 32 == 0 && p.in_Cs % 4 == 0 && p.out_Cs % 4 == 0 &&
+                       rows % 16 == 0 && (p.mode == 0 || p.Cout % 16 == 0) && (!p.up || p.up_Cs % 4 == 0);
+  if (mfma_ok) {
+    if (rows % 128 == 0) return launch_f32_variant<2, 2, 4, 4>(p, stream);    // 128 px x 128 ch
+    if (rows % 64 == 0) return launch_f32_variant<4, 1, 4, 2>(p, stream);     // 128 px x 64 ch
+    return launch_f32_variant<4, 1, 1, 4>(p, stream);                          // 256 px x 16 ch (heads)
+  }
   const long long nblk = (long long)cdiv(rows, TN) * cdiv(p.M, TM);
   RS_CHECK(nblk > 0 && nblk < (1ll << 31), RS_ERR_ARG, "conv_f32: bad grid");
-  hipLaunchKernelGGL(conv_f32_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(conv_f32_valu_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

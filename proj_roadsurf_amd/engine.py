@@ -86,6 +86,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_stage_count.argtypes = [vp]
     lib.rs_engine_stage_info.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_double), i32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rs_engine_stage_kernel.argtypes = [vp, i32, C.c_char_p]
+    lib.rs_engine_stage_variant.argtypes = [vp, i32]
+    lib.rs_op_conv_variant.argtypes = [i32] * 7 + [i32p]
     lib.rs_engine_tensor.argtypes = [vp, C.c_char_p, C.POINTER(vp), i32p, i32p, C.POINTER(C.c_int64), i32p]
     lib.rs_engine_tensor_count.argtypes = [vp]
     lib.rs_engine_tensor_name.argtypes = [vp, i32, C.c_char_p]
@@ -415,6 +417,17 @@ class Engine:
                         "kernel": kn.value.decode()})
         return out
 
+    def stage_variants(self) -> Dict[str, int]:
+        """Conv tile variant each GEMM stage launched in its last call (numbering: include/rs_engine.h rs_op_conv_variant)."""
+        name = C.create_string_buffer(96)
+        out = {}
+        for i in range(self.lib.rs_engine_stage_count(self._h)):
+            v = self.lib.rs_engine_stage_variant(self._h, i)
+            if v != -2:
+                self.lib.rs_engine_stage_info(self._h, i, name, None, None, None, None)
+                out[name.value.decode()] = v
+        return out
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             if not getattr(self, "_borrowed", False):
@@ -579,9 +592,10 @@ class Predictor:
 
 
 class Trainer:
-    """Training engine (include/rs_engine.h ``rs_trainer_*``; SURVEY.md §8a rows T1/T2, in progress): forward engine +
-    flat fp32 master / gradient / momentum buffers + backward stage list.  Round 1: trunk forward/backward and the SGD
-    step; losses, label assignment and RoI-head backward exist as operators (``rs_op_*``) and are wired in next."""
+    """Training engine (include/rs_engine.h ``rs_trainer_*``): forward engine + flat fp32
+    master / gradient / momentum buffers + backward stage list.  ``train_step`` = ``SimpleTrainer.run_step`` up to
+    ``losses.backward()`` (forward, label assignment + sampling, the five losses, backward of every trainable layer);
+    ``apply_sgd`` = the optimiser step; ``allreduce_gradients`` = DDP's gradient averaging over RCCL."""
 
     def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], batch: int = 2,
                  device: int = 0, loss_scale: float = 1.0, lib_path: Optional[str] = None):
@@ -607,6 +621,13 @@ class Trainer:
         lib.rs_trainer_set_loss_scale.argtypes = [vp, C.c_float]
         lib.rs_trainer_fetch_rois.argtypes = [vp, C.c_int, vp, vp, vp]
         lib.rs_trainer_grad_buffer.restype = vp
+        lib.rs_trainer_master_buffer.argtypes = [vp]
+        lib.rs_trainer_master_buffer.restype = vp
+        lib.rs_trainer_bucket_count.argtypes = [vp]
+        lib.rs_trainer_bucket_info.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.rs_trainer_bucket_wait.argtypes = [vp, i32, vp]
+        lib.rs_trainer_bucket_sync.argtypes = [vp, i32]
+        lib.rs_trainer_wait_stream.argtypes = [vp, vp]
         lib.rs_trainer_mask_forward.argtypes = [vp, i32]
         lib.rs_trainer_mask_backward.argtypes = [vp, i32, vp, i32]
         lib.rs_trainer_sync.argtypes = [vp]
@@ -727,9 +748,11 @@ class Trainer:
 
     # ------------------------------------------------------------------ a whole step
     def train_step(self, tiles: np.ndarray, gt_boxes: Sequence[np.ndarray], gt_classes: Sequence[np.ndarray],
-                   gt_polygons: Optional[Sequence[Sequence[Sequence[np.ndarray]]]], seed: int) -> Dict[str, float]:
+                   gt_polygons: Optional[Sequence[Sequence[Sequence[np.ndarray]]]], seed: int, allreduce: bool = False) -> Dict[str, float]:
         """Forward + losses + backward of one batch (``SimpleTrainer.run_step`` up to ``losses.backward()``): gradients end
-        up in the flat gradient buffer; returns the five losses.  ``gt_*`` in NETWORK-INPUT pixels."""
+        up in the flat gradient buffer; returns the five losses.  ``gt_*`` in NETWORK-INPUT pixels.  ``allreduce``: enqueue
+        the data-parallel gradient all-reduce (``allreduce_gradients``) behind the backward pass before the losses are read
+        back, so that the collectives of the early buckets overlap the rest of the backward."""
         n = int(tiles.shape[0])
         self.set_targets(gt_boxes, gt_classes)
         self.forward_trunk(self.upload_tiles(tiles), n)
@@ -741,6 +764,8 @@ class Trainer:
             self.mask_backward(n, targets)
         self.rpn_step(n, seed)
         self.backward_trunk(n)
+        if allreduce:
+            self.allreduce_gradients()
         l = self.tensor("losses")
         names = ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask")
         return {k: float(l[i]) for i, k in enumerate(names)}
@@ -756,29 +781,70 @@ class Trainer:
             self._infer = Engine.from_handle(self.lib, int(self._eng.value), self.spec, (self.tile_h, self.tile_w, self.tile_c), self.batch)
         return self._infer
 
+    def buckets(self) -> List[Tuple[str, int, int]]:
+        """Gradient buckets (name, offset, count in floats of the flat gradient buffer) in the order a step completes them."""
+        out = []
+        name = C.create_string_buffer(96)
+        off, cnt = C.c_int64(), C.c_int64()
+        for i in range(self.lib.rs_trainer_bucket_count(self._h)):
+            _check(self.lib, self.lib.rs_trainer_bucket_info(self._h, i, name, C.byref(off), C.byref(cnt)), "rs_trainer_bucket_info")
+            out.append((name.value.decode(), int(off.value), int(cnt.value)))
+        return out
+
+    def flat(self, which: str = "grad") -> np.ndarray:
+        """Host copy of the whole flat fp32 gradient ("grad") or master-weight ("master") buffer (waits for the step)."""
+        ptr = int(self.lib.rs_trainer_grad_buffer(self._h) if which == "grad" else self.lib.rs_trainer_master_buffer(self._h))
+        a = np.empty(self.param_count, np.float32)
+        self.sync()
+        _check(self.lib, self.lib.rs_memcpy_d2h(a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), a.nbytes), "rs_memcpy_d2h")
+        return a
+
+    def write_flat_grad(self, g: np.ndarray) -> None:
+        g = np.ascontiguousarray(g, np.float32)
+        assert g.shape == (self.param_count,)
+        self.sync()
+        _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(int(self.lib.rs_trainer_grad_buffer(self._h))), g.ctypes.data_as(C.c_void_p), g.nbytes), "rs_memcpy_h2d")
+
     def allreduce_gradients(self) -> None:
-        """Sum the flat gradient buffer over the ranks of the default process group (RCCL: the buffer is handed to
-        torch.distributed in place through ``__cuda_array_interface__``; gloo: through a host copy) and set the divisor the SGD
-        step applies (DDP's averaging)."""
+        """DistributedDataParallel's gradient averaging: SUM every gradient bucket over the ranks of the default process group
+        and set the divisor the SGD step applies.  Buckets are reduced in the order the step completes them (heads, FPN,
+        res5, res4, res3 -- ``buckets()``), each behind its own completion events:
+
+        * RCCL (backend "nccl"): the bucket is handed to torch.distributed in place (``__cuda_array_interface__`` view of the
+          device buffer) as an ASYNCHRONOUS all-reduce; torch's current stream is first made to wait (device side) for the
+          bucket's events, so the call returns at once and the collective runs over xGMI while the trainer's streams are still
+          computing the later buckets' gradients.  Afterwards the trainer's stream waits for the collectives (one event).
+          One process per GPU; the host never blocks here.
+        * gloo (CPU tests, several ranks on one card): per bucket, wait for its events on the host, reduce through a host copy.
+
+        Call it after the backward pass has been ENQUEUED (``train_step(..., allreduce=True)`` does, before it reads the
+        losses back) and before ``apply_sgd``."""
         import torch
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        n = self.param_count
         ptr = int(self.lib.rs_trainer_grad_buffer(self._h))
-        self.sync()
         if dist.get_backend() == "nccl":
-            class _Buf:                      # zero-copy view of the device buffer
-                __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-            t = torch.as_tensor(_Buf(), device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
+            cur = torch.cuda.current_stream()
+            works = []
+            for i, (_, off, cnt) in enumerate(self.buckets()):
+                _check(self.lib, self.lib.rs_trainer_bucket_wait(self._h, i, C.c_void_p(cur.cuda_stream)), "rs_trainer_bucket_wait")
+
+                class _Buf:                      # zero-copy view of the bucket inside the device buffer
+                    __cuda_array_interface__ = {"shape": (cnt,), "typestr": "<f4", "data": (ptr + 4 * off, False), "version": 2}
+                t = torch.as_tensor(_Buf(), device="cuda")
+                works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            for w in works:
+                w.wait()                         # torch's current stream waits for the collective (no host block)
+            _check(self.lib, self.lib.rs_trainer_wait_stream(self._h, C.c_void_p(cur.cuda_stream)), "rs_trainer_wait_stream")
         else:
-            host = np.empty(n, np.float32)
-            _check(self.lib, self.lib.rs_memcpy_d2h(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), host.nbytes), "rs_memcpy_d2h")
-            t = torch.from_numpy(host)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(ptr), host.ctypes.data_as(C.c_void_p), host.nbytes), "rs_memcpy_h2d")
+            for i, (_, off, cnt) in enumerate(self.buckets()):
+                _check(self.lib, self.lib.rs_trainer_bucket_sync(self._h, i), "rs_trainer_bucket_sync")
+                host = np.empty(cnt, np.float32)
+                _check(self.lib, self.lib.rs_memcpy_d2h(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr + 4 * off), host.nbytes), "rs_memcpy_d2h")
+                t = torch.from_numpy(host)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(ptr + 4 * off), host.ctypes.data_as(C.c_void_p), host.nbytes), "rs_memcpy_h2d")
         _check(self.lib, self.lib.rs_trainer_set_grad_divisor(self._h, float(dist.get_world_size())), "rs_trainer_set_grad_divisor")
 
     def export_weights(self, base: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
@@ -863,12 +929,20 @@ class MultiScaleTrainer:
         for t in self._t.values():
             t.set_loss_scale(loss_scale)
 
+    def set_rpn_topk(self, pre: int, post: int) -> None:
+        """RPN.PRE_NMS_TOPK_TRAIN / POST_NMS_TOPK_TRAIN (R:config/detectron2_config_3bands.yaml:248-250) of every trainer."""
+        self._rpn_topk = (int(pre), int(post))
+        for t in self._t.values():
+            t.set_rpn_topk(*self._rpn_topk)
+
     def select(self, size: int) -> Trainer:
         """The trainer for shortest-edge ``size``, holding the up-to-date optimiser state."""
         if size not in self._t:
             t = Trainer(self.spec.replace(min_size_test=int(size)), self.weights, self.tile_shape, self.batch, self.device, self.loss_scale)
             if self._sampling:
                 t.set_sampling(*self._sampling)
+            if getattr(self, "_rpn_topk", None):
+                t.set_rpn_topk(*self._rpn_topk)
             self._t[size] = t
         t = self._t[size]
         if self.current is not None and self.current is not t:

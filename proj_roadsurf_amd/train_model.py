@@ -17,7 +17,7 @@ What follows the reference / detectron2 0.6 and where it is pinned:
   * data parallel: one process per GPU, gradients all-reduced over RCCL/xGMI in one flat 175 MB fp32 buffer and averaged
     (DistributedDataParallel semantics).
 Documented deviations: MIN_SIZE_TRAIN's multi-scale "choice" (R:31-38) is drawn once per BATCH, not per image
-(identical at the reference's one image per GPU), fp16 activations/weights with fp32 master weights and static loss scaling instead of fp32 everywhere, the
+(identical at the reference's one image per GPU), fp16 activations/weights with fp32 master weights and dynamic loss scaling (GradScaler's policy) instead of fp32 everywhere, the
 model-zoo URL of ``model_weights.model_zoo_checkpoint_url`` cannot be fetched offline (use ``model_weights.pth_file`` or
 ``--synthetic-weights``).  Every TEST.EVAL_PERIOD iterations the validation loss and the COCO bbox / segm AP (coco_eval.py, a
 restatement of pycocotools' COCOeval) of the `val` set are logged to metrics.json.
@@ -59,7 +59,70 @@ def load_solver(d2_yaml: str) -> Dict[str, Any]:
         "eval_period": int((cfg.get("TEST", {}) or {}).get("EVAL_PERIOD", 0)),
         "min_size_train": tuple(int(x) for x in ((cfg.get("INPUT", {}) or {}).get("MIN_SIZE_TRAIN") or ())),
         "min_size_sampling": str((cfg.get("INPUT", {}) or {}).get("MIN_SIZE_TRAIN_SAMPLING", "choice")),
+        "max_size_train": int((cfg.get("INPUT", {}) or {}).get("MAX_SIZE_TRAIN", 1333)),
+        "max_size_test": int((cfg.get("INPUT", {}) or {}).get("MAX_SIZE_TEST", 1333)),
+        "crop": bool(((cfg.get("INPUT", {}) or {}).get("CROP", {}) or {}).get("ENABLED", False)),
+        "pre_nms_topk_train": int((m.get("RPN", {}) or {}).get("PRE_NMS_TOPK_TRAIN", 2000)),
+        "post_nms_topk_train": int((m.get("RPN", {}) or {}).get("POST_NMS_TOPK_TRAIN", 1000)),
+        "warmup_method": str(s.get("WARMUP_METHOD", "linear")), "bias_lr_factor": float(s.get("BIAS_LR_FACTOR", 1.0)),
+        "weight_decay_bias": s.get("WEIGHT_DECAY_BIAS", None), "nesterov": bool(s.get("NESTEROV", False)),
+        "clip_gradients": bool((s.get("CLIP_GRADIENTS", {}) or {}).get("ENABLED", False)),
+        "amp": bool((s.get("AMP", {}) or {}).get("ENABLED", False)),
+        "lr_scheduler": str(s.get("LR_SCHEDULER_NAME", "WarmupMultiStepLR")),
+        "sampler_train": str((cfg.get("DATALOADER", {}) or {}).get("SAMPLER_TRAIN", "TrainingSampler")),
     }
+
+
+# capacities of the training engine (csrc/train_engine.inc): ground-truth boxes per image, mask-head entries per image,
+# RoI slots per image, RPN candidates per level
+GT_CAP, MASK_ENTRIES_CAP, ROI_CAP, RPN_PRE_TOPK_CAP, RPN_POST_TOPK_CAP = 128, 256, 1024, 2048, 1024
+
+
+def validate_solver(sv: Dict[str, Any]) -> None:
+    """Reject, up front, every solver / sampler value the training engine does not implement -- never clamp or ignore one
+    silently (the same rule as ``EngineSpec.check_supported`` for the model keys).  Values of the reference YAML
+    (R:config/detectron2_config_3bands.yaml:268-305, :29, :178, :192, :248-250) all pass."""
+    errs = []
+    if sv["lr_scheduler"] != "WarmupMultiStepLR":
+        errs.append(f"SOLVER.LR_SCHEDULER_NAME {sv['lr_scheduler']!r} (only WarmupMultiStepLR)")
+    if sv["warmup_method"] != "linear":
+        errs.append(f"SOLVER.WARMUP_METHOD {sv['warmup_method']!r} (only linear)")
+    if sv["bias_lr_factor"] != 1.0:
+        errs.append(f"SOLVER.BIAS_LR_FACTOR {sv['bias_lr_factor']} (only 1.0: one SGD launch over the flat parameter buffer)")
+    if sv["weight_decay_bias"] not in (None, "None") and float(sv["weight_decay_bias"]) != sv["weight_decay"]:
+        errs.append(f"SOLVER.WEIGHT_DECAY_BIAS {sv['weight_decay_bias']} != WEIGHT_DECAY {sv['weight_decay']}")
+    if sv["nesterov"]:
+        errs.append("SOLVER.NESTEROV true")
+    if sv["clip_gradients"]:
+        errs.append("SOLVER.CLIP_GRADIENTS.ENABLED true")
+    if sv["crop"]:
+        errs.append("INPUT.CROP.ENABLED true")
+    if sv["sampler_train"] != "TrainingSampler":
+        errs.append(f"DATALOADER.SAMPLER_TRAIN {sv['sampler_train']!r} (only TrainingSampler)")
+    if sv["max_size_train"] != sv["max_size_test"]:
+        errs.append(f"INPUT.MAX_SIZE_TRAIN {sv['max_size_train']} != MAX_SIZE_TEST {sv['max_size_test']} (one maximum size per engine geometry)")
+    if sv["roi_batch"] > ROI_CAP:
+        errs.append(f"ROI_HEADS.BATCH_SIZE_PER_IMAGE {sv['roi_batch']} > {ROI_CAP} RoI slots per image")
+    if sv["roi_batch"] * sv["roi_pos"] > MASK_ENTRIES_CAP:
+        errs.append(f"ROI_HEADS.BATCH_SIZE_PER_IMAGE * POSITIVE_FRACTION = {sv['roi_batch'] * sv['roi_pos']:g} foreground RoIs per image > "
+                    f"{MASK_ENTRIES_CAP} mask-head entries per image (the mask loss would silently train on a subset)")
+    if not 1 <= sv["pre_nms_topk_train"] <= RPN_PRE_TOPK_CAP:
+        errs.append(f"RPN.PRE_NMS_TOPK_TRAIN {sv['pre_nms_topk_train']} outside [1, {RPN_PRE_TOPK_CAP}]")
+    if not 1 <= sv["post_nms_topk_train"] <= RPN_POST_TOPK_CAP:
+        errs.append(f"RPN.POST_NMS_TOPK_TRAIN {sv['post_nms_topk_train']} outside [1, {RPN_POST_TOPK_CAP}]")
+    if sv["min_size_sampling"] not in ("choice", "range"):
+        errs.append(f"INPUT.MIN_SIZE_TRAIN_SAMPLING {sv['min_size_sampling']!r}")
+    if errs:
+        raise SystemExit("unsupported training configuration:\n  " + "\n  ".join(errs))
+
+
+def check_gt_capacity(recs: Sequence[Dict[str, Any]], what: str) -> None:
+    """More ground-truth boxes in one image than the engine's per-image capacity would abort the run mid-training: find it
+    before the first step."""
+    worst = max(recs, key=lambda r: len(r["classes"]), default=None)
+    if worst is not None and len(worst["classes"]) > GT_CAP:
+        raise SystemExit(f"{what}: {worst['file_name']} has {len(worst['classes'])} annotations; the training engine holds at most "
+                         f"{GT_CAP} ground-truth boxes per image")
 
 
 def lr_at(sv: Dict[str, Any], it: int) -> float:
@@ -165,7 +228,10 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         backend = os.environ.get("RS_DIST_BACKEND", "nccl")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # rank 0 merges the sharded validation results and runs the (pure-Python) COCO evaluation while the others wait at
+        # the barrier behind it: give the collectives more room than the default watchdog's 10 minutes
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60))
     if world > 1:
         import torch
         ndev = max(1, torch.cuda.device_count())            # counting devices does not initialise the GPU
@@ -199,6 +265,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 draw_annotations(rgb, anns, {k: k for k in range(len(dcats))}, names or None).save(png)
         log.info("tagged sample training images -> %s/", sub)
     sv = load_solver(cfg["detectron2_config_file"])
+    validate_solver(sv)
+    check_gt_capacity(recs, "training set")
     max_iter = args.max_iter or sv["max_iter"]
     mw = cfg.get("model_weights", {}) or {}
     if args.synthetic_weights:
@@ -220,7 +288,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     if sv["min_size_sampling"] == "range" and len(sizes) == 2:
         sizes = list(range(sizes[0], sizes[1] + 1, 32))
     ms = MultiScaleTrainer(spec, W, first.shape, sizes, batch=per_rank, device=local_rank, loss_scale=args.loss_scale)
-    ms.set_sampling(sv["rpn_batch"], sv["rpn_pos"], min(sv["roi_batch"], 1024), sv["roi_pos"])
+    ms.set_sampling(sv["rpn_batch"], sv["rpn_pos"], sv["roi_batch"], sv["roi_pos"])
+    ms.set_rpn_topk(sv["pre_nms_topk_train"], sv["post_nms_topk_train"])
     size_rng = np.random.default_rng(args.seed * 104729 + rank)
     trainer = ms.select(sizes[-1])
     log.info("training: %d images, %d classes, batch %d x %d ranks, %d iterations, shortest-edge sizes %s, %.1f M trainable values",
@@ -245,6 +314,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         val_recs, _ = load_coco_training_set(cfg["COCO_files"]["val"])
         if args.val_max_images:
             val_recs = val_recs[: args.val_max_images]
+        check_gt_capacity(val_recs, "validation set")
 
     def validation_loss(it: int) -> Optional[float]:
         if not val_recs:
@@ -271,17 +341,22 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         return tot / max(cnt, 1)
 
     def validation_ap() -> Dict[str, float]:
-        """COCOEvaluator on the val set (rank 0, bbox + segm AP; coco_eval.py) with the CURRENT weights: inference through the
-        trainer's own forward engine at the test size."""
-        if not val_recs or rank != 0:
+        """COCOEvaluator on the val set (bbox + segm AP; coco_eval.py) with the CURRENT weights.  As detectron2's
+        ``inference_on_dataset`` + ``COCOEvaluator`` do, the images are sharded over the ranks (rank r takes val_recs[r::world]):
+        every rank runs inference through its trainer's own forward engine at the test size and matches detections with
+        ground truth per image (mask IoUs included); only the per-image match records are gathered on rank 0, which
+        accumulates them in image order.  Every rank calls this; a barrier follows, so no rank runs ahead into the next
+        iteration's all-reduce while rank 0 is still evaluating."""
+        if not val_recs:
             return {}
-        from .coco_eval import evaluate
+        from .coco_eval import accumulate, match_images
         from .train_targets import rasterize_polygons_within_box
         vt = ms.select(sizes[-1])
         eng = vt.inference_engine()
+        mine = list(range(rank, len(val_recs), world))
         gts, dts = [], []
-        for k in range(0, len(val_recs), per_rank):
-            chunk = val_recs[k:k + per_rank]
+        for k in range(0, len(mine), per_rank):
+            chunk = [val_recs[i] for i in mine[k:k + per_rank]]
             tiles = np.stack([read_tile(r["file_name"]) for r in chunk])
             for r, inst in zip(chunk, eng.infer(tiles)):
                 h, w = tiles.shape[1:3]
@@ -291,13 +366,28 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                     g["masks"] = np.stack([rasterize_polygons_within_box(p, np.array([0.0, 0.0, w, h]), h) for p in r["polygons"]])
                     d["masks"] = inst.pred_masks
                 gts.append(g); dts.append(d)
-        out = {f"bbox/{k}": v for k, v in evaluate(gts, dts, spec.num_classes, "bbox", spec.detections_per_image).items()}
-        if all("masks" in g for g in gts):
-            out.update({f"segm/{k}": v for k, v in evaluate(gts, dts, spec.num_classes, "segm", spec.detections_per_image).items()})
+        segm = spec.mask_on and all("masks" in g for g in gts)
+        local = {"idx": mine, "bbox": match_images(gts, dts, spec.num_classes, "bbox", spec.detections_per_image),
+                 "segm": match_images(gts, dts, spec.num_classes, "segm", spec.detections_per_image) if segm else None}
+        parts = [local]
+        if world > 1:
+            import torch.distributed as dist
+            gathered = [None] * world if rank == 0 else None
+            dist.gather_object(local, gathered, dst=0)
+            parts = gathered if rank == 0 else []
+            dist.barrier()
+        if rank != 0:
+            return {}
+        out: Dict[str, float] = {}
+        for kind in ("bbox", "segm"):
+            if any(p[kind] is None for p in parts):
+                continue
+            by_image = sorted(((i, r) for p in parts for i, r in zip(p["idx"], p[kind])), key=lambda t: t[0])
+            out.update({f"{kind}/{k}": v for k, v in accumulate([r for _, r in by_image], spec.num_classes).items()})
         return {k: (None if v != v else v) for k, v in out.items()}           # NaN -> null in metrics.json
 
     t0 = time.time()
-    last_trainer, skipped_steps, clean_steps = None, 0, 0
+    last_trainer, skipped_steps, clean_steps, scale_just_cut = None, 0, 0, False
     def load_batch(_it: int):
         """One batch of the DatasetMapper (size draw, sampler, decode, flip, scale): runs on a loader thread one iteration ahead
         of the GPU step.  Only this function touches the sampler and the two RNGs, and batches are requested in order, so the
@@ -322,7 +412,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         if it + 1 < max_iter:
             pending = loader.submit(load_batch, it + 1)      # decoded while this iteration's step runs on the GPU
         trainer = ms.select(size)
-        losses = trainer.train_step(tile_batch, boxes, classes, polys, seed=args.seed * 1000003 + it * world + rank)
+        losses = trainer.train_step(tile_batch, boxes, classes, polys, seed=args.seed * 1000003 + it * world + rank,
+                                    allreduce=world > 1)      # bucketed all-reduce enqueued behind the backward pass
         # dynamic fp16 loss scale (GradScaler's policy): the previous step's overflow flag is read here, after this step's own
         # synchronisation, so it costs no extra stall; a skipped step halves the scale, `--scale-window` clean steps double it.
         # The flag is taken after the all-reduce, so every rank sees the same value and the scales stay in step.
@@ -330,28 +421,52 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         if last_trainer is not None and last_trainer.overflowed():
             skipped_steps += 1
             clean_steps = 0
-            new_scale = max(ms.loss_scale / 2.0, 1.0)
-            log.warning("iteration %d: gradient overflow, step skipped; loss scale %g -> %g", it - 1, ms.loss_scale, new_scale)
+            if not scale_just_cut:
+                # The flag is read one iteration late: this iteration's gradient was computed with the scale that overflowed,
+                # and will most likely overflow (and be skipped on the device) too.  Halve ONCE per overflow episode: the flag
+                # of the step right after a cut still belongs to the old scale and is not counted again.
+                new_scale = max(ms.loss_scale / 2.0, 1.0)
+                log.warning("iteration %d: gradient overflow, step skipped; loss scale %g -> %g", it - 1, ms.loss_scale, new_scale)
+            scale_just_cut = new_scale is not None
         else:
+            scale_just_cut = False
             clean_steps += 1
             if args.scale_window > 0 and clean_steps >= args.scale_window and ms.loss_scale < 65536.0:
                 clean_steps = 0
                 new_scale = ms.loss_scale * 2.0
-        trainer.allreduce_gradients()
         lr = lr_at(sv, it)
         trainer.apply_sgd(lr, sv["momentum"], sv["weight_decay"])
         last_trainer = trainer
         if new_scale is not None:
             ms.set_loss_scale(new_scale)          # after the step: the gradient buffer carried the old scale
-        if not all(np.isfinite(v) for v in losses.values()):
-            raise SystemExit(f"iteration {it}: non-finite loss {losses} (lower --loss-scale)")
-        vloss = validation_loss(it) if (sv["eval_period"] > 0 and ((it + 1) % sv["eval_period"] == 0 or it == max_iter - 1)) else None
+        bad = not all(np.isfinite(v) for v in losses.values())
+        if world > 1:
+            # the decision to stop must be collective: a rank that exits alone leaves the others hung in the next all-reduce
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if bad else 0.0])
+            if dist.get_backend() == "nccl":
+                flag = flag.cuda()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            bad_any = bool(flag.item() > 0)
+        else:
+            bad_any = bad
+        if bad_any:
+            if bad:
+                log.error("iteration %d: non-finite loss %s on rank %d (lower --loss-scale)", it, losses, rank)
+            if world > 1:
+                import torch.distributed as dist
+                dist.destroy_process_group()
+            raise SystemExit(f"iteration {it}: non-finite loss on {'this' if bad else 'another'} rank; every rank stops")
+        do_eval = sv["eval_period"] > 0 and ((it + 1) % sv["eval_period"] == 0 or it == max_iter - 1)
+        vloss = validation_loss(it) if do_eval else None
+        vap = validation_ap() if (do_eval and vloss is not None) else {}
         if rank == 0 and ((it + 1) % args.log_period == 0 or it == max_iter - 1 or vloss is not None):
             rec = {"iteration": it, "total_loss": float(sum(losses.values())), "lr": lr, "time": (time.time() - t0) / (it + 1), **losses,
                    "loss_scale": ms.loss_scale, "skipped_steps": skipped_steps}
             if vloss is not None:
                 rec["validation_loss"] = vloss
-                rec.update(validation_ap())
+                rec.update(vap)
             metrics.write(json.dumps(rec) + "\n")
             metrics.flush()
             log.info("iter %d  total_loss %.4f  %s  lr %.6f  %.3f s/iter", it, rec["total_loss"],

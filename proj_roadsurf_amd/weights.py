@@ -5,8 +5,8 @@
   is a training artefact, R:config/detectron2_config_3bands.yaml:265 a URL), so benches and parity
   tests use these.
 * ``load_checkpoint``    -- reads a detectron2 ``.pth`` (``torch.save({'model': state_dict, ...})``)
-  with ``weights_only=True``.  The model-zoo ``.pkl`` is a pickle and is NOT loaded (executing
-  pickles from outside is forbidden here); convert it to ``.pth``/``.npz`` elsewhere.
+  with ``weights_only=True``; the model-zoo ``.pkl`` through ``load_zoo_pkl``, a restricted unpickler
+  that admits numpy array reconstruction only and refuses every other global (nothing from the file runs).
 * ``pack_weights``       -- folds FrozenBN into conv scale/bias, converts to the engine's
   kernel-ready layout (fp16 ``[Cout][KH][KW][Cin]``, K padded to 64, fp32 bias) and serialises to
   the flat blob ``rs_engine_create`` consumes (format: include/rs_engine.h "weight blob").
@@ -146,12 +146,55 @@ def load_checkpoint(path: str) -> Dict[str, np.ndarray]:
         with np.load(path, allow_pickle=False) as z:
             return {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
     if path.endswith(".pkl"):
-        raise ValueError("model-zoo .pkl files are pickles and are not loaded here; convert to .pth/.npz")
+        return load_zoo_pkl(path)
     import torch
 
     ck = torch.load(path, map_location="cpu", weights_only=True)
     sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
     return {k: v.detach().float().numpy() for k, v in sd.items() if hasattr(v, "detach")}
+
+
+# globals a dict-of-ndarrays pickle needs, and nothing else: numpy's array / dtype / scalar reconstructors, the dict
+# type detectron2's zoo files use, and the str->bytes helper protocol-2 pickles written by Python 2 carry
+_PKL_ALLOWED = {
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"), ("collections", "OrderedDict"), ("_codecs", "encode"),
+}
+
+
+def load_zoo_pkl(path: str) -> Dict[str, np.ndarray]:
+    """Code-free reader for detectron2 model-zoo ``.pkl`` checkpoints (R:config/detectron2_config_3bands.yaml:265,
+    R:config/config_obj_detec.yaml:71-72: ``{"model": {name: ndarray}, "__author__": ...}``).  A ``pickle.Unpickler``
+    whose ``find_class`` admits ONLY the symbols in ``_PKL_ALLOWED`` (numpy array / dtype / scalar reconstruction,
+    ``OrderedDict``, ``_codecs.encode``); any other global -- i.e. any pickle that would import or call something --
+    raises ``pickle.UnpicklingError`` before anything of it runs.  Object-dtype arrays are rejected as well.
+    Keys must already be detectron2's names (zoo files of detectron2-trained models are; Caffe2-converted files with
+    ``matching_heuristics`` are not supported)."""
+    import importlib
+    import pickle
+
+    class _Restricted(pickle.Unpickler):
+        def find_class(self, module: str, name: str):
+            if (module, name) not in _PKL_ALLOWED:
+                raise pickle.UnpicklingError(f"{path}: pickle references {module}.{name}; only numpy array data is accepted")
+            return getattr(importlib.import_module(module), name)
+
+    with open(path, "rb") as f:
+        obj = _Restricted(f, encoding="latin1").load()
+    model = obj["model"] if isinstance(obj, dict) and "model" in obj else obj
+    if not isinstance(model, dict):
+        raise ValueError(f"{path}: expected a dict of arrays, got {type(model).__name__}")
+    out: Dict[str, np.ndarray] = {}
+    for k, v in model.items():
+        a = np.asarray(v)
+        if a.dtype == object or not isinstance(k, str):
+            raise ValueError(f"{path}: entry {k!r} is not numeric array data")
+        out[k] = a.astype(np.float32)
+    if not any(k.startswith("backbone.bottom_up.") for k in out):
+        raise ValueError(f"{path}: keys are not detectron2 names (Caffe2-style checkpoints need detectron2's c2_model_loading "
+                         "renaming, which is not restated here)")
+    return out
 
 
 def infer_num_classes(W: Dict[str, np.ndarray]) -> int:

@@ -468,3 +468,101 @@ def test_no_detections_and_mixed_batches(gpu_required):
             assert np.array_equal(alone._packed, batch[i]._packed)
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# The configurations bench.py measures (BASELINE.json configs[1] and configs[3]) at full size.  The conv tile variant is
+# chosen from M = batch * pixels (csrc/conv_igemm.hip conv_choose_variant), so batch 16 / batch 8 launch other kernels than
+# the batch 1-3 tests above; every variant accumulates each output over K in the same order, so a tile's result must not
+# depend on the batch it travels in.
+# ---------------------------------------------------------------------------------------------
+def _same_instances(a, b):
+    return (len(a) == len(b) and np.array_equal(a.pred_boxes, b.pred_boxes) and np.array_equal(a.scores, b.scores) and
+            np.array_equal(a.pred_classes, b.pred_classes) and np.array_equal(a._packed, b._packed))
+
+
+def test_engine_launches_the_tabled_variants(gpu_required):
+    """What the engine launches per layer at batch 1 / 3 / 8 / 16 of the 800x800 input == the committed dispatch table
+    (tests/golden/conv_variants.json, whose CPU side is tests/test_host_cpu.py::test_conv_variant_table)."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "conv_variants.json")))
+    spec = EngineSpec(num_classes=2)
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(16, 512, 512, 3, seed=1234)
+    eng = Engine(spec, W, (512, 512, 3), max_batch=16)
+    try:
+        for bi, b in enumerate(gold["batches"]):
+            eng.infer(tiles[:b])
+            got = eng.stage_variants()
+            assert list(got) == list(gold["variants"]), "stage list changed: regenerate tests/golden/conv_variants.json"
+            for name, v in got.items():
+                assert v == gold["variants"][name][bi], f"batch {b}, {name}: launched variant {v}, table says {gold['variants'][name][bi]}"
+    finally:
+        eng.close()
+
+
+def test_config1_batch16_of_512_tiles(gpu_required):
+    """BASELINE configs[1], the headline: batch 16 of 512x512x3 tiles, 800x800 network input.
+    (a) fp16 production mode: each of the 16 detection sets is BIT-IDENTICAL to the same tile run alone (other tile variants);
+    (b) reference-precision mode: batch 16 == the same tiles run alone, bit for bit, and tiles 0 and 15 meet the strict
+        bar against the fp32 oracle (>= 98 % matched both ways at IoU >= 0.99, |dscore| <= 1e-4, |dbox| <= 1e-2 px)."""
+    O = _oracle()
+    spec = EngineSpec(num_classes=2)
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(16, 512, 512, 3, seed=1234)
+    eng = Engine(spec, W, (512, 512, 3), max_batch=16)
+    try:
+        batch = eng.infer(tiles)
+        assert all(len(d) > 0 for d in batch)
+        for i in (0, 5, 10, 15):
+            alone = eng.infer(tiles[i:i + 1])[0]
+            assert _same_instances(alone, batch[i]), f"fp16: tile {i} differs between batch 16 and batch 1"
+    finally:
+        eng.close()
+    spec32 = spec.replace(precision="fp32")
+    eng = Engine(spec32, W, (512, 512, 3), max_batch=16)
+    try:
+        batch = eng.infer(tiles)
+        for i in (0, 15):
+            alone = eng.infer(tiles[i:i + 1])[0]
+            assert _same_instances(alone, batch[i]), f"fp32: tile {i} differs between batch 16 and batch 1"
+        ref = O.OracleModel(spec32, W)([tiles[0], tiles[15]])
+        _strict_compare(ref[0], batch[0], "config1_b16[0]")
+        _strict_compare(ref[1], batch[15], "config1_b16[15]")
+    finally:
+        eng.close()
+
+
+def test_config3_4band_1024_tiles_batch8(gpu_required):
+    """BASELINE configs[3] at FULL size: RGB+NIR 1024x1024 tiles (antialiased Pillow down-scaling to 800x800, stem Cin = 4),
+    batch 8.  Reference-precision mode: tile 0 meets the strict bar against the oracle; fp16 mode: batch 8 is bit-identical to
+    the tiles run alone, pre-processing is bit-exact, and the detections match the oracle's to the fp16 bar of this
+    random-weight workload."""
+    O = _oracle()
+    spec = EngineSpec(num_classes=2, pixel_mean=(103.53, 116.28, 123.675, 110.0), pixel_std=(1.0, 1.0, 1.0, 1.0))
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(8, 1024, 1024, 4, seed=4321)
+    ref = O.OracleModel(spec, W)([tiles[0]], keep=True)[0]
+    eng = Engine(spec.replace(precision="fp32"), W, (1024, 1024, 4), max_batch=1)
+    try:
+        d32 = eng.infer(tiles[:1])[0]
+        x = eng.tensor("net_input", n=1)
+        assert np.array_equal(x[0], ref["inter"]["net_input"].permute(1, 2, 0).numpy()), "4-band antialiased resize differs"
+        _strict_compare(ref, d32, "config3_fp32")
+    finally:
+        eng.close()
+    eng = Engine(spec, W, (1024, 1024, 4), max_batch=8)
+    try:
+        assert eng.net_shape() == (800, 800, 800, 800)
+        batch = eng.infer(tiles)
+        for i in (0, 7):
+            assert _same_instances(eng.infer(tiles[i:i + 1])[0], batch[i]), f"tile {i} differs between batch 8 and batch 1"
+        r = {"boxes": ref["boxes"].numpy(), "scores": ref["scores"].numpy(), "classes": ref["classes"].numpy(), "masks": ref["masks"].numpy()}
+        g = {"boxes": batch[0].pred_boxes, "scores": batch[0].scores, "classes": batch[0].pred_classes, "masks": batch[0].pred_masks}
+        fw, bw = match_detections(r, g), match_detections(g, r)
+        print("config3_fp16", fw, bw)
+        assert fw["max_dscore"] <= 0.02 and fw["agg_mask_iou"] >= 0.9, fw
+        assert fw["frac_matched"] >= 0.8 and bw["frac_matched"] >= 0.8, (fw, bw)
+    finally:
+        eng.close()

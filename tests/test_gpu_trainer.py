@@ -515,6 +515,20 @@ def test_train_model_two_ranks_data_parallel(gpu_required, tmp_path):
     assert "batch 1 x 2 ranks" in r.stderr
 
 
+def test_data_parallel_allreduce_sums_and_averages(gpu_required):
+    """The data-parallel gradient exchange (engine.Trainer.allreduce_gradients: bucketed, behind per-bucket completion events),
+    two ranks on this box's GPU over gloo -- tests/dp_worker.py asserts: reduced buffer == g0 + g1 exactly, master weights
+    bit-identical across ranks after the SGD step and equal to a single-process step on the summed gradient with divisor 2."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29537", os.path.join(root, "tests", "dp_worker.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DP_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_multi_scale_state_handover(gpu_required):
     """MIN_SIZE_TRAIN "choice": the optimiser state follows the batch from the trainer of one input size to the next -- after a
     step at 160 px, the 192 px trainer holds bit-identical master weights and momentum and a refolded forward."""
@@ -631,10 +645,12 @@ def test_trainer_inference_engine_tracks_the_weights(gpu_required):
 
 
 def test_side_stream_gradients_equal_single_stream(gpu_required, monkeypatch):
-    """Weight / bias gradients run on the trainer's side stream next to the input-gradient chain (rs_trainer::run_list).  The
-    flat gradient of the same step (same tiles, targets, sampling seed) must equal the single-stream run up to the last-bit
-    noise of ROIAlign-backward's float atomics (measured floor: 1.5e-5 relative L2)."""
-    import ctypes as C
+    """Weight / bias gradients run on the trainer's side stream next to the input-gradient chain (rs_trainer::run_list), and
+    RoIAlign backward may run there too (RS_TRAIN_ROI_SIDE).  The gradients of the same step (same tiles, targets, sampling
+    seed) are compared PER TENSOR with the single-stream run: the head layers (box / mask / RPN: nothing of theirs is downstream
+    of RoIAlign-backward's float atomics) must be bit-identical; FPN and ResNet tensors see the atomics' last-bit noise through
+    d:p2..p5 (measured floor 1.5e-5 relative L2 on the whole buffer) and must agree to 2e-4 each -- a race that corrupts one
+    small layer cannot hide in a global norm."""
     spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533)
     Wn = synthetic_weights(spec, seed=0)
     tiles = synthetic_tiles(2, 256, 256, 3, seed=77)
@@ -642,27 +658,34 @@ def test_side_stream_gradients_equal_single_stream(gpu_required, monkeypatch):
     gc = [np.array([0, 1]), np.array([1])]
     polys = [[[np.array([b[0], b[1], b[2], b[1], b[2], b[3], b[0], b[3]], np.float64)] for b in bs] for bs in gb]
 
-    def grads(side):
+    def grads(side, roi_side):
         monkeypatch.setenv("RS_TRAIN_SIDE", str(side))
+        monkeypatch.setenv("RS_TRAIN_ROI_SIDE", str(roi_side))
         tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=256.0)
         out = []
         try:
+            names = [n for n in tr.tensor_names() if n.startswith("g:")]
             for _ in range(2):
                 tr.train_step(tiles, gb, gc, polys, seed=5)
-                tr.sync()
-                host = np.empty(tr.param_count, np.float32)
-                ptr = int(tr.lib.rs_trainer_grad_buffer(tr._h))
-                assert tr.lib.rs_memcpy_d2h(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), host.nbytes) == 0
-                out.append(host)
+                out.append({n: tr.tensor(n) for n in names})
         finally:
             tr.close()
         return out
 
-    ref = grads(0)[0]
-    assert float(np.abs(ref).max()) > 0
-    for g in grads(1):
-        rel = float(np.linalg.norm(g - ref) / np.linalg.norm(ref))
-        assert rel <= 1e-3, rel
+    ref = grads(0, 0)[0]
+    assert len(ref) > 100 and all(float(np.abs(v).max()) > 0 for k, v in ref.items() if k.endswith(".w"))
+    worst = 0.0
+    for side, roi_side in ((1, 0), (1, 1)):
+        for g in grads(side, roi_side):
+            for name, want in ref.items():
+                got = g[name]
+                if "backbone." in name:
+                    rel = float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+                    worst = max(worst, rel)
+                    assert rel <= 2e-4, (side, roi_side, name, rel)
+                else:
+                    assert np.array_equal(got, want), (side, roi_side, name, float(np.abs(got - want).max()))
+    print("side-stream per-tensor worst rel L2 (backbone tensors):", worst)
 
 
 def test_overflowing_gradient_skips_the_step(gpu_required):

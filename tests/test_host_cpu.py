@@ -127,9 +127,7 @@ def test_pack_weights_blob_roundtrip_and_bn_fold():
     assert T["roi_heads.mask_head.deconv.w"].shape == (1024, 256)
 
 
-def test_checkpoint_loader_refuses_pickle(tmp_path):
-    with pytest.raises(ValueError):
-        Wt.load_checkpoint(str(tmp_path / "model_final.pkl"))
+def test_checkpoint_loader_pth_weights_only(tmp_path):
     import torch
     W = {"roi_heads.box_predictor.cls_score.weight": torch.zeros(3, 1024)}
     p = tmp_path / "m.pth"
@@ -147,3 +145,84 @@ def test_engine_fails_loudly_without_gpu(lib):
     spec = EngineSpec(num_classes=2)
     with pytest.raises(RsError):
         Engine(spec, Wt.synthetic_weights(spec, 0), (64, 64, 3), max_batch=1)
+
+
+def test_zoo_pkl_reader_accepts_arrays_only(tmp_path):
+    """R:config/detectron2_config_3bands.yaml:265 (model-zoo .pkl): a dict-of-ndarrays pickle loads; a pickle that references
+    any other global is refused before anything of it runs."""
+    import pickle
+
+    from proj_roadsurf_amd.weights import load_checkpoint, load_zoo_pkl
+
+    good = {"model": {"backbone.bottom_up.stem.conv1.weight": np.arange(24, dtype=np.float32).reshape(2, 3, 2, 2),
+                      "roi_heads.box_predictor.cls_score.weight": np.ones((3, 4), np.float64)},
+            "__author__": "Detectron2 Model Zoo"}
+    for proto in (2, 4):
+        p = tmp_path / f"good{proto}.pkl"
+        p.write_bytes(pickle.dumps(good, protocol=proto))
+        W = load_checkpoint(str(p))
+        assert set(W) == set(good["model"]) and all(v.dtype == np.float32 for v in W.values())
+        assert np.array_equal(W["backbone.bottom_up.stem.conv1.weight"], good["model"]["backbone.bottom_up.stem.conv1.weight"])
+
+    marker = tmp_path / "executed"
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, (f"touch {marker}",))
+
+    for payload in ({"model": {"backbone.bottom_up.x": Evil()}}, Evil(), {"model": {"backbone.bottom_up.x": np.array([Evil()], dtype=object)}}):
+        p = tmp_path / "evil.pkl"
+        p.write_bytes(pickle.dumps(payload))
+        with pytest.raises(pickle.UnpicklingError):
+            load_zoo_pkl(str(p))
+        assert not marker.exists()
+    # not detectron2 key names
+    p = tmp_path / "c2.pkl"
+    p.write_bytes(pickle.dumps({"blobs": {"conv1_w": np.zeros(3, np.float32)}}))
+    with pytest.raises(ValueError):
+        load_zoo_pkl(str(p))
+
+
+def test_conv_variant_table(lib):
+    """The conv tile dispatch depends on M = batch * pixels, i.e. on the batch size (csrc/conv_igemm.hip
+    conv_choose_variant).  Enumerate it per layer at batch 1 / 3 / 8 / 16 of the 800x800 network input and compare with
+    the committed table, so that a change of the rule -- and which benchmarked layers it moves -- is visible in review.
+    The GPU side (tests/test_gpu_engine.py::test_engine_launches_the_tabled_variants) checks that the engine really
+    launches these."""
+    import json
+
+    from tests.util import conv_stage_shapes
+    lib.rs_op_conv_variant.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)]
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "conv_variants.json")))
+    shapes = conv_stage_shapes(EngineSpec(num_classes=2), *gold["net_input"])
+    assert [s[0] for s in shapes] == list(gold["variants"])
+    for name, mpi, cin, k, cout, cin2, forced in shapes:
+        got = [forced if forced is not None else lib.rs_op_conv_variant(b * mpi, cin, k, cout, cin2, 0, 0, None) for b in gold["batches"]]
+        assert got == gold["variants"][name], f"{name}: dispatch {got} != committed {gold['variants'][name]}"
+    # the benchmarked batch (16) runs the deep 256x256 kernel on exactly these layers
+    deep = [n for n, v in gold["variants"].items() if v[gold["batches"].index(16)] == 12]
+    assert deep == ["res5.1.conv3", "res5.2.conv3", "fpn_lateral3", "fpn_output3", "fpn_output2", "rpn.conv2", "rpn.conv3",
+                    "box.fc1", "box.fc2", "mask.fcn1", "mask.fcn2", "mask.fcn3", "mask.fcn4"]
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks through torch.distributed.run on 127.0.0.1 before it
+    touches the GPU."""
+    import subprocess
+    import sys
+
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    assert bench.spawn_ranks(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

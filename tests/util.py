@@ -2,34 +2,7 @@
 import numpy as np
 
 
-def synthetic_tiles(n, h, w, c=3, seed=1234, kind="S"):
-    """SURVEY.md §8d synthetic inputs: (U) iid uniform noise, (S) smooth multi-octave noise + random
-    filled rectangles ("aerial-like")."""
-    out = np.zeros((n, h, w, c), np.uint8)
-    for i in range(n):
-        rng = np.random.default_rng(seed + i)
-        if kind == "U":
-            out[i] = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
-            continue
-        img = np.zeros((h, w, c), np.float32)
-        for o in range(4):
-            g = 4 * (2 ** o)
-            coarse = rng.uniform(0, 1, (g + 1, g + 1, c)).astype(np.float32)
-            ys = np.linspace(0, g, h, endpoint=False)
-            xs = np.linspace(0, g, w, endpoint=False)
-            y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
-            fy = (ys - y0)[:, None, None]; fx = (xs - x0)[None, :, None]
-            a = coarse[y0][:, x0]; b = coarse[y0][:, x0 + 1]; cc = coarse[y0 + 1][:, x0]; d = coarse[y0 + 1][:, x0 + 1]
-            img += ((a * (1 - fx) + b * fx) * (1 - fy) + (cc * (1 - fx) + d * fx) * fy) / (2 ** o)
-        img = img / img.max() * 200.0
-        for _ in range(20):
-            cx, cy = rng.uniform(0, w), rng.uniform(0, h)
-            rw, rh = rng.uniform(4, w / 3), rng.uniform(4, h / 3)
-            x0, x1 = int(max(0, cx - rw / 2)), int(min(w, cx + rw / 2))
-            y0, y1 = int(max(0, cy - rh / 2)), int(min(h, cy + rh / 2))
-            img[y0:y1, x0:x1] = rng.uniform(0, 255, c)
-        out[i] = np.clip(img, 0, 255).astype(np.uint8)
-    return out
+from proj_roadsurf_amd.synthetic import synthetic_scenes, synthetic_tiles  # noqa: F401  (one definition, in the package)
 
 
 def box_iou(a, b):
@@ -76,3 +49,45 @@ def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
     n = len(sel)
     return {"frac_matched": matched / n if n else 1.0, "max_dscore": dscore, "min_mask_iou": miou, "n_ref": n,
             "agg_mask_iou": (inter_sum / union_sum) if union_sum else 1.0, "max_dbox": dbox}
+
+
+def conv_stage_shapes(spec, net_h=800, net_w=800):
+    """(stage name, output pixels per tile, cin, k, cout, cin2, forced variant or None) of every GEMM stage of the fp16
+    inference engine, in execution order -- the host-side mirror of csrc/engine.hip rs_engine::build() that the
+    tile-dispatch tests enumerate.  Output pixels per tile times the batch size is the GEMM's M."""
+    out = []
+    h2, w2, h4, w4 = net_h // 2, net_w // 2, net_h // 4, net_w // 4
+    out.append(("stem.conv1", h2 * w2, 4, 7, spec.stem_out_channels, 0, None))
+    cur_c, bott, cout, ch, cw = spec.stem_out_channels, 64, spec.res2_out_channels, h4, w4
+    for si, nb in enumerate(spec.res_blocks):
+        for bi in range(nb):
+            nm = f"res{si + 2}.{bi}"
+            stride = 2 if (bi == 0 and si > 0) else 1
+            s1 = stride if spec.stride_in_1x1 else 1
+            oh, ow = ch // stride, cw // stride
+            proj = cur_c != cout
+            out.append((nm + ".conv1", (ch // s1) * (cw // s1), cur_c, 1, bott, 0, None))
+            out.append((nm + ".conv2", oh * ow, bott, 3, bott, 0, None))
+            out.append((nm + ".conv3", oh * ow, bott, 1, cout, cur_c if proj else 0, None))
+            cur_c, ch, cw = cout, oh, ow
+        bott *= 2
+        cout *= 2
+    sizes = [(h4 >> l, w4 >> l) for l in range(4)]
+    res_c = [spec.res2_out_channels * (2 ** i) for i in range(4)]
+    for l in (3, 2, 1, 0):
+        out.append((f"fpn_lateral{l + 2}", sizes[l][0] * sizes[l][1], res_c[l], 1, 256, 0, None))
+        out.append((f"fpn_output{l + 2}", sizes[l][0] * sizes[l][1], 256, 3, 256, 0, None))
+    p6 = ((sizes[3][0] - 1) // 2 + 1, (sizes[3][1] - 1) // 2 + 1)
+    for l, (a, b) in enumerate(sizes + [p6]):
+        out.append((f"rpn.conv{l + 2}", a * b, 256, 3, 256, 0, None))
+        out.append((f"rpn.heads{l + 2}", a * b, 256, 1, 16, 0, 2))
+    pr, fc = spec.box_pooler_resolution, spec.box_fc_dim
+    out.append(("box.fc1", 1024, pr * pr * 256, 1, fc, 0, None))
+    out.append(("box.fc2", 1024, fc, 1, fc, 0, None))
+    out.append(("box.predictor", 1024, fc, 1, 16, 0, 2))
+    if spec.mask_on:
+        mr, d = spec.mask_pooler_resolution, spec.detections_per_image
+        for i in range(spec.mask_num_conv):
+            out.append((f"mask.fcn{i + 1}", d * mr * mr, 256, 3, 256, 0, None))
+        out.append(("mask.deconv_predict", d * mr * mr, 256, 1, 256, 0, 10))
+    return out

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from proj_roadsurf_amd.engine import Engine
 from proj_roadsurf_amd.spec import EngineSpec
 from proj_roadsurf_amd.weights import synthetic_weights
-from tests.util import synthetic_tiles
+from proj_roadsurf_amd.synthetic import synthetic_tiles
 
 spec = EngineSpec(num_classes=2)
 W = synthetic_weights(spec, 0)

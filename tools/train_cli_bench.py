@@ -26,7 +26,7 @@ def main():
     import yaml
     from PIL import Image
     from proj_roadsurf_amd import train_model
-    from tests.util import synthetic_tiles
+    from proj_roadsurf_amd.synthetic import synthetic_tiles
 
     with tempfile.TemporaryDirectory() as td:
         wd = os.path.join(td, "obj_detector")

@@ -25,7 +25,7 @@ def main():
     from proj_roadsurf_amd.engine import Trainer
     from proj_roadsurf_amd.spec import EngineSpec
     from proj_roadsurf_amd.weights import synthetic_weights
-    from tests.util import synthetic_tiles
+    from proj_roadsurf_amd.synthetic import synthetic_tiles
 
     spec = EngineSpec(num_classes=2)
     W = synthetic_weights(spec, seed=0)
