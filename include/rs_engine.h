@@ -85,6 +85,19 @@ typedef struct rs_dets {
   float* mask_probs;  /* [n][D][28][28] sigmoid probabilities before pasting */
 } rs_dets;
 
+/* Detection masks cropped to their boxes (a pasted mask is zero outside its box): what the streaming host interface copies
+ * instead of the full canvases -- 100 x h x ceil(w/8) bytes per tile (3.3 MB at 512x512, 13 MB at 1024x1024) shrink to the
+ * boxes' area.  Crop (i, d) covers byte columns [rects[0], rects[0] + rects[2]) and rows [rects[1], rects[1] + rects[3]) of
+ * the bit-packed canvas rs_dets.masks describes, rows stored back to back at data + offsets[i][d]; crops follow each other
+ * in (tile, slot) order.  Caller-allocated (pinned memory recommended); capacity n*D*h*ceil(w/8) always suffices. */
+typedef struct rs_mask_crops {
+  int32_t* rects;      /* [n][D][4]: first byte column, first row, bytes per row, rows; zeros for empty slots */
+  uint32_t* offsets;   /* [n][D] */
+  uint8_t* data;
+  uint64_t capacity;   /* bytes available at data */
+  uint64_t used;       /* out (rs_engine_fetch_crops_wait): bytes written */
+} rs_mask_crops;
+
 typedef struct rs_engine rs_engine;
 
 /* Build an engine for tiles of one fixed shape (h, w, c) and batches of up to max_batch tiles.
@@ -125,6 +138,12 @@ void rs_host_free(void* p);
 int rs_engine_upload_async(rs_engine* e, const uint8_t* tiles_host, int n);
 int rs_engine_fetch_async(rs_engine* e, int n, rs_dets* out_host);
 int rs_engine_fetch_wait(rs_engine* e);
+/* The same two calls with the masks as crops: rs_engine_fetch_crops_async enqueues, on the copy stream behind the forward, the
+ * crop planning + compaction kernels and the copies of count / boxes / scores / classes (dets->masks and ->mask_probs are
+ * ignored) and of the crop table; rs_engine_fetch_crops_wait waits for them, then copies exactly `used` bytes of crop data
+ * and waits for that copy.  The engine's result buffers are free for the next forward after the first step. */
+int rs_engine_fetch_crops_async(rs_engine* e, int n, rs_dets* dets_host, rs_mask_crops* crops_host);
+int rs_engine_fetch_crops_wait(rs_engine* e, rs_mask_crops* crops_host);
 
 /* Stream the engine launches on (hipStream_t), for event timing by the caller. */
 void* rs_engine_stream(rs_engine* e);
@@ -167,6 +186,16 @@ int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, co
                  const void* upsample_add, int n, int hi, int wi, int cin, int in_halo, int kh, int kw,
                  int stride, int pad, int cout, int kpad, int out_halo, int relu, int out_f32, int deconv2x,
                  int variant, int use_glds, void* stream);
+
+/* Fused tail of an identity-shortcut bottleneck block of the 64-wide stage (csrc/bneck_fused.hip): t2 = relu(conv3x3(t1, w2) + b2),
+ * out = relu(w3 . t2 + b3 + x), and -- when w1p is given -- t1n = relu(w1 . out + b1), the next block's conv1, in one launch
+ * ([EXT d2: modeling/backbone/resnet.py BottleneckBlock.forward]).  All maps NHWC fp16 with a zero halo of 1: t1 / t1n
+ * [n][h+2][w+2][64], x / out [n][h+2][w+2][256].  w2 [64][576] (kh, kw, cin); w3p [256][64] and w1p [64][256] with their K columns
+ * in the register-chaining order (weights.py _perm_k64); biases fp32.  Projection-shortcut form (first block of the stage): x =
+ * NULL and instead x0 [n][h+2][w+2][64], the shortcut's input, with wsc [256][64] (natural K order); b3 then is conv3's plus the
+ * shortcut's bias: out = relu(w3 . t2 + wsc . x0 + b3). */
+int rs_op_bneck_tail(const void* t1, const void* w2, const float* b2, const void* w3p, const float* b3, const void* x, void* out,
+                     const void* w1p, const float* b1, void* t1n, const void* x0, const void* wsc, int n, int h, int w, void* stream);
 
 /* The tile variant launch_conv would pick for a conv / linear layer of this shape (no launch, no GPU needed): m = batch *
  * Ho * Wo output pixels, k x k taps over cin channels (+ cin2 channels of a second 1x1 K source, 0 = none), cout channels,
@@ -382,6 +411,9 @@ int rs_abi_version(void);
  * Python restatement with identical vertex output: proj_roadsurf_amd/vectorize.py. */
 typedef struct rs_vec_result rs_vec_result;
 rs_vec_result* rs_vectorize_masks(const uint8_t* masks, int n, int h, int w, double rdp_epsilon, int threads);
+/* The same for masks that arrive as crops (rs_mask_crops): rects [n][4], offsets [n] into data. */
+rs_vec_result* rs_vectorize_mask_crops(const uint8_t* data, const int32_t* rects, const uint32_t* offsets, int n, int h, int w,
+                                       double rdp_epsilon, int threads);
 void rs_vec_counts(const rs_vec_result* r, int64_t* n_instances, int64_t* n_polygons, int64_t* n_rings, int64_t* n_vertices);
 int rs_vec_copy(const rs_vec_result* r, int32_t* inst_poly_count, int32_t* poly_ring_count, int32_t* ring_len, double* xy);
 void rs_vec_free(rs_vec_result* r);

@@ -53,6 +53,7 @@ struct RsDebug {
   int narrow_roialign = 0;        // RS_NARROW_ROIALIGN
   int use_glds = 1;               // RS_USE_GLDS              0: register staging instead of LDS-DMA
   int fuse_shortcut = 1;          // RS_FUSE_SHORTCUT
+  int fuse_bneck = 1;             // RS_FUSE_BNECK            conv2 + conv3 + next conv1 of the res2 identity blocks in one launch
   int use_graph = 0;              // RS_USE_GRAPH
   int train_roi_side = -1;        // RS_TRAIN_ROI_SIDE        -1: trainer default
   int train_side = -1;            // RS_TRAIN_SIDE            -1: trainer default (on)
@@ -119,6 +120,26 @@ struct ConvParams {
 int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant /* -1 auto */, int use_glds);
 int conv_choose_variant(ConvParams& p, int force_variant, int use_glds);   // the dispatch rule (also sets p.stages / p.persist)
 extern thread_local int g_last_conv_variant;
+
+// ------------------------------------------------------------------ fused bottleneck tail (bneck_fused.hip)
+// conv2 (3x3 64->64) + conv3 (1x1 64->256, + residual + ReLU) [+ the next block's conv1 (1x1 256->64)] of an identity-shortcut
+// bottleneck block in one launch.  Every map is NHWC fp16 with a zero halo of 1 and the same H x W.
+struct BneckParams {
+  const half_t* t1;     // conv2 input  [N][H+2][W+2][64]
+  const half_t* w2;     // [64][576] (kh, kw, cin)
+  const float* b2;
+  const half_t* w3p;    // conv3 weight [256][64], K columns in the register-chaining order (weights.py _perm_k64)
+  const float* b3;
+  const half_t* x;      // block input = residual [N][H+2][W+2][256] (identity shortcut); nullptr with x0 / wsc
+  const half_t* x0;     // projection shortcut: its 64-channel input [N][H+2][W+2][64] at the same resolution (res2.0: the stem output)
+  const half_t* wsc;    //   and its weight [256][64], natural K order; b3 then holds conv3's + the shortcut's bias
+  half_t* out;          // block output            [N][H+2][W+2][256]
+  const half_t* w1p;    // next block's conv1 [64][256], K columns permuted per group of 64; nullptr = stop after conv3
+  const float* b1;
+  half_t* t1n;          // next block's conv1 output [N][H+2][W+2][64]
+  int M, H, W, Hp, Wp;  // M = N*H*W pixels
+};
+int launch_bneck_tail(const BneckParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------ training: weight gradient (conv_wgrad.hip)
 struct WgradParams {

@@ -121,6 +121,20 @@ struct PasteParams {
   float threshold;
 };
 
+// Detection masks cropped to their boxes for the host (the pasted mask is zero outside its box): per (image, slot) a byte-aligned
+// rectangle [x0b, x0b + wbytes) x [y0, y0 + rows) of the bit-packed canvas, stored back to back in (image, slot) order.
+struct CropParams {
+  const float* det_boxes;     // [n][D][4] tile pixels
+  const int* det_count;       // [n]
+  const uint8_t* masks;       // [n][D][h][Wb]
+  int n, D, h, w, Wb;
+  int* rects;                 // [n][D][4]: x0b, y0, wbytes, rows (zeros for empty slots)
+  unsigned int* offsets;      // [n][D]
+  unsigned long long* total;  // [1] bytes used
+  uint8_t* data;
+};
+int launch_mask_crops(const CropParams& p, hipStream_t s);
+
 int launch_rpn_select(const RpnParams& p, hipStream_t s);
 int launch_nms(const NmsParams& p, int segments, hipStream_t s);
 int launch_rpn_merge(const RpnMergeParams& p, int N, hipStream_t s);

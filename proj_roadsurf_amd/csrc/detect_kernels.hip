@@ -1175,9 +1175,82 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// mask crops for the host: plan (sizes + exclusive scan, one workgroup) and copy (one workgroup per slot)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void mask_crop_plan_kernel(const CropParams p) {
+  __shared__ unsigned int part[1024];
+  __shared__ unsigned long long base_sh;
+  const int tid = threadIdx.x;
+  const int E = p.n * p.D;
+  if (tid == 0) base_sh = 0ull;
+  __syncthreads();
+  for (int e0 = 0; e0 < E; e0 += 1024) {
+    const int e = e0 + tid;
+    unsigned int size = 0;
+    int x0b = 0, y0 = 0, wb = 0, rows = 0;
+    if (e < E) {
+      const int i = e / p.D, d = e - i * p.D;
+      if (d < p.det_count[i]) {
+        const float* b = p.det_boxes + (long long)e * 4;
+        // the pasted mask is zero at every pixel whose centre lies outside the box (grid_sample, zeros padding, >= 0.5 of a
+        // probability < 1); one pixel of margin covers the rounding of the sample coordinates
+        int xa = (int)floorf(fminf(b[0], b[2])) - 1, xz = (int)ceilf(fmaxf(b[0], b[2])) + 1;
+        int ya = (int)floorf(fminf(b[1], b[3])) - 1, yz = (int)ceilf(fmaxf(b[1], b[3])) + 1;
+        xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
+        xz = xz > p.w - 1 ? p.w - 1 : xz; yz = yz > p.h - 1 ? p.h - 1 : yz;
+        if (xz >= xa && yz >= ya) {
+          x0b = xa >> 3; wb = (xz >> 3) - x0b + 1; y0 = ya; rows = yz - ya + 1;
+          size = (unsigned int)(wb * rows);
+        }
+      }
+    }
+    part[tid] = size;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan (Hillis-Steele)
+      const unsigned int v = tid >= off ? part[tid - off] : 0u;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    const unsigned long long base = base_sh;
+    if (e < E) {
+      int* r = p.rects + (long long)e * 4;
+      r[0] = x0b; r[1] = y0; r[2] = wb; r[3] = rows;
+      p.offsets[e] = (unsigned int)(base + part[tid] - size);
+    }
+    __syncthreads();
+    if (tid == 1023) base_sh = base + part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) *p.total = base_sh;
+}
+
+__global__ __launch_bounds__(256) void mask_crop_copy_kernel(const CropParams p) {
+  const int e = blockIdx.x;
+  const int* r = p.rects + (long long)e * 4;
+  const int x0b = r[0], y0 = r[1], wb = r[2], rows = r[3];
+  const int total = wb * rows;
+  if (total == 0) return;
+  const uint8_t* src = p.masks + ((long long)e * p.h + y0) * p.Wb + x0b;
+  uint8_t* dst = p.data + p.offsets[e];
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int rr = idx / wb, c = idx - rr * wb;
+    dst[idx] = src[(long long)rr * p.Wb + c];
+  }
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------- launchers
+int launch_mask_crops(const CropParams& p, hipStream_t s) {
+  RS_CHECK(p.n > 0 && p.D > 0 && p.masks && p.rects && p.offsets && p.total && p.data, RS_ERR_ARG, "mask crops: bad argument");
+  hipLaunchKernelGGL(mask_crop_plan_kernel, dim3(1), dim3(1024), 0, s, p);
+  hipLaunchKernelGGL(mask_crop_copy_kernel, dim3(p.n * p.D), dim3(256), 0, s, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
 int launch_rpn_select(const RpnParams& p, hipStream_t s) {
   const int cap = p.cand_cap ? p.cand_cap : 1024;
   RS_CHECK((cap == 1024 || cap == 2048) && p.topk <= cap && p.A <= RS_MAX_ANCHORS && p.L <= RS_MAX_LEVELS, RS_ERR_UNSUPPORTED,

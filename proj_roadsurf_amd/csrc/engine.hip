@@ -29,7 +29,7 @@ void rs_debug_reload() {
   rd("RS_CONV_SINGLE_STAGE_NK", &d.conv_single_stage_nk); rd("RS_CONV_PERSIST", &d.conv_persist); rd("RS_CONV_TUNED", &d.conv_tuned);
   rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
   rd("RS_DECONV_VARIANT", &d.deconv_variant); rd("RS_FUSE_MASK_PREDICTOR", &d.fuse_mask_predictor); rd("RS_SIDE_STREAM", &d.side_stream);
-  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut);
+  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_FUSE_BNECK", &d.fuse_bneck);
   rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
   rd("RS_TRAIN_SIDE", &d.train_side); rd("RS_WGRAD_TARGET", &d.wgrad_target); rd("RS_WGRAD_CB", &d.wgrad_cb);
   rd("RS_SELECT_DEBUG", &d.select_debug); rd("RS_NMS_DEBUG", &d.nms_debug); rd("RS_ROI_WINDOW", &d.roi_window);
@@ -181,6 +181,13 @@ struct rs_engine {
   uint8_t* masks = nullptr;
   float* mask_probs = nullptr;
   int D = 0;
+  // mask crops for the host (rs_engine_fetch_crops_*): table + compacted data on the device, byte count read back pinned
+  int* crop_rects = nullptr;
+  unsigned int* crop_offsets = nullptr;
+  unsigned long long* crop_total = nullptr;
+  uint8_t* crop_data = nullptr;
+  unsigned long long* h_crop_total = nullptr;   // pinned
+  hipEvent_t ev_crop_hdr = nullptr;
 
   int alloc(void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -222,6 +229,7 @@ struct rs_engine {
   int assign_phases();
   int use_graph = 0;
   int fuse_shortcut = 1;
+  int fuse_bneck = 1;
   long long forward_index = 0;
   std::set<int> warmed;
   std::map<int, hipGraphExec_t> graphs;
@@ -413,6 +421,8 @@ int rs_engine::build() {
   // ---- res2..res5
   Act cur = c1;
   Act res_out[4];
+  Act t1_pre;              // conv1 output of the NEXT block when the previous block's fused tail already produced it
+  bool have_t1 = false;
   int bott = 64, cout = S.res2_out_channels;
   int ch = h4, cw = w4;
   for (int si = 0; si < 4; ++si) {
@@ -423,25 +433,67 @@ int rs_engine::build() {
       const int s1 = S.stride_in_1x1 ? stride : 1, s3 = S.stride_in_1x1 ? 1 : stride;
       const int oh = ch / stride, ow = cw / stride;
       Act t1, t2, sc, out;
-      if ((rc = new_act(&t1, nm + ".conv1", NB, ch / s1, cw / s1, bott, 1))) return rc;
-      if ((rc = new_act(&t2, nm + ".conv2", NB, oh, ow, bott, 1))) return rc;
+      // Fused tail (bneck_fused.hip): identity-shortcut blocks of the 64-wide stage run conv2 + conv3 (+ the next block's conv1)
+      // in one launch -- t2 is never materialised and the next conv1 reads `out` from registers.  fp16 inference engine only.
+      // Block 0 of the stage has a projection shortcut from the 64-channel stem output at the same resolution: the tail then adds
+      // Wsc . x0 as two more K steps instead of the identity residual (needs the folded conv3sc bias = conv3's + the shortcut's).
+      const bool tail0 = !f32 && fuse_bneck && fuse_shortcut && bi == 0 && bott == 64 && cout == 256 && stride == 1 && cur.C == 64 &&
+                         findw(wn + ".conv3p") != nullptr && findw(wn + ".shortcut") != nullptr && find(wn + ".conv3sc.b") != nullptr;
+      const bool tail = tail0 || (!f32 && fuse_bneck && bi > 0 && bott == 64 && cout == 256 && stride == 1 && findw(wn + ".conv3p") != nullptr);
+      const bool tail_next = tail && bi + 1 < S.res_blocks[si] &&
+                             findw(bu + "res" + std::to_string(si + 2) + "." + std::to_string(bi + 1) + ".conv1p") != nullptr;
+      if (have_t1) t1 = t1_pre;
+      else if ((rc = new_act(&t1, nm + ".conv1", NB, ch / s1, cw / s1, bott, 1))) return rc;
+      if (!tail) { if ((rc = new_act(&t2, nm + ".conv2", NB, oh, ow, bott, 1))) return rc; }
       if ((rc = new_act(&out, bi == S.res_blocks[si] - 1 ? "res" + std::to_string(si + 2) : nm + ".out", NB, oh, ow, cout, 1))) return rc;
       const Act* resid = &cur;
       // Projection shortcut: in the fp16 path it is folded into conv3 as a second K source (one GEMM over
       // [conv2 out ; block input], no shortcut tensor written or re-read); the fp32 validation path and
       // RS_FUSE_SHORTCUT=0 keep the reference's two-convolution form.
       const bool proj = cur.C != cout;
-      const bool fuse_sc = proj && !f32 && fuse_shortcut && s3 == 1 && cur.C % 64 == 0 && findw(wn + ".conv3sc") != nullptr;
-      if (proj && !fuse_sc) {
+      const bool fuse_sc = proj && !tail0 && !f32 && fuse_shortcut && s3 == 1 && cur.C % 64 == 0 && findw(wn + ".conv3sc") != nullptr;
+      if (proj && !fuse_sc && !tail0) {
         if ((rc = new_act(&sc, nm + ".shortcut", NB, oh, ow, cout, 1))) return rc;
         if ((rc = add_conv(nm + ".shortcut", wn + ".shortcut", cur, sc, 1, stride, 0, false, nullptr, nullptr, cur.C))) return rc;
         resid = &sc;
       }
-      if ((rc = add_conv(nm + ".conv1", wn + ".conv1", cur, t1, 1, s1, 0, true, nullptr, nullptr, cur.C))) return rc;
-      if ((rc = add_conv(nm + ".conv2", wn + ".conv2", t1, t2, 3, s3, 1, true, nullptr, nullptr, bott))) return rc;
-      if (fuse_sc) {
+      if (!have_t1) { if ((rc = add_conv(nm + ".conv1", wn + ".conv1", cur, t1, 1, s1, 0, true, nullptr, nullptr, cur.C))) return rc; }
+      have_t1 = false;
+      if (tail) {
+        const std::string nn = "res" + std::to_string(si + 2) + "." + std::to_string(bi + 1);
+        if (tail_next) { if ((rc = new_act(&t1_pre, nn + ".conv1", NB, oh, ow, bott, 1))) return rc; }
+        const BlobEntry *w2 = findw(wn + ".conv2"), *b2 = find(wn + ".conv2.b"), *w3 = findw(wn + ".conv3p"), *b3 = find(wn + (tail0 ? ".conv3sc.b" : ".conv3.b"));
+        const BlobEntry* wsc = tail0 ? findw(wn + ".shortcut") : nullptr;
+        const BlobEntry *w1 = tail_next ? findw(bu + nn + ".conv1p") : nullptr, *b1 = tail_next ? find(bu + nn + ".conv1.b") : nullptr;
+        RS_CHECK(w2 && b2 && w3 && b3 && (!tail_next || (w1 && b1)), RS_ERR_BLOB, "weights of the fused tail of %s missing", nm.c_str());
+        RS_CHECK(w2->dims[0] == 64 && w2->dims[1] == 576 && w3->dims[0] == 256 && w3->dims[1] == 64 && (!w1 || (w1->dims[0] == 64 && w1->dims[1] == 256)),
+                 RS_ERR_BLOB, "fused tail of %s: weight shapes", nm.c_str());
+        BneckParams bp;
+        memset(&bp, 0, sizeof bp);
+        bp.t1 = t1.p; bp.w2 = (const half_t*)w2->dev; bp.b2 = (const float*)b2->dev; bp.w3p = (const half_t*)w3->dev; bp.b3 = (const float*)b3->dev;
+        bp.out = out.p;
+        if (tail0) {
+          RS_CHECK(wsc && wsc->dims[0] == 256 && wsc->dims[1] == 64, RS_ERR_BLOB, "fused tail of %s: shortcut weight shape", nm.c_str());
+          bp.x0 = cur.p; bp.wsc = (const half_t*)wsc->dev;
+        } else {
+          bp.x = cur.p;
+        }
+        if (tail_next) { bp.w1p = (const half_t*)w1->dev; bp.b1 = (const float*)b1->dev; bp.t1n = t1_pre.p; }
+        bp.H = oh; bp.W = ow; bp.Hp = out.Hp(); bp.Wp = out.Wp();
+        RS_CHECK(t1.pad == 1 && cur.pad == 1 && out.pad == 1 && t1.H == oh && cur.H == oh && t1.C == 64 && cur.C == (tail0 ? 64 : 256), RS_ERR_ARG, "fused tail of %s: geometry", nm.c_str());
+        const int mpi = oh * ow;
+        Stage st;
+        st.name = nm + (tail_next ? ".conv2+conv3+next.conv1" : ".conv2+conv3");
+        st.flops_per_image = 2.0 * mpi * (576.0 * 64 + 64.0 * 256 + (tail0 ? 64.0 * 256 : 0.0) + (tail_next ? 256.0 * 64 : 0.0));
+        st.bytes_per_image = 2.0 * mpi * (64.0 + (tail0 ? 64.0 : 256.0) + 256 + (tail_next ? 64.0 : 0.0));       // t1 + x (or x0) in, out (+ t1n) out
+        st.fn = [bp, mpi](int n, hipStream_t s) mutable { bp.M = n * mpi; g_last_conv_variant = 13; return launch_bneck_tail(bp, s); };
+        stages.push_back(st);
+        have_t1 = tail_next;
+      } else if (fuse_sc) {
+        if ((rc = add_conv(nm + ".conv2", wn + ".conv2", t1, t2, 3, s3, 1, true, nullptr, nullptr, bott))) return rc;
         if ((rc = add_conv(nm + ".conv3", wn + ".conv3sc", t2, out, 1, 1, 0, true, nullptr, nullptr, bott, 1, nullptr, &cur, stride))) return rc;
       } else {
+        if ((rc = add_conv(nm + ".conv2", wn + ".conv2", t1, t2, 3, s3, 1, true, nullptr, nullptr, bott))) return rc;
         if ((rc = add_conv(nm + ".conv3", wn + ".conv3", t2, out, 1, 1, 0, true, resid, nullptr, bott))) return rc;
       }
       cur = out;
@@ -799,6 +851,10 @@ int rs_engine::build() {
     const int Wb = (tile_w + 7) / 8;
     if ((rc = alloc((void**)&masks, (size_t)R * tile_h * Wb))) return rc;
     reg("masks", masks, DT_U8, {NB, D, tile_h, Wb}, 0);
+    if ((rc = alloc((void**)&crop_data, (size_t)R * tile_h * Wb))) return rc;
+    if ((rc = alloc((void**)&crop_rects, (size_t)R * 16))) return rc;
+    if ((rc = alloc((void**)&crop_offsets, (size_t)R * 4))) return rc;
+    if ((rc = alloc((void**)&crop_total, 16))) return rc;
     {
       PasteParams pm;
       pm.probs = mask_probs; pm.det_boxes = det_boxes; pm.slot_list = slot_list; pm.n_entries = det_total; pm.out = masks;
@@ -983,7 +1039,8 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   e->f32 = spec->precision == 1;
   if (e->f32) e->use_glds = -1;
   e->fuse_shortcut = rs_debug().fuse_shortcut;
-  if (g_trainer_unfused_shortcut) e->fuse_shortcut = 0;   // the training engine differentiates conv3 and the shortcut separately
+  e->fuse_bneck = rs_debug().fuse_bneck;
+  if (g_trainer_unfused_shortcut) { e->fuse_shortcut = 0; e->fuse_bneck = 0; }   // the training engine differentiates every convolution separately and needs every layer output
   e->use_graph = rs_debug().use_graph;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
   else {
@@ -1007,6 +1064,8 @@ void rs_engine_destroy(rs_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->narrow) { (void)hipStreamSynchronize(e->narrow); (void)hipStreamDestroy(e->narrow); }
   if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+  if (e->ev_crop_hdr) (void)hipEventDestroy(e->ev_crop_hdr);
+  if (e->h_crop_total) (void)hipHostFree(e->h_crop_total);
   if (e->ev_results) (void)hipEventDestroy(e->ev_results);
   if (e->ev_copied) (void)hipEventDestroy(e->ev_copied);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -1098,6 +1157,51 @@ int rs_engine_fetch_async(rs_engine* e, int n, rs_dets* o) {
   return RS_OK;
 }
 
+int rs_engine_fetch_crops_async(rs_engine* e, int n, rs_dets* o, rs_mask_crops* c) {
+  RS_CHECK(e && o && o->count && c && c->rects && c->offsets && c->data && n >= 1 && n <= e->max_batch, RS_ERR_ARG, "bad argument");
+  RS_CHECK(e->masks && e->crop_data, RS_ERR_ARG, "mask crops requested but MASK_ON is false");
+  if (!e->copy_stream) {
+    RS_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    RS_HIP(hipEventCreateWithFlags(&e->ev_results, hipEventDisableTiming));
+    RS_HIP(hipEventCreateWithFlags(&e->ev_copied, hipEventDisableTiming));
+  }
+  if (!e->ev_crop_hdr) {
+    RS_HIP(hipEventCreateWithFlags(&e->ev_crop_hdr, hipEventDisableTiming));
+    RS_HIP(hipHostMalloc((void**)&e->h_crop_total, 16, hipHostMallocDefault));
+  }
+  const int D = e->D;
+  hipStream_t s = e->copy_stream;
+  RS_HIP(hipEventRecord(e->ev_results, e->stream));
+  RS_HIP(hipStreamWaitEvent(s, e->ev_results, 0));
+  CropParams cp;
+  memset(&cp, 0, sizeof cp);
+  cp.det_boxes = e->det_boxes; cp.det_count = e->det_count; cp.masks = e->masks; cp.n = n; cp.D = D; cp.h = e->tile_h; cp.w = e->tile_w;
+  cp.Wb = (e->tile_w + 7) / 8; cp.rects = e->crop_rects; cp.offsets = e->crop_offsets; cp.total = e->crop_total; cp.data = e->crop_data;
+  { int rc = launch_mask_crops(cp, s); if (rc) return rc; }
+  RS_HIP(hipMemcpyAsync(o->count, e->det_count, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  if (o->boxes) RS_HIP(hipMemcpyAsync(o->boxes, e->det_boxes, (size_t)n * D * 16, hipMemcpyDeviceToHost, s));
+  if (o->scores) RS_HIP(hipMemcpyAsync(o->scores, e->det_scores, (size_t)n * D * 4, hipMemcpyDeviceToHost, s));
+  if (o->classes) RS_HIP(hipMemcpyAsync(o->classes, e->det_classes, (size_t)n * D * 4, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpyAsync(c->rects, e->crop_rects, (size_t)n * D * 16, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpyAsync(c->offsets, e->crop_offsets, (size_t)n * D * 4, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpyAsync(e->h_crop_total, e->crop_total, 8, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipEventRecord(e->ev_copied, s));       // detections and canvases are free for the next forward: the crops live in their own buffer
+  RS_HIP(hipEventRecord(e->ev_crop_hdr, s));
+  e->copy_pending = true;
+  return RS_OK;
+}
+
+int rs_engine_fetch_crops_wait(rs_engine* e, rs_mask_crops* c) {
+  RS_CHECK(e && c && c->data && e->ev_crop_hdr, RS_ERR_ARG, "rs_engine_fetch_crops_wait without rs_engine_fetch_crops_async");
+  RS_HIP(hipEventSynchronize(e->ev_crop_hdr));
+  const unsigned long long used = *e->h_crop_total;
+  RS_CHECK(used <= c->capacity, RS_ERR_ARG, "mask crops need %llu bytes, the caller's buffer holds %llu", used, (unsigned long long)c->capacity);
+  c->used = used;
+  if (used) RS_HIP(hipMemcpyAsync(c->data, e->crop_data, (size_t)used, hipMemcpyDeviceToHost, e->copy_stream));
+  RS_HIP(hipStreamSynchronize(e->copy_stream));
+  return RS_OK;
+}
+
 int rs_engine_fetch_wait(rs_engine* e) {
   RS_CHECK(e, RS_ERR_ARG, "null engine");
   if (e->copy_stream) RS_HIP(hipStreamSynchronize(e->copy_stream));
@@ -1156,9 +1260,10 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
                                 "(retired)",
                                 "conv_igemm_kernel<2,2,4,2> 64x128", "conv_igemm_kernel<4,1,4,2> 128x64", "conv_igemm_kernel<2,2,4,1> 32x128",
                                 "conv_igemm_kernel<2,4,4,2> 64x256", "(retired)",
-                                "conv_deep_kernel 256x256 (3 activation + 2 weight LDS stages)"};
+                                "conv_deep_kernel 256x256 (3 activation + 2 weight LDS stages)",
+                                "bneck_tail_kernel 256 px (conv2 + conv3 + next conv1 chained through registers)"};
   const int v = e->stages[i].variant;
-  const char* s = v == -1 ? "conv_f32_kernel" : (v >= 0 && v <= 12 ? names[v] : "");
+  const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 13 ? names[v] : "");
   strncpy(name_out, s, 95);
   name_out[95] = 0;
   return RS_OK;
@@ -1273,6 +1378,17 @@ int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const floa
   RS_CHECK(in2, RS_ERR_ARG, "null argument");
   return op_conv2d(in, w, bias, out, nullptr, nullptr, n, hi, wi, cin, in_halo, kh, kw, stride, pad, cout, kpad, out_halo,
                    relu, 0, 0, variant, 1, stream, in2, h2, w2, cin2, in2_halo, stride2);
+}
+
+int rs_op_bneck_tail(const void* t1, const void* w2, const float* b2, const void* w3p, const float* b3, const void* x, void* out,
+                     const void* w1p, const float* b1, void* t1n, const void* x0, const void* wsc, int n, int h, int w, void* stream) {
+  RS_CHECK(t1 && w2 && b2 && w3p && b3 && out && n > 0 && h > 0 && w > 0, RS_ERR_ARG, "bad argument");
+  BneckParams p;
+  memset(&p, 0, sizeof p);
+  p.t1 = (const half_t*)t1; p.w2 = (const half_t*)w2; p.b2 = b2; p.w3p = (const half_t*)w3p; p.b3 = b3; p.x = (const half_t*)x; p.out = (half_t*)out;
+  p.w1p = (const half_t*)w1p; p.b1 = b1; p.t1n = (half_t*)t1n; p.x0 = (const half_t*)x0; p.wsc = (const half_t*)wsc;
+  p.M = n * h * w; p.H = h; p.W = w; p.Hp = h + 2; p.Wp = w + 2;
+  return launch_bneck_tail(p, (hipStream_t)stream);
 }
 
 int rs_op_conv2d_dgrad(const void* dy, const void* w_t, void* dx, const void* res, const float* res32, const void* mask,

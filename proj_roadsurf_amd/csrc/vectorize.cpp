@@ -195,9 +195,15 @@ void trace_rings(const uint8_t* m, int wb, int h, int w, std::vector<Ring>& ring
   }
 }
 
-void vectorize_one(const uint8_t* m, int wb, int h, int w, double eps, InstOut& o) {
+// (ox, oy): position of the image `m` inside its tile -- a crop's first pixel column / row; vertices are reported in tile
+// coordinates.  Ring discovery order, start vertices and RDP depend on differences of integer coordinates only, so tracing a
+// crop gives exactly the vertices of tracing the full canvas.
+void vectorize_one(const uint8_t* m, int wb, int h, int w, double eps, InstOut& o, int ox = 0, int oy = 0) {
   std::vector<Ring> rings;
   trace_rings(m, wb, h, w, rings);
+  if (ox || oy)
+    for (Ring& r : rings)
+      for (Pt& q : r) { q.x += ox; q.y += oy; }
   std::vector<double> area(rings.size());
   std::vector<int> ext;                               // ring indices of exteriors, in order
   for (size_t i = 0; i < rings.size(); ++i) { area[i] = ring_area(rings[i]); if (area[i] > 0) ext.push_back((int)i); }
@@ -256,6 +262,41 @@ rs_vec_result* rs_vectorize_masks(const uint8_t* masks, int n, int h, int w, dou
   if (nt > n) nt = n > 0 ? n : 1;
   auto work = [&](int t) {
     for (int i = t; i < n; i += nt) vectorize_one(masks + (size_t)i * h * wb, wb, h, w, rdp_epsilon, per[i]);
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
+  }
+  rs_vec_result* r = new rs_vec_result();
+  for (int i = 0; i < n; ++i) {
+    r->inst_poly_count.push_back((int32_t)per[i].poly_ring_count.size());
+    r->poly_ring_count.insert(r->poly_ring_count.end(), per[i].poly_ring_count.begin(), per[i].poly_ring_count.end());
+    r->ring_len.insert(r->ring_len.end(), per[i].ring_len.begin(), per[i].ring_len.end());
+    r->xy.insert(r->xy.end(), per[i].xy.begin(), per[i].xy.end());
+  }
+  return r;
+}
+
+// Masks as crops (rs_mask_crops, include/rs_engine.h): crop i = rows [rects[i][1], +rects[i][3]) x byte columns [rects[i][0],
+// +rects[i][2]) of the h x w canvas, stored at data + offsets[i].  Same polygons, vertex for vertex, as rs_vectorize_masks on the
+// full canvases.
+rs_vec_result* rs_vectorize_mask_crops(const uint8_t* data, const int32_t* rects, const uint32_t* offsets, int n, int h, int w,
+                                       double rdp_epsilon, int threads) {
+  if (n < 0 || h <= 0 || w <= 0 || (n > 0 && (!data || !rects || !offsets))) return nullptr;
+  std::vector<InstOut> per(n);
+  int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  if (nt < 1) nt = 1;
+  if (nt > n) nt = n > 0 ? n : 1;
+  auto work = [&](int t) {
+    for (int i = t; i < n; i += nt) {
+      const int x0b = rects[i * 4], y0 = rects[i * 4 + 1], wb = rects[i * 4 + 2], rows = rects[i * 4 + 3];
+      if (wb <= 0 || rows <= 0) continue;
+      int cw = wb * 8;
+      if (x0b * 8 + cw > w) cw = w - x0b * 8;          // the canvas' last byte may be partial
+      vectorize_one(data + offsets[i], wb, rows, cw, rdp_epsilon, per[i], x0b * 8, y0);
+    }
   };
   if (nt == 1) work(0);
   else {

@@ -18,7 +18,8 @@ from .spec import EngineSpec
 from .weights import pack_weights
 
 _LIB: Optional[C.CDLL] = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librs_engine.so")
+# RS_ENGINE_LIB: another build of the library (diagnostic builds of tools/ubench: ablations, clock probes); default = the in-tree one
+LIB_PATH = os.environ.get("RS_ENGINE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librs_engine.so")
 MAX_LEVELS, MAX_ANCHORS, MASK_SIDE = 5, 8, 28
 DT_NP = {1: np.float16, 2: np.float32, 3: np.int32, 4: np.uint8}
 
@@ -52,12 +53,25 @@ class RsDets(C.Structure):
                 ("classes", C.POINTER(C.c_int32)), ("masks", C.POINTER(C.c_uint8)), ("mask_probs", C.POINTER(C.c_float))]
 
 
+class RsMaskCrops(C.Structure):
+    _fields_ = [("rects", C.POINTER(C.c_int32)), ("offsets", C.POINTER(C.c_uint32)), ("data", C.POINTER(C.c_uint8)),
+                ("capacity", C.c_uint64), ("used", C.c_uint64)]
+
+
 def load_library(path: Optional[str] = None) -> C.CDLL:
     """Load librs_engine.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
     p = path or LIB_PATH
+    try:
+        # PyTorch-ROCm wheels bundle their own libamdhip64; librs_engine.so links the system one (/opt/rocm).  If ours is loaded
+        # first and torch later initialises the GPU through its copy, the second HIP runtime of the process reports "no
+        # ROCm-capable device".  Importing torch first (when it is installed -- tests, bench.py and the data-parallel trainer use it)
+        # lets both bind to ONE runtime; the engine itself never calls into torch.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise RsError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc, gfx950). There is no CPU fallback for the detection path.")
@@ -79,6 +93,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_upload_async.argtypes = [vp, vp, i32]
     lib.rs_engine_fetch_async.argtypes = [vp, i32, C.POINTER(RsDets)]
     lib.rs_engine_fetch_wait.argtypes = [vp]
+    lib.rs_engine_fetch_crops_async.argtypes = [vp, i32, C.POINTER(RsDets), C.POINTER(RsMaskCrops)]
+    lib.rs_engine_fetch_crops_wait.argtypes = [vp, C.POINTER(RsMaskCrops)]
     lib.rs_engine_fetch.argtypes = [vp, i32, C.POINTER(RsDets)]
     lib.rs_engine_stream.argtypes = [vp]
     lib.rs_engine_stream.restype = vp
@@ -93,6 +109,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_tensor_name.argtypes = [vp, i32, C.c_char_p]
     lib.rs_engine_net_shape.argtypes = [vp, i32p, i32p, i32p, i32p]
     lib.rs_op_conv2d.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 17 + [vp]
+    lib.rs_op_bneck_tail.argtypes = [vp] * 12 + [i32, i32, i32, vp]
     lib.rs_op_conv2d_dual.argtypes = [vp, vp, vp, vp, vp] + [i32] * 19 + [vp]
     lib.rs_op_conv2d_dgrad.argtypes = [vp] * 7 + [i32] * 14 + [vp]
     lib.rs_op_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i32] * 13 + [vp]
@@ -193,19 +210,38 @@ class Instances:
     ``pred_classes``, ``pred_masks`` (n,H,W bool).  Sorted by score, descending."""
 
     def __init__(self, image_size: Tuple[int, int], pred_boxes: np.ndarray, scores: np.ndarray, pred_classes: np.ndarray,
-                 packed_masks: Optional[np.ndarray], mask_probs: Optional[np.ndarray]):
+                 packed_masks: Optional[np.ndarray], mask_probs: Optional[np.ndarray],
+                 crops: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None):
         self.image_size = image_size
         self.pred_boxes = pred_boxes
         self.scores = scores
         self.pred_classes = pred_classes
-        self._packed = packed_masks
+        self._packed_full = packed_masks
         self.mask_probs = mask_probs
+        # masks as crops of their boxes (rs_mask_crops): (rects (n,4) int32 [first byte column, first row, bytes per row, rows],
+        # offsets (n,) uint32 into data, data uint8); the full canvases are rebuilt on demand
+        self._crops = crops
+
+    @property
+    def _packed(self) -> Optional[np.ndarray]:
+        """Bit-packed full-canvas masks (n, h, ceil(w/8)); rebuilt from the crops when the masks arrived cropped."""
+        if self._packed_full is None and self._crops is not None:
+            h, w = self.image_size
+            rects, offs, data = self._crops
+            full = np.zeros((len(self), h, (w + 7) // 8), np.uint8)
+            for i in range(len(self)):
+                x0b, y0, wb, rows = (int(v) for v in rects[i])
+                if wb > 0 and rows > 0:
+                    o = int(offs[i])
+                    full[i, y0:y0 + rows, x0b:x0b + wb] = data[o:o + wb * rows].reshape(rows, wb)
+            self._packed_full = full
+        return self._packed_full
 
     def __len__(self) -> int:
         return int(self.scores.shape[0])
 
     def has(self, name: str) -> bool:
-        return name in ("pred_boxes", "scores", "pred_classes") or (name == "pred_masks" and self._packed is not None)
+        return name in ("pred_boxes", "scores", "pred_classes") or (name == "pred_masks" and (self._packed_full is not None or self._crops is not None))
 
     @property
     def pred_masks(self) -> np.ndarray:
@@ -222,7 +258,7 @@ class Instances:
 
     def get_fields(self) -> Dict[str, Any]:
         d = {"pred_boxes": self.pred_boxes, "scores": self.scores, "pred_classes": self.pred_classes}
-        if self._packed is not None:
+        if self.has("pred_masks"):
             d["pred_masks"] = self.pred_masks
         return d
 
@@ -284,6 +320,12 @@ class Engine:
         self._masks = self._pinned((n, D, h, wb), np.uint8) if self.spec.mask_on else None
         self._probs = np.zeros((n, D, MASK_SIDE, MASK_SIDE), np.float32) if self.spec.mask_on else None
         self._stage_tiles = self._pinned((n, self.tile_h, self.tile_w, self.tile_c), np.uint8)
+        # masks as crops (rs_engine_fetch_crops_*): table + data; the data buffer is pinned lazily on first use
+        self._crop_rects = self._pinned((n, D, 4), np.int32) if self.spec.mask_on else None
+        self._crop_offsets = self._pinned((n, D), np.uint32) if self.spec.mask_on else None
+        self._crop_data: Optional[np.ndarray] = None
+        self._crops_struct: Optional[RsMaskCrops] = None
+        self._crops_pending = False
 
     def _dets_struct(self, want_probs: bool) -> RsDets:
         d = RsDets()
@@ -297,8 +339,23 @@ class Engine:
                 d.mask_probs = self._probs.ctypes.data_as(C.POINTER(C.c_float))
         return d
 
-    def _collect(self, n: int, want_probs: bool) -> List[Instances]:
+    def _collect(self, n: int, want_probs: bool, crops: bool = False) -> List[Instances]:
         out = []
+        if crops:
+            for i in range(n):
+                c = int(self._count[i])
+                rects = self._crop_rects[i, :c].copy()
+                offs = self._crop_offsets[i, :c].astype(np.int64)
+                if c:
+                    lo = int(offs[0])
+                    hi = int(offs[c - 1]) + int(rects[c - 1, 2]) * int(rects[c - 1, 3])
+                    data = self._crop_data[lo:hi].copy()          # the tile's crops are contiguous, in slot order
+                    offs = (offs - lo).astype(np.uint32)
+                else:
+                    data, offs = np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+                out.append(Instances((self.tile_h, self.tile_w), self._boxes[i, :c].copy(), self._scores[i, :c].copy(),
+                                     self._classes[i, :c].astype(np.int64), None, None, crops=(rects, offs, data)))
+            return out
         for i in range(n):
             c = int(self._count[i])
             out.append(Instances((self.tile_h, self.tile_w), self._boxes[i, :c].copy(), self._scores[i, :c].copy(),
@@ -331,13 +388,43 @@ class Engine:
         _check(self.lib, self.lib.rs_engine_upload_async(self._h, self._stage_tiles.ctypes.data_as(C.c_void_p), n), "rs_engine_upload_async")
         return self.tensor_ptr("tiles")[0]
 
-    def fetch_async(self, n: int) -> None:
+    def fetch_async(self, n: int, crops: bool = True) -> None:
+        """Enqueue the copy of the last forward's results to the host behind it.  ``crops`` (default, with MASK_ON): the masks
+        travel as crops of their boxes (``rs_mask_crops``) instead of full canvases -- 100 x h x w/8 bytes per tile shrink to
+        the boxes' area, on the PCIe link and in the host-side copies."""
         d = self._dets_struct(False)
+        if crops and self._masks is not None:
+            if self._crop_data is None:
+                self._crop_data = self._pinned((self.max_batch * self.D * self.tile_h * ((self.tile_w + 7) // 8),), np.uint8)
+                c = RsMaskCrops()
+                c.rects = self._crop_rects.ctypes.data_as(C.POINTER(C.c_int32))
+                c.offsets = self._crop_offsets.ctypes.data_as(C.POINTER(C.c_uint32))
+                c.data = self._crop_data.ctypes.data_as(C.POINTER(C.c_uint8))
+                c.capacity = self._crop_data.nbytes
+                self._crops_struct = c
+            d.masks = None
+            _check(self.lib, self.lib.rs_engine_fetch_crops_async(self._h, n, C.byref(d), C.byref(self._crops_struct)), "rs_engine_fetch_crops_async")
+            self._crops_pending = True
+            return
         _check(self.lib, self.lib.rs_engine_fetch_async(self._h, n, C.byref(d)), "rs_engine_fetch_async")
 
+    def wait_results(self) -> None:
+        """Block until the copies of the last ``fetch_async`` have landed (for crops: wait for the crop table, copy exactly the
+        bytes in use, wait for them)."""
+        if self._crops_pending:
+            _check(self.lib, self.lib.rs_engine_fetch_crops_wait(self._h, C.byref(self._crops_struct)), "rs_engine_fetch_crops_wait")
+            self._crops_pending, self._crops_landed = False, True
+        else:
+            _check(self.lib, self.lib.rs_engine_fetch_wait(self._h), "rs_engine_fetch_wait")
+            self._crops_landed = False
+
+    def collect_results(self, n: int) -> List[Instances]:
+        """``Instances`` of the results ``wait_results`` waited for (copies out of the pinned buffers)."""
+        return self._collect(n, False, crops=getattr(self, "_crops_landed", False))
+
     def fetch_wait(self, n: int) -> List[Instances]:
-        _check(self.lib, self.lib.rs_engine_fetch_wait(self._h), "rs_engine_fetch_wait")
-        return self._collect(n, False)
+        self.wait_results()
+        return self.collect_results(n)
 
     def infer_device(self, tiles_dev_ptr: int, n: int) -> None:
         """Enqueue a forward on tiles already in device memory (no wait)."""
@@ -433,7 +520,8 @@ class Engine:
             if not getattr(self, "_borrowed", False):
                 self.lib.rs_engine_destroy(self._h)
             self._h = None
-            for name in ("_count", "_boxes", "_scores", "_classes", "_masks", "_stage_tiles"):
+            self._crops_struct = None
+            for name in ("_count", "_boxes", "_scores", "_classes", "_masks", "_stage_tiles", "_crop_rects", "_crop_offsets", "_crop_data"):
                 setattr(self, name, None)             # views over the pinned memory freed below
             for p in getattr(self, "_pinned_ptrs", []):
                 self.lib.rs_host_free(p)
@@ -517,7 +605,7 @@ class LanePipeline:
                 # this lane's previous batch: its result copy was enqueued one submit ago; once it has landed the lane's pinned
                 # staging buffer (upload) is free again.  The other lane's batch keeps the GPU busy meanwhile.
                 ol, on = inflight.pop(0)
-                _check(self.engines[ol].lib, self.engines[ol].lib.rs_engine_fetch_wait(self.engines[ol]._h), "rs_engine_fetch_wait")
+                self.engines[ol].wait_results()
                 done = (ol, on)
             ptr = e.upload_async(np.ascontiguousarray(tiles))
             e.infer_phase(ptr, n, 0)
@@ -530,7 +618,7 @@ class LanePipeline:
             self._pending = (lane, ptr, n)
             inflight.append((lane, n))
             if done is not None:                    # host-side collection overlaps the batches just enqueued; this lane's next
-                yield self.engines[done[0]]._collect(done[1], False)      # fetch_async comes one submit later
+                yield self.engines[done[0]].collect_results(done[1])      # fetch_async comes one submit later
         if self._pending is not None:
             pl, pp, pn = self._pending
             self.engines[pl].infer_phase(pp, pn, 2)
@@ -584,6 +672,38 @@ class Predictor:
                 out.extend({"instances": r} for r in res)
             i = j
         return out
+
+    def predict_stream(self, batches) -> "Iterator[List[Dict[str, Instances]]]":
+        """Streaming form for a whole tileset: ``batches`` is an iterator of image lists (each at most ``max_batch`` images);
+        yields one result list per batch, in order.  Consecutive batches of one tile shape flow through ONE
+        ``LanePipeline.run`` generator, so the upload, forward and result copy of batch k+1 overlap batch k (calling
+        ``predict_batch`` once per batch would drain the pipeline after every batch).  The iterator is pulled lazily, two
+        batches ahead of what is yielded."""
+        it = iter(batches)
+        carry: List[Any] = []            # a batch read ahead that does not fit the running pipeline
+
+        def next_batch():
+            return carry.pop() if carry else next(it, None)
+
+        while True:
+            first = next_batch()
+            if first is None:
+                return
+            shapes = {tuple(im.shape) for im in first}
+            if len(shapes) != 1 or len(first) > self.max_batch:
+                yield self.predict_batch(first)          # mixed shapes inside one batch: no streaming for it
+                continue
+            shape = shapes.pop()
+
+            def run_of_shape(b=first):
+                while b is not None:
+                    if len(b) > self.max_batch or any(tuple(im.shape) != shape for im in b):
+                        carry.append(b)
+                        return
+                    yield np.stack(b)
+                    b = next_batch()
+            for res in self._pipe(shape).run(run_of_shape()):
+                yield [{"instances": r} for r in res]
 
     def close(self) -> None:
         for p in self._pipes.values():
@@ -805,7 +925,7 @@ class Trainer:
         self.sync()
         _check(self.lib, self.lib.rs_memcpy_h2d(C.c_void_p(int(self.lib.rs_trainer_grad_buffer(self._h))), g.ctypes.data_as(C.c_void_p), g.nbytes), "rs_memcpy_h2d")
 
-    def allreduce_gradients(self) -> None:
+    def allreduce_gradients(self, force: bool = False) -> None:
         """DistributedDataParallel's gradient averaging: SUM every gradient bucket over the ranks of the default process group
         and set the divisor the SGD step applies.  Buckets are reduced in the order the step completes them (heads, FPN,
         res5, res4, res3 -- ``buckets()``), each behind its own completion events:
@@ -821,8 +941,8 @@ class Trainer:
         losses back) and before ``apply_sgd``."""
         import torch
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
+            return                      # ``force``: run the collectives even in a one-rank group (exercises the RCCL path on one GPU)
         ptr = int(self.lib.rs_trainer_grad_buffer(self._h))
         if dist.get_backend() == "nccl":
             cur = torch.cuda.current_stream()

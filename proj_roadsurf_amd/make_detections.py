@@ -132,14 +132,34 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank)
 
     # decode (PIL), GPU forward and vectorisation (C++, rs_vectorize_masks) overlap across batches (shard.run_sharded)
+    busy = {"decode": 0.0, "predict": 0.0, "vectorise": 0.0}      # seconds summed over the threads that ran each stage
+
     def prepare(entries: Sequence[dict]) -> List[Any]:
-        return [read_tile(e["file_name"]) for e in entries]
+        t = time.perf_counter()
+        out = [read_tile(e["file_name"]) for e in entries]
+        busy["decode"] += time.perf_counter() - t
+        return out
 
     def predict_batch(ims: Sequence[Any]) -> List[Any]:
-        return predictor.predict_batch(ims)
+        t = time.perf_counter()
+        out = predictor.predict_batch(ims)
+        busy["predict"] += time.perf_counter() - t
+        return out
+
+    def predict_stream(batches):
+        # the whole dataset through one lane pipeline: batch k+1 uploads and runs while batch k's results come back
+        it = predictor.predict_stream(batches)
+        while True:
+            t = time.perf_counter()
+            out = next(it, None)
+            busy["predict"] += time.perf_counter() - t
+            if out is None:
+                return
+            yield out
 
     def finish(entries: Sequence[dict], outs: List[Any]) -> List[Any]:
         # per tile: (GeoPackage rows, bbox[, GeoJSON features]) -- masks -> polygons -> RDP -> georeferenced blobs in C++
+        t_fin = time.perf_counter()
         res = []
         for e, o in zip(entries, outs):
             ext, epsg_t = tile_extent(meta, e["file_name"])
@@ -148,6 +168,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             rows, bbox = instances_to_gpkg_rows(o["instances"], name, ext, rdp_on, eps, srs_id=cur_srs["id"], threads=args.vector_threads)
             feats = instances_to_features(o["instances"], name, ext, rdp_on, eps, threads=args.vector_threads) if args.geojson else None
             res.append((rows, bbox, feats))
+        busy["vectorise"] += time.perf_counter() - t_fin
         return res
 
     cur_srs = {"id": -1}
@@ -163,14 +184,16 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 break
         cur_srs["id"] = int(epsg) if epsg else -1
         per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
-                               workers=args.host_workers)
+                               workers=args.host_workers, predict_stream=predict_stream)
         if rank != 0:
             continue
         base = f"{dataset}_detections_at_{thr_tag(thr)}_threshold"
+        t_w = time.time()
         gw = GpkgWriter(base + ".gpkg", table=base, epsg=epsg)
         for rows, bbox, _ in per_tile:
             gw.add_rows(rows, bbox)
         n = gw.close()
+        dt_write = time.time() - t_w
         if args.geojson:
             feats = [f for _, _, fs in per_tile for f in fs]
             with open(base + ".geojson", "w") as f:
@@ -178,6 +201,9 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         dt = time.time() - t0
         log.info("%s: %d tiles -> %d features in %.1f s (%.1f tiles/s) -> %s.gpkg", dataset, len(images), n, dt,
                  len(images) / max(dt, 1e-9), base)
+        log.info("%s: stage busy time (summed over threads) decode %.2f s, predict %.2f s, vectorise %.2f s, write %.2f s",
+                 dataset, busy["decode"], busy["predict"], busy["vectorise"], dt_write)
+        busy.update({k: 0.0 for k in busy})
         sub = cfg.get("sample_tagged_img_subfolder")
         if sub and args.tagged_samples > 0:
             # the reference tags the first images of every dataset with their predictions (R:config/config_obj_detec.yaml:77)

@@ -23,14 +23,19 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 def run_sharded(items: Sequence[Any], predict_batch: Callable[[Sequence[Any]], List[Any]], batch: int,
                 rank: int = 0, world: int = 1, gather: bool = True,
                 prepare: Optional[Callable[[Sequence[Any]], Any]] = None,
-                finish: Optional[Callable[[Sequence[Any], Any], List[Any]]] = None, workers: int = 4) -> Optional[List[Any]]:
+                finish: Optional[Callable[[Sequence[Any], Any], List[Any]]] = None, workers: int = 4,
+                predict_stream: Optional[Callable[[Any], Any]] = None) -> Optional[List[Any]]:
     """Run ``predict_batch`` over this rank's block in batches of ``batch``; with ``gather`` the
     per-item results of all ranks are returned on rank 0 in the original item order (None elsewhere).
 
     Three-stage form (``prepare`` and/or ``finish`` given): ``prepare(batch_items)`` (tile decode) and
     ``finish(batch_items, raw)`` (vectorisation) run on a small thread pool while the calling thread keeps the GPU
     busy with ``predict_batch(prepared)``: batch k+1 is being decoded and batch k-1 vectorised while batch k is on
-    the device.  The reference does all three serially per tile ([EXT od] make_detections.py)."""
+    the device.  The reference does all three serially per tile ([EXT od] make_detections.py).
+
+    ``predict_stream(iterator of prepared batches) -> iterator of raw results`` (``engine.Predictor.predict_stream``), when
+    given, replaces the per-batch ``predict_batch`` calls: the GPU pipeline then also overlaps CONSECUTIVE batches (upload of
+    k+1 / forward of k / result copy of k-1) instead of draining after every batch."""
     lo, hi = shard_range(len(items), rank, world)
     mine: List[Any] = []
     starts = list(range(lo, hi, batch))
@@ -45,11 +50,14 @@ def run_sharded(items: Sequence[Any], predict_batch: Callable[[Sequence[Any]], L
         with ThreadPoolExecutor(max_workers=max(2, workers)) as pool:
             ahead = [pool.submit(prep, c) for c in chunks[:2]]           # decode runs two batches ahead
             done = []
-            for k, c in enumerate(chunks):
-                prepared = ahead[k].result()
-                if k + 2 < len(chunks):
-                    ahead.append(pool.submit(prep, chunks[k + 2]))
-                raw = predict_batch(prepared)
+            def prepared_batches():
+                for k in range(len(chunks)):
+                    prepared = ahead[k].result()
+                    if k + 2 < len(chunks):
+                        ahead.append(pool.submit(prep, chunks[k + 2]))
+                    yield prepared
+            raws = predict_stream(prepared_batches()) if predict_stream is not None else (predict_batch(b) for b in prepared_batches())
+            for c, raw in zip(chunks, raws):
                 done.append(pool.submit(fin, c, raw))
             for f in done:
                 mine.extend(f.result())

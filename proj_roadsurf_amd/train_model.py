@@ -59,7 +59,8 @@ def load_solver(d2_yaml: str) -> Dict[str, Any]:
         "eval_period": int((cfg.get("TEST", {}) or {}).get("EVAL_PERIOD", 0)),
         "min_size_train": tuple(int(x) for x in ((cfg.get("INPUT", {}) or {}).get("MIN_SIZE_TRAIN") or ())),
         "min_size_sampling": str((cfg.get("INPUT", {}) or {}).get("MIN_SIZE_TRAIN_SAMPLING", "choice")),
-        "max_size_train": int((cfg.get("INPUT", {}) or {}).get("MAX_SIZE_TRAIN", 1333)),
+        # a file that is silent on MAX_SIZE_TRAIN trains at its test maximum (both default to 1333 in detectron2)
+        "max_size_train": int((cfg.get("INPUT", {}) or {}).get("MAX_SIZE_TRAIN", (cfg.get("INPUT", {}) or {}).get("MAX_SIZE_TEST", 1333))),
         "max_size_test": int((cfg.get("INPUT", {}) or {}).get("MAX_SIZE_TEST", 1333)),
         "crop": bool(((cfg.get("INPUT", {}) or {}).get("CROP", {}) or {}).get("ENABLED", False)),
         "pre_nms_topk_train": int((m.get("RPN", {}) or {}).get("PRE_NMS_TOPK_TRAIN", 2000)),

@@ -215,11 +215,21 @@ def instances_to_gpkg_rows(instances, image_name: str, extent: Optional[Sequence
     lib.rs_vec_gpkg_blobs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.rs_vec_gpkg_blobs.restype = C.c_int64
     h, w = instances.image_size
-    packed = getattr(instances, "_packed", None)
-    if packed is None:
-        packed = np.packbits(np.asarray(instances.pred_masks, dtype=bool), axis=2, bitorder="little")
-    packed = np.ascontiguousarray(packed, dtype=np.uint8)
-    r = lib.rs_vectorize_masks(packed.ctypes.data_as(C.c_void_p), n, h, w, float(rdp_epsilon if rdp_enabled else 0.0), int(threads))
+    crops = getattr(instances, "_crops", None)
+    if crops is not None:
+        # masks arrived as crops of their boxes (engine.Engine.fetch_wait, rs_mask_crops): trace inside the crops, same vertices
+        rects, offs_c, data = crops
+        lib.rs_vectorize_mask_crops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        lib.rs_vectorize_mask_crops.restype = C.c_void_p
+        rects = np.ascontiguousarray(rects, np.int32); offs_c = np.ascontiguousarray(offs_c, np.uint32); data = np.ascontiguousarray(data, np.uint8)
+        r = lib.rs_vectorize_mask_crops(data.ctypes.data_as(C.c_void_p), rects.ctypes.data_as(C.c_void_p), offs_c.ctypes.data_as(C.c_void_p),
+                                        n, h, w, float(rdp_epsilon if rdp_enabled else 0.0), int(threads))
+    else:
+        packed = getattr(instances, "_packed", None)
+        if packed is None:
+            packed = np.packbits(np.asarray(instances.pred_masks, dtype=bool), axis=2, bitorder="little")
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        r = lib.rs_vectorize_masks(packed.ctypes.data_as(C.c_void_p), n, h, w, float(rdp_epsilon if rdp_enabled else 0.0), int(threads))
     if not r:
         raise RsError("rs_vectorize_masks failed")
     try:

@@ -529,6 +529,19 @@ def test_data_parallel_allreduce_sums_and_averages(gpu_required):
     assert r.returncode == 0 and "DP_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_rccl_allreduce_path_on_one_gpu(gpu_required):
+    """The device-side form of the gradient exchange (backend "nccl" = RCCL: zero-copy bucket views, asynchronous all-reduces
+    behind the bucket events, stream hand-back) in a one-rank process group on this box's GPU -- tests/nccl_worker.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_worker.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_multi_scale_state_handover(gpu_required):
     """MIN_SIZE_TRAIN "choice": the optimiser state follows the batch from the trainer of one input size to the next -- after a
     step at 160 px, the 192 px trainer holds bit-identical master weights and momentum and a refolded forward."""
@@ -673,7 +686,7 @@ def test_side_stream_gradients_equal_single_stream(gpu_required, monkeypatch):
         return out
 
     ref = grads(0, 0)[0]
-    assert len(ref) > 100 and all(float(np.abs(v).max()) > 0 for k, v in ref.items() if k.endswith(".w"))
+    assert len(ref) >= 60 and all(float(np.abs(v).max()) > 0 for k, v in ref.items() if k.endswith(".w"))
     worst = 0.0
     for side, roi_side in ((1, 0), (1, 1)):
         for g in grads(side, roi_side):

@@ -109,3 +109,28 @@ def test_run_sharded_three_stage_pipeline_keeps_order_and_overlaps():
     for tag in ("prep", "gpu", "fin"):
         assert sorted(v for t, v in log if t == tag) == [0, 4, 8, 12, 16, 20]
     assert log.index(("prep", 4)) < log.index(("gpu", 4)) and log.index(("prep", 8)) < log.index(("fin", 4)) + 3
+
+
+def test_run_sharded_streaming_form_keeps_order_and_pulls_lazily():
+    """``predict_stream``: the batches reach the predictor as ONE lazy iterator (at most two prepared batches ahead of what it has
+    consumed) and the per-item results come back in item order, ragged last batch included."""
+    from proj_roadsurf_amd.shard import run_sharded
+    items = list(range(23))
+    pulled = []
+
+    def prepare(b):
+        return [x * 10 for x in b]
+
+    def stream(batches):
+        held = []
+        for b in batches:                     # a consumer that, like LanePipeline.run, yields two batches behind its input
+            pulled.append(list(b))
+            held.append(b)
+            if len(held) > 2:
+                yield [x + 1 for x in held.pop(0)]
+        for b in held:
+            yield [x + 1 for x in b]
+
+    out = run_sharded(items, None, 4, prepare=prepare, finish=lambda b, raw: [(i, r) for i, r in zip(b, raw)], predict_stream=stream)
+    assert out == [(i, i * 10 + 1) for i in items]
+    assert [len(b) for b in pulled] == [4, 4, 4, 4, 4, 3]

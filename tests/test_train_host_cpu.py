@@ -71,3 +71,38 @@ def test_coco_mapper_flip_scale_and_sampler(tmp_path):
     a, b2 = TM.training_sampler(10, 3, 0, 2), TM.training_sampler(10, 3, 1, 2)
     s0, s1 = [next(a) for _ in range(10)], [next(b2) for _ in range(10)]
     assert sorted(s0[:5] + s1[:5]) == list(range(10)) and sorted(s0[5:] + s1[5:]) == list(range(10))
+
+
+def test_solver_validation_accepts_the_reference_yaml_and_rejects_unsupported_values(tmp_path):
+    """R:config/detectron2_config_3bands.yaml's solver / sampler values pass; values the training engine does not implement are
+    rejected up front (never clamped or ignored), as are images with more ground-truth boxes than the engine holds."""
+    import os
+
+    import yaml
+
+    from proj_roadsurf_amd import train_model as TM
+    ref = "/root/reference/config/detectron2_config_3bands.yaml"
+    if os.path.exists(ref):
+        sv = TM.load_solver(ref)
+        TM.validate_solver(sv)
+        assert sv["pre_nms_topk_train"] == 2000 and sv["post_nms_topk_train"] == 1000 and sv["roi_batch"] == 1024 and sv["max_size_train"] == 1333
+    base = {"INPUT": {"MAX_SIZE_TEST": 320}, "SOLVER": {"BASE_LR": 0.01}, "MODEL": {"ROI_HEADS": {"BATCH_SIZE_PER_IMAGE": 64}}}
+    p = tmp_path / "ok.yaml"
+    yaml.safe_dump(base, open(p, "w"))
+    TM.validate_solver(TM.load_solver(str(p)))            # silent on MAX_SIZE_TRAIN: trains at the test maximum
+    bad = [({"SOLVER": {"WARMUP_METHOD": "constant"}}, "WARMUP_METHOD"), ({"SOLVER": {"BIAS_LR_FACTOR": 2.0}}, "BIAS_LR_FACTOR"),
+           ({"SOLVER": {"CLIP_GRADIENTS": {"ENABLED": True}}}, "CLIP_GRADIENTS"), ({"INPUT": {"MAX_SIZE_TRAIN": 1000, "MAX_SIZE_TEST": 1333}}, "MAX_SIZE_TRAIN"),
+           ({"MODEL": {"ROI_HEADS": {"BATCH_SIZE_PER_IMAGE": 2048}}}, "BATCH_SIZE_PER_IMAGE"),
+           ({"MODEL": {"ROI_HEADS": {"BATCH_SIZE_PER_IMAGE": 1024, "POSITIVE_FRACTION": 0.5}}}, "mask-head entries"),
+           ({"MODEL": {"RPN": {"PRE_NMS_TOPK_TRAIN": 6000}}}, "PRE_NMS_TOPK_TRAIN"), ({"SOLVER": {"NESTEROV": True}}, "NESTEROV")]
+    for cfg, word in bad:
+        q = tmp_path / "bad.yaml"
+        yaml.safe_dump(cfg, open(q, "w"))
+        with pytest.raises(SystemExit) as e:
+            TM.validate_solver(TM.load_solver(str(q)))
+        assert word in str(e.value), (word, str(e.value))
+    recs = [{"file_name": "a.tif", "classes": np.zeros(5)}, {"file_name": "b.tif", "classes": np.zeros(129)}]
+    with pytest.raises(SystemExit) as e:
+        TM.check_gt_capacity(recs, "training set")
+    assert "b.tif" in str(e.value) and "129" in str(e.value)
+    TM.check_gt_capacity(recs[:1], "training set")

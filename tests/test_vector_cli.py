@@ -244,3 +244,44 @@ def test_make_detections_cli_end_to_end(gpu_required, tmp_path):
     assert pngs and all(p.startswith("val_det_") and p.endswith(".png") for p in pngs)
     from PIL import Image
     assert Image.open(wd / "sample_detection_images" / pngs[0]).size == (128, 128) or Image.open(wd / "sample_detection_images" / pngs[0]).size[0] > 0
+
+
+def test_cropped_vectoriser_equals_full_canvas(lib_path_ok=None):
+    """Masks as crops of their boxes (rs_mask_crops, what the streaming host interface copies back) give the same polygons,
+    vertex for vertex and byte for byte in the GeoPackage blobs, as the full canvases: tracing, RDP and hole assignment only
+    use differences of integer coordinates."""
+    import numpy as np
+
+    from proj_roadsurf_amd.engine import Instances
+    from proj_roadsurf_amd.vectorize import instances_to_gpkg_rows
+    rng = np.random.default_rng(3)
+    h, w = 96, 101                       # partial last byte
+    n = 6
+    masks = np.zeros((n, h, w), bool)
+    rects = np.zeros((n, 4), np.int32)
+    for i in range(n):
+        x0, y0 = int(rng.integers(0, 60)), int(rng.integers(0, 50))
+        bw, bh = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+        blob = rng.random((bh, bw)) > 0.35
+        blob[bh // 3: bh // 3 + 3, bw // 3: bw // 3 + 3] = False          # holes
+        masks[i, y0:y0 + bh, x0:x0 + bw] = blob
+        if i == n - 1:
+            masks[i] = False; masks[i, :, w - 3:] = True                  # touches the partial last byte
+            x0, y0, bw, bh = w - 3, 0, 3, h
+        xb0, xb1 = x0 >> 3, min(w - 1, x0 + bw) >> 3
+        rects[i] = (xb0, max(0, y0 - 1), xb1 - xb0 + 1, min(h, y0 + bh + 1) - max(0, y0 - 1))
+    packed = np.packbits(masks, axis=2, bitorder="little")
+    data, offs = [], []
+    for i in range(n):
+        xb0, yy, wb, rows = (int(v) for v in rects[i])
+        offs.append(sum(len(d) for d in data))
+        data.append(packed[i, yy:yy + rows, xb0:xb0 + wb].reshape(-1))
+    boxes = np.zeros((n, 4), np.float32); scores = np.linspace(0.9, 0.5, n).astype(np.float32); classes = np.arange(n) % 2
+    full = Instances((h, w), boxes, scores, classes, packed, None)
+    crop = Instances((h, w), boxes, scores, classes, None, None, crops=(rects, np.array(offs, np.uint32), np.concatenate(data)))
+    assert np.array_equal(crop._packed, packed) and np.array_equal(crop.pred_masks, masks)
+    for eps in (0.0, 0.75):
+        a = instances_to_gpkg_rows(full, "t.tif", (10.0, 20.0, 110.0, 120.0), True, eps, srs_id=2056, threads=2)
+        b = instances_to_gpkg_rows(crop, "t.tif", (10.0, 20.0, 110.0, 120.0), True, eps, srs_id=2056, threads=2)
+        assert a[1] == b[1] and len(a[0]) == len(b[0]) > n
+        assert all(x == y for x, y in zip(a[0], b[0]))

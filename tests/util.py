@@ -59,6 +59,7 @@ def conv_stage_shapes(spec, net_h=800, net_w=800):
     h2, w2, h4, w4 = net_h // 2, net_w // 2, net_h // 4, net_w // 4
     out.append(("stem.conv1", h2 * w2, 4, 7, spec.stem_out_channels, 0, None))
     cur_c, bott, cout, ch, cw = spec.stem_out_channels, 64, spec.res2_out_channels, h4, w4
+    have_t1 = False
     for si, nb in enumerate(spec.res_blocks):
         for bi in range(nb):
             nm = f"res{si + 2}.{bi}"
@@ -66,9 +67,16 @@ def conv_stage_shapes(spec, net_h=800, net_w=800):
             s1 = stride if spec.stride_in_1x1 else 1
             oh, ow = ch // stride, cw // stride
             proj = cur_c != cout
-            out.append((nm + ".conv1", (ch // s1) * (cw // s1), cur_c, 1, bott, 0, None))
-            out.append((nm + ".conv2", oh * ow, bott, 3, bott, 0, None))
-            out.append((nm + ".conv3", oh * ow, bott, 1, cout, cur_c if proj else 0, None))
+            tail = bott == 64 and cout == 256 and stride == 1     # fused tail of the 64-wide stage (csrc/bneck_fused.hip), variant 13
+            if not have_t1:
+                out.append((nm + ".conv1", (ch // s1) * (cw // s1), cur_c, 1, bott, 0, None))
+            have_t1 = False
+            if tail:
+                have_t1 = bi + 1 < nb
+                out.append((nm + (".conv2+conv3+next.conv1" if have_t1 else ".conv2+conv3"), oh * ow, bott, 3, cout, 0, 13))
+            else:
+                out.append((nm + ".conv2", oh * ow, bott, 3, bott, 0, None))
+                out.append((nm + ".conv3", oh * ow, bott, 1, cout, cur_c if proj else 0, None))
             cur_c, ch, cw = cout, oh, ow
         bott *= 2
         cout *= 2

@@ -22,6 +22,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--host-workers", type=int, default=4)
     ap.add_argument("--vector-threads", type=int, default=4)
+    ap.add_argument("--weights", choices=["random", "trained"], default="random",
+                    help="random: synthetic_weights (speckle masks, ~1900 polygons per tile); trained: synthetic.train_trained_like on "
+                         "synthetic scenes (a handful of clean objects per tile, like a trained detector on real tiles)")
+    ap.add_argument("--train-steps", type=int, default=300)
     args = ap.parse_args()
     import yaml
     from PIL import Image
@@ -32,10 +36,22 @@ def main():
         wd = os.path.join(td, "obj_detector")
         os.makedirs(os.path.join(wd, "oth-images"))
         base = synthetic_tiles(16, 512, 512, 3, seed=1234)
+        extra = ["--synthetic-weights"]
+        if args.weights == "trained":
+            import numpy as np
+            import torch
+            from proj_roadsurf_amd.spec import EngineSpec
+            from proj_roadsurf_amd.synthetic import synthetic_scenes, train_trained_like
+            W, _ = train_trained_like(EngineSpec(num_classes=2), 512, steps=args.train_steps)
+            os.makedirs(os.path.join(wd, "logs"), exist_ok=True)
+            torch.save({"model": {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in W.items()}, "iteration": args.train_steps},
+                       os.path.join(wd, "logs", "model_0005999.pth"))
+            base = synthetic_scenes(64, 512, 512, 3, seed=555)[0]
+            extra = []
         images, meta = [], {}
         for i in range(args.tiles):
             fn = f"oth-images/18_{1000 + i}_2000.tif"
-            Image.fromarray(base[i % 16][:, :, ::-1]).save(os.path.join(wd, fn))
+            Image.fromarray(base[i % len(base)][:, :, ::-1]).save(os.path.join(wd, fn))
             images.append({"id": i, "file_name": fn, "width": 512, "height": 512})
             meta[fn] = {"extent": [100.0 * i, 0.0, 100.0 * i + 104.6, 104.6], "crs": "EPSG:3857"}
         cats = [{"id": 1, "name": "artificial"}, {"id": 2, "name": "natural"}]
@@ -49,12 +65,12 @@ def main():
         yaml.safe_dump(cfg, open(os.path.join(td, "config.yaml"), "w"))
         cwd = os.getcwd()
         t0 = time.time()
-        rc = make_detections.main([os.path.join(td, "config.yaml"), "--synthetic-weights", "--batch", str(args.batch),
+        rc = make_detections.main([os.path.join(td, "config.yaml"), *extra, "--batch", str(args.batch),
                                    "--host-workers", str(args.host_workers), "--vector-threads", str(args.vector_threads)])
         dt = time.time() - t0
         os.chdir(cwd)
         size = os.path.getsize(os.path.join(wd, "oth_detections_at_0dot05_threshold.gpkg"))
-    print(json.dumps({"cli_tiles": args.tiles, "seconds_total_incl_engine_build": dt, "rc": rc, "gpkg_bytes": size}))
+    print(json.dumps({"cli_tiles": args.tiles, "weights": args.weights, "seconds_total_incl_engine_build": dt, "rc": rc, "gpkg_bytes": size}))
 
 
 if __name__ == "__main__":
