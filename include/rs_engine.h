@@ -195,7 +195,8 @@ int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, co
  * NULL and instead x0 [n][h+2][w+2][64], the shortcut's input, with wsc [256][64] (natural K order); b3 then is conv3's plus the
  * shortcut's bias: out = relu(w3 . t2 + wsc . x0 + b3). */
 int rs_op_bneck_tail(const void* t1, const void* w2, const float* b2, const void* w3p, const float* b3, const void* x, void* out,
-                     const void* w1p, const float* b1, void* t1n, const void* x0, const void* wsc, int n, int h, int w, void* stream);
+                     const void* w1p, const float* b1, void* t1n, const void* x0, const void* wsc, int n, int h, int w, int width,
+                     void* stream);     /* width: 64 (as written above) or 128 (every 64 / 256 / 576 above doubled; no projection form) */
 
 /* The tile variant launch_conv would pick for a conv / linear layer of this shape (no launch, no GPU needed): m = batch *
  * Ho * Wo output pixels, k x k taps over cin channels (+ cin2 channels of a second 1x1 K source, 0 = none), cout channels,

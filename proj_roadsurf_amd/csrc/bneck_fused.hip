@@ -33,14 +33,28 @@
 
 namespace {
 
-// 4 waves x NJ*16 pixels.  NJ = 2 (128-pixel tiles): 48 KB of LDS and ~150 VGPRs, THREE workgroups per CU -- measured against
-// NJ = 4 (256-pixel tiles, 80 KB: only ONE workgroup fits a CU, two would need exactly the 160 KB the CU has): with a single
-// resident workgroup nothing overlaps its waits and the kernel's costs simply add up (0.26 ms = 0.10 compute skeleton + 0.10
-// residual stream + 0.04 conv2 staging + 0.02 stores, ablation builds -DRS_BNECK_DIAG).
+// 4 waves x NJ*16 pixels.  NJ = 2 (128-pixel tiles): THREE (by registers: two) workgroups per CU -- measured against NJ = 4
+// (256-pixel tiles, 80 KB: only ONE workgroup fits a CU, two would need exactly the 160 KB the CU has): with a single resident
+// workgroup nothing overlaps its waits and the kernel's costs simply add up (0.26 ms = 0.10 compute skeleton + 0.10 residual
+// stream + 0.04 conv2 staging + 0.02 stores, ablation builds -DRS_BNECK_DIAG).
 constexpr int NJ = 2, NT = 256, BM = 4 * NJ * 16, PXW = NJ * 16;
-constexpr int STAGE = (BM + 64) * 128;          // activations [BM][128 B] + weights [64][128 B]
-constexpr int BIAS_OFF = 3 * STAGE;              // b2 [64], b3 [256], b1n [64] as fp32: 1536 B
-constexpr int LDS_BYTES = 3 * STAGE + 1536;      // 73.5 KB: two workgroups per CU
+
+// CB = bottleneck width / 64: 1 = res2 (64 -> 256), 2 = res3 (128 -> 512).
+template <int CB>
+struct Cfg {
+  static constexpr int CBW = 64 * CB;              // bottleneck width (t1, t2, t1n channels)
+  static constexpr int C4 = 256 * CB;              // block input / output channels
+  static constexpr int MIB = 4 * CB;               // 16-row blocks of a CBW-row weight matrix (conv2, next conv1)
+  static constexpr int NPASS = 4 * CB;             // conv3 output channel groups of 64
+  static constexpr int KS2 = 9 * CB;               // conv2 K steps of 64: 64-channel slice outer, taps inner
+  static constexpr int RING = CB == 1 ? 3 : 2;     // LDS stage buffers of the conv2 loop
+  static constexpr int STAGE = (BM + CBW) * 128;   // activations [BM][128 B] + weights [CBW][128 B]; a pass's slices fit the same space
+  static constexpr int W1_OFF = CB * 8192;         // pass slice layout: W3 (CB sub-tiles of [64][128 B]), W1n [CBW][128 B], Wsc [64][128 B]
+  static constexpr int SC_OFF = 2 * CB * 8192;
+  static constexpr int NBIAS = 2 * CBW + C4;       // b2 [CBW], b3 [C4], b1n [CBW] as fp32
+  static constexpr int BIAS_OFF = RING * STAGE;
+  static constexpr int LDS_BYTES = RING * STAGE + NBIAS * 4;   // CB 1: 73.5 KB, CB 2: 67 KB -- two workgroups per CU
+};
 
 __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -67,8 +81,11 @@ __device__ __forceinline__ float clamp_h(float f) { return f > 65504.f ? 65504.f
 // SC: the block's shortcut is a 1x1 projection of a 64-channel input x0 at the same resolution (res2.0: the stem output) instead
 // of the identity: out = relu(W3 . t2 + Wsc . x0 + b), i.e. two more K steps per pass whose B operand (x0 of the lane's pixels)
 // is loaded once per tile straight into registers in the MFMA's own k order (Wsc keeps its natural column order).
-template <bool NEXT, int DBG = 0, bool SC = false>
-__global__ __launch_bounds__(NT) void bneck_tail_kernel(const BneckParams p) {
+template <int CB, bool NEXT, int DBG = 0, bool SC = false>
+__global__ __launch_bounds__(NT, 2) void bneck_tail_kernel(const BneckParams p) {
+  using G = Cfg<CB>;
+  constexpr int CBW = G::CBW, C4 = G::C4, MIB = G::MIB, NPASS = G::NPASS, KS2 = G::KS2, RING = G::RING, STAGE = G::STAGE;
+  static_assert(!SC || CB == 1, "the projection-shortcut form exists for the 64-wide stage only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,49 +99,62 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const BneckParams p) {
     m0 = ((x < r ? x * (qn + 1) : r * (qn + 1) + (x - r) * qn) + (q >> 3)) * BM;
   }
   const int lrow = lane >> 3, lchk = lane & 7;
-  // ---- conv2 staging pointers: BM/32 passes of 32 rows (this wave: rows ps*32 + wave*8 + lrow)
+  // ---- conv2 staging pointers: BM/32 passes of 32 activation rows, CBW/32 passes of weight rows (this wave: rows ps*32 + wave*8 + lrow)
   const half_t* aptr[BM / 32];
 #pragma unroll
   for (int ps = 0; ps < BM / 32; ++ps) {
     int m = m0 + ps * 32 + wave * 8 + lrow;
     if (m >= M) m = M - 1;
     const int x = m % p.W, t = m / p.W, y = t % p.H, n = t / p.H;
-    aptr[ps] = p.t1 + ((long long)(n * p.Hp + y) * p.Wp + x) * 64 + (lchk ^ lrow) * 8;     // tap (0,0) of the zero-haloed map
+    aptr[ps] = p.t1 + ((long long)(n * p.Hp + y) * p.Wp + x) * CBW + (lchk ^ lrow) * 8;     // tap (0,0) of the zero-haloed map
   }
-  const half_t* wptr[2];
+  const half_t* wptr[CBW / 32];
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
+  for (int ps = 0; ps < CBW / 32; ++ps) {
     const int row = ps * 32 + wave * 8 + lrow;
-    const int key = (row & 3) | (((row >> 4) & 1) << 2);
-    wptr[ps] = p.w2 + (long long)row * 576 + (lchk ^ key) * 8;
+    const int key = (row & 3) | (((row / (4 * MIB)) & 1) << 2);
+    wptr[ps] = p.w2 + (long long)row * (9 * CBW) + (lchk ^ key) * 8;
   }
-  auto stage_tap = [&](int buf, int tap) {
+  auto stage_tap = [&](int buf, int step) {                     // K step = (64-channel slice, tap)
     char* abase = smem + buf * STAGE;
-    const int a_off = ((tap / 3) * p.Wp + (tap % 3)) * 64;
+    const int slice = step / 9, tap = step - slice * 9;
+    const int a_off = ((tap / 3) * p.Wp + (tap % 3)) * CBW + slice * 64;
     if (!(DBG & 4)) {
 #pragma unroll
       for (int ps = 0; ps < BM / 32; ++ps) glds16(aptr[ps] + a_off, abase + (ps * 32 + wave * 8) * 128);
     }
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) glds16(wptr[ps] + tap * 64, abase + BM * 128 + (ps * 32 + wave * 8) * 128);
+    for (int ps = 0; ps < CBW / 32; ++ps) glds16(wptr[ps] + tap * CBW + slice * 64, abase + BM * 128 + (ps * 32 + wave * 8) * 128);
   };
-  // pass slices of conv3 / next conv1: W3p rows 64 pass .. +63 (128-byte rows) at +0, W1p columns 64 pass .. +63 of its 64 rows at +8 KB
+  // pass slices of conv3 / next conv1: W3p rows 64 pass .. +63 as CB sub-tiles of 64 K columns, W1p columns 64 pass .. +63 of its
+  // CBW rows, (SC) Wsc rows 64 pass .. +63
   auto stage_pass = [&](int buf, int pass) {
     char* base = smem + buf * STAGE;
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int row = ps * 32 + wave * 8 + lrow;
       const int key = (row & 3) | (((row >> 4) & 1) << 2);
-      glds16(p.w3p + (long long)(pass * 64 + row) * 64 + (lchk ^ key) * 8, base + (ps * 32 + wave * 8) * 128);
-      if (NEXT) glds16(p.w1p + (long long)row * 256 + pass * 64 + (lchk ^ key) * 8, base + 8192 + (ps * 32 + wave * 8) * 128);
-      if (SC) glds16(p.wsc + (long long)(pass * 64 + row) * 64 + (lchk ^ key) * 8, base + 16384 + (ps * 32 + wave * 8) * 128);
+#pragma unroll
+      for (int c = 0; c < CB; ++c)
+        glds16(p.w3p + (long long)(pass * 64 + row) * CBW + c * 64 + (lchk ^ key) * 8, base + c * 8192 + (ps * 32 + wave * 8) * 128);
+      if (SC) glds16(p.wsc + (long long)(pass * 64 + row) * 64 + (lchk ^ key) * 8, base + G::SC_OFF + (ps * 32 + wave * 8) * 128);
+    }
+    if (NEXT) {
+#pragma unroll
+      for (int ps = 0; ps < CBW / 32; ++ps) {
+        const int row = ps * 32 + wave * 8 + lrow;
+        const int key = (row & 3) | (((row / (4 * MIB)) & 1) << 2);
+        glds16(p.w1p + (long long)row * C4 + pass * 64 + (lchk ^ key) * 8, base + G::W1_OFF + (ps * 32 + wave * 8) * 128);
+      }
     }
   };
 
   const int fi = lane & 15, fq = lane >> 4, fkey = lane & 7;
-  int w_off[4], x_off[NJ];
+  int w_off[4], wB_off[MIB], x_off[NJ];          // rows of a 64-row slice / of a CBW-row matrix this lane reads as MFMA A rows
 #pragma unroll
   for (int i = 0; i < 4; ++i) w_off[i] = ((fi >> 2) * 16 + i * 4 + (fi & 3)) * 128;
+#pragma unroll
+  for (int i = 0; i < MIB; ++i) wB_off[i] = ((fi >> 2) * 4 * MIB + i * 4 + (fi & 3)) * 128;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) x_off[j] = (wave * PXW + j * 16 + fi) * 128;
   const int c_off[2] = {(fq ^ fkey) * 16, ((4 + fq) ^ fkey) * 16};
@@ -148,7 +178,7 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const BneckParams p) {
   auto load_res = [&](half8 (&dst)[NJ][2], int pass) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const half_t* xp = p.x + opix[j] * 256 + pass * 64 + fq * 16;
+      const half_t* xp = p.x + opix[j] * C4 + pass * 64 + fq * 16;
       if ((DBG & 1) || SC) { dst[j][0] = half8{}; dst[j][1] = half8{}; continue; }
       gload16_untracked(dst[j][0], xp);
       gload16_untracked(dst[j][1], xp + 8);
@@ -157,29 +187,30 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const BneckParams p) {
 
   // Biases go through LDS: an ordinary global load anywhere between two prefetch points would make the compiler wait vmcnt(0) at
   // its first use and so drain the LDS-DMA pieces and residual loads that are supposed to stay in flight across a pass.
-  float* bias_s = (float*)(smem + BIAS_OFF);
-  for (int i = tid; i < 384; i += NT) bias_s[i] = i < 64 ? p.b2[i] : (i < 320 ? p.b3[i - 64] : (NEXT ? p.b1[i - 320] : 0.f));
+  float* bias_s = (float*)(smem + G::BIAS_OFF);
+  for (int i = tid; i < G::NBIAS; i += NT) bias_s[i] = i < CBW ? p.b2[i] : (i < CBW + C4 ? p.b3[i - CBW] : (NEXT ? p.b1[i - CBW - C4] : 0.f));
 
-  // ================================================================ conv2: 9 K steps
-  f32x4 acc[4][NJ];
+  // ================================================================ conv2: KS2 K steps
+  f32x4 acc[MIB][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MIB; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // Three-buffer ring: tap t+2 is issued while tap t is computed, so a piece has TWO K steps (~0.25 us of MFMA work) plus
-  // the other workgroups' share of the CU to arrive from L2 / HBM; the wait that opens step t leaves exactly the 6 pieces of tap
-  // t+1 (4 activation + 2 weight pieces per wave) in flight.  The pass slices reuse ring buffers 0 and 1.
+  // CB 1, three-buffer ring: step t+2 is issued while step t is computed, so a piece has TWO K steps plus the other workgroup's
+  // share of the CU to arrive; the wait that opens step t leaves exactly the pieces of step t+1 (BM/32 activation + CBW/32 weight
+  // pieces per wave) in flight.  CB 2 (32 KB stages): two buffers, one step ahead.  The pass slices reuse buffers 0 and 1.
+  constexpr int PIECES = BM / 32 + CBW / 32;
   __syncthreads();                                  // biases are in LDS; nothing else is in flight
   stage_tap(0, 0);
-  stage_tap(1, 1);
+  if (RING == 3) stage_tap(1, 1);
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    if (t + 1 < 9) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  for (int t = 0; t < KS2; ++t) {
+    if (RING == 3 && t + 1 < KS2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                   // raw barrier: __syncthreads() would drain the piece in flight (its fence waits vmcnt(0))
-    if (t + 2 < 9) stage_tap((t + 2) % 3, t + 2);
-    else if (t == 8) {                              // buffers 0 (tap 6) and 1 (tap 7) are free: first conv3 / conv1n slices + residuals
+    if (t + RING - 1 < KS2) stage_tap((t + RING - 1) % RING, t + RING - 1);
+    else if (t == KS2 - 1) {                        // the buffer(s) of the earlier steps are free: first conv3 / conv1n slices + residuals
       stage_pass(0, 0);
       load_res(rb[0], 0);
       if (SC) {
@@ -191,40 +222,41 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const BneckParams p) {
         }
       }
     }
-    const char* sb = smem + (t % 3) * STAGE;
+    const char* sb = smem + (t % RING) * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      half8 wf[4], xf[NJ];
+      half8 wf[MIB], xf[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(sb + BM * 128 + w_off[i] + c_off[kk]);
+      for (int i = 0; i < MIB; ++i) wf[i] = *(const half8*)(sb + BM * 128 + wB_off[i] + c_off[kk]);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) xf[j] = *(const half8*)(sb + x_off[j] + c_off[kk]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MIB; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
   }
-  // ---- t2 = relu(acc + b2), rounded to fp16 exactly as a store would: the B operand of conv3 (two K steps of 32)
-  half8 tf[2][NJ];
+  // ---- t2 = relu(acc + b2), rounded to fp16 exactly as a store would: the B operand of conv3 (2 CB K steps of 32); the lane holds
+  // channels 16 CB fq + 4 i + r, K step s takes accumulators 2s and 2s+1 = channels 16 CB fq + 8 s + j
+  half8 tf[2 * CB][NJ];
   {
-    f32x4 b2v[4];
+    f32x4 b2v[MIB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b2v[i] = *(const f32x4*)(bias_s + fq * 16 + i * 4);
+    for (int i = 0; i < MIB; ++i) b2v[i] = *(const f32x4*)(bias_s + fq * 4 * MIB + i * 4);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MIB; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r] + b2v[i][r]; acc[i][j][r] = clamp_h(v > 0.f ? v : 0.f); }
-      tf[0][j] = pack8(acc[0][j], acc[1][j]);
-      tf[1][j] = pack8(acc[2][j], acc[3][j]);
+#pragma unroll
+      for (int s2 = 0; s2 < 2 * CB; ++s2) tf[s2][j] = pack8(acc[2 * s2][j], acc[2 * s2 + 1][j]);
     }
   }
   const bool full_tile = m0 + BM <= M;
-  f32x4 acc3[4][NJ];           // t1n accumulators: channels 16 fq + 4 i + r of pixel (j, fi)
+  f32x4 acc3[MIB][NJ];         // t1n accumulators: channels 16 CB fq + 4 i + r of pixel (j, fi)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MIB; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -234,7 +266,7 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const BneckParams p) {
   auto passes = [&](auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; pass < NPASS; ++pass) {
     // this pass's slices and residuals were issued BEFORE the previous pass's 2*NJ `out` stores: leave exactly those in flight
     // (a partial last tile skips stores, so it drains everything)
     static_assert(NJ == 2, "the wait below names the 2*NJ residual registers of the pass");
@@ -248,54 +280,48 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const BneckParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // pass slices + this pass's residuals landed; everyone is done with the other buffer
-    // this pass's residuals as floats (their loads were issued one pass ago by gload16_untracked; the wait above covers them)
-    float rf[NJ][16];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        rf[j][e] = SC ? 0.f : (float)rb[pass & 1][j][0][e];
-        rf[j][8 + e] = SC ? 0.f : (float)rb[pass & 1][j][1][e];
-      }
-    if (pass + 1 < 4) { stage_pass((pass + 1) & 1, pass + 1); load_res(rb[(pass + 1) & 1], pass + 1); }
+    if (pass + 1 < NPASS) { stage_pass((pass + 1) & 1, pass + 1); load_res(rb[(pass + 1) & 1], pass + 1); }
     const char* sb = smem + (pass & 1) * STAGE;
     const int cb = pass * 64 + fq * 16;              // this lane's 16 output channels of the pass
-    f32x4 b3v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b3v[i] = *(const f32x4*)(bias_s + 64 + cb + i * 4);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       f32x4 a2[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const half8 wa = *(const half8*)(sb + w_off[i] + c_off[0]), wb = *(const half8*)(sb + w_off[i] + c_off[1]);
         a2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, tf[0][j], a2[i], 0, 0, 0);
-        a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, tf[1][j], a2[i], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {               // K sub-tile c of the W3 slice = K steps 2c, 2c+1
+          const half8 wa = *(const half8*)(sb + c * 8192 + w_off[i] + c_off[0]), wb = *(const half8*)(sb + c * 8192 + w_off[i] + c_off[1]);
+          a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, tf[2 * c][j], a2[i], 0, 0, 0);
+          a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, tf[2 * c + 1][j], a2[i], 0, 0, 0);
+        }
         if (SC) {
-          const half8 sa = *(const half8*)(sb + 16384 + w_off[i] + c_off[0]), sc = *(const half8*)(sb + 16384 + w_off[i] + c_off[1]);
+          const half8 sa = *(const half8*)(sb + G::SC_OFF + w_off[i] + c_off[0]), sc = *(const half8*)(sb + G::SC_OFF + w_off[i] + c_off[1]);
           a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sa, xq[0][j], a2[i], 0, 0, 0);
           a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sc, xq[1][j], a2[i], 0, 0, 0);
         }
       }
+      f32x4 b3q[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b3q[i] = *(const f32x4*)(bias_s + CBW + cb + i * 4);      // from LDS, per pixel block: no registers held across the pass
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float res = rf[j][i * 4 + r];
-          const float v = a2[i][r] + b3v[i][r] + res;
+          const float res = SC ? 0.f : (float)rb[pass & 1][j][i >> 1][(i & 1) * 4 + r];     // loaded one pass ago (gload16_untracked), covered by the wait above
+          const float v = a2[i][r] + b3q[i][r] + res;
           a2[i][r] = clamp_h(v > 0.f ? v : 0.f);
         }
       const half8 o0 = pack8(a2[0], a2[1]), o1 = pack8(a2[2], a2[3]);
       if (valid[j] && !(DBG & 2)) {
-        half_t* op = p.out + opix[j] * 256 + cb;
+        half_t* op = p.out + opix[j] * C4 + cb;
         *(half8*)op = o0;
         *(half8*)(op + 8) = o1;
       }
       if (NEXT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const half8 wa = *(const half8*)(sb + 8192 + w_off[i] + c_off[0]), wb = *(const half8*)(sb + 8192 + w_off[i] + c_off[1]);
+        for (int i = 0; i < MIB; ++i) {
+          const half8 wa = *(const half8*)(sb + G::W1_OFF + wB_off[i] + c_off[0]), wb = *(const half8*)(sb + G::W1_OFF + wB_off[i] + c_off[1]);
           acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o0, acc3[i][j], 0, 0, 0);
           acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, o1, acc3[i][j], 0, 0, 0);
         }
@@ -307,21 +333,72 @@ __global__ __launch_bounds__(NT) void bneck_tail_kernel(const BneckParams p) {
   if (full_tile) passes(std::true_type{});
   else passes(std::false_type{});
   if (NEXT) {
-    f32x4 b1v[4];
+    f32x4 b1v[MIB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b1v[i] = *(const f32x4*)(bias_s + 320 + fq * 16 + i * 4);
+    for (int i = 0; i < MIB; ++i) b1v[i] = *(const f32x4*)(bias_s + CBW + C4 + fq * 4 * MIB + i * 4);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if (!valid[j]) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MIB; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float v = acc3[i][j][r] + b1v[i][r]; acc3[i][j][r] = clamp_h(v > 0.f ? v : 0.f); }
-      half_t* op = p.t1n + opix[j] * 64 + fq * 16;
-      *(half8*)op = pack8(acc3[0][j], acc3[1][j]);
-      *(half8*)(op + 8) = pack8(acc3[2][j], acc3[3][j]);
+      half_t* op = p.t1n + opix[j] * CBW + fq * 4 * MIB;
+#pragma unroll
+      for (int k = 0; k < MIB / 2; ++k) *(half8*)(op + 8 * k) = pack8(acc3[2 * k][j], acc3[2 * k + 1][j]);
     }
   }
+}
+
+template <int CB>
+int launch_cb(const BneckParams& p, hipStream_t stream) {
+  using G = Cfg<CB>;
+  const long long nblk = cdiv(p.M, BM);
+  RS_CHECK(nblk < (1ll << 31), RS_ERR_ARG, "bneck_tail: grid too large");
+  const void* k;
+  if constexpr (CB == 1)
+    k = p.x0 ? (p.w1p ? (const void*)bneck_tail_kernel<1, true, 0, true> : (const void*)bneck_tail_kernel<1, false, 0, true>)
+             : (p.w1p ? (const void*)bneck_tail_kernel<1, true> : (const void*)bneck_tail_kernel<1, false>);
+  else
+    k = p.w1p ? (const void*)bneck_tail_kernel<CB, true> : (const void*)bneck_tail_kernel<CB, false>;
+#ifdef RS_BNECK_DIAG
+  {
+    static bool once = false;
+    if (!once) {
+      once = true;
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, G::LDS_BYTES);
+      fprintf(stderr, "[bneck diag] CB %d occupancy API: %d workgroups of %d threads / %d B LDS per CU\n", CB, nb, NT, G::LDS_BYTES);
+    }
+  }
+  if (p.w1p && !p.x0) {                // diagnostic build only (make EXTRA=-DRS_BNECK_DIAG): RS_DEEP_DBG selects the ablation of the NEXT form
+    const void* kd = nullptr;
+    switch (rs_debug().deep_dbg) {
+      case 1: kd = (const void*)bneck_tail_kernel<CB, true, 1>; break;
+      case 2: kd = (const void*)bneck_tail_kernel<CB, true, 2>; break;
+      case 4: kd = (const void*)bneck_tail_kernel<CB, true, 4>; break;
+      case 7: kd = (const void*)bneck_tail_kernel<CB, true, 7>; break;
+      default: break;
+    }
+    if (kd) {
+      RS_HIP(hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+      BneckParams pd = p;
+      void* argsd[] = {&pd};
+      RS_HIP(hipLaunchKernel(kd, dim3((unsigned)nblk), dim3(NT), argsd, G::LDS_BYTES, stream));
+      return RS_OK;
+    }
+  }
+#endif
+  static bool attr[4] = {false, false, false, false};
+  const int ai = (p.w1p ? 1 : 0) | (p.x0 ? 2 : 0);
+  if (!attr[ai]) {
+    RS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr[ai] = true;
+  }
+  BneckParams pc = p;
+  void* args[] = {&pc};
+  RS_HIP(hipLaunchKernel(k, dim3((unsigned)nblk), dim3(NT), args, G::LDS_BYTES, stream));
+  return RS_OK;
 }
 
 }  // namespace
@@ -331,47 +408,6 @@ int launch_bneck_tail(const BneckParams& p, hipStream_t stream) {
   RS_CHECK((p.x != nullptr) != (p.x0 != nullptr && p.wsc != nullptr), RS_ERR_ARG, "bneck_tail: give either the identity residual x or the projection shortcut x0 + wsc");
   RS_CHECK(p.Hp == p.H + 2 && p.Wp == p.W + 2, RS_ERR_ARG, "bneck_tail: maps must carry a halo of 1");
   RS_CHECK(!p.w1p || (p.b1 && p.t1n), RS_ERR_ARG, "bneck_tail: next conv1 needs weights, bias and output");
-  const long long nblk = cdiv(p.M, BM);
-  RS_CHECK(nblk < (1ll << 31), RS_ERR_ARG, "bneck_tail: grid too large");
-  const void* k = p.x0 ? (p.w1p ? (const void*)bneck_tail_kernel<true, 0, true> : (const void*)bneck_tail_kernel<false, 0, true>)
-                       : (p.w1p ? (const void*)bneck_tail_kernel<true> : (const void*)bneck_tail_kernel<false>);
-#ifdef RS_BNECK_DIAG
-  {
-    static bool once = false;
-    if (!once) {
-      once = true;
-      int nb = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, LDS_BYTES);
-      fprintf(stderr, "[bneck diag] occupancy API: %d workgroups of %d threads / %d B LDS per CU\n", nb, NT, LDS_BYTES);
-    }
-  }
-  if (p.w1p && !p.x0) {                // diagnostic build only (make EXTRA=-DRS_BNECK_DIAG): RS_DEEP_DBG selects the ablation of the NEXT form
-    const void* kd = nullptr;
-    switch (rs_debug().deep_dbg) {
-      case 1: kd = (const void*)bneck_tail_kernel<true, 1>; break;
-      case 2: kd = (const void*)bneck_tail_kernel<true, 2>; break;
-      case 3: kd = (const void*)bneck_tail_kernel<true, 3>; break;
-      case 4: kd = (const void*)bneck_tail_kernel<true, 4>; break;
-      case 7: kd = (const void*)bneck_tail_kernel<true, 7>; break;
-      default: break;
-    }
-    if (kd) {
-      RS_HIP(hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-      BneckParams pd = p;
-      void* argsd[] = {&pd};
-      RS_HIP(hipLaunchKernel(kd, dim3((unsigned)nblk), dim3(NT), argsd, LDS_BYTES, stream));
-      return RS_OK;
-    }
-  }
-#endif
-  static bool attr[4] = {false, false, false, false};
-  const int ai = (p.w1p ? 1 : 0) | (p.x0 ? 2 : 0);
-  if (!attr[ai]) {
-    RS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr[ai] = true;
-  }
-  BneckParams pc = p;
-  void* args[] = {&pc};
-  RS_HIP(hipLaunchKernel(k, dim3((unsigned)nblk), dim3(NT), args, LDS_BYTES, stream));
-  return RS_OK;
+  RS_CHECK(p.CB == 1 || (p.CB == 2 && !p.x0), RS_ERR_UNSUPPORTED, "bneck_tail: bottleneck width %d (64 or 128; projection shortcut: 64 only)", 64 * p.CB);
+  return p.CB == 1 ? launch_cb<1>(p, stream) : launch_cb<2>(p, stream);
 }

@@ -138,6 +138,7 @@ struct BneckParams {
   const float* b1;
   half_t* t1n;          // next block's conv1 output [N][H+2][W+2][64]
   int M, H, W, Hp, Wp;  // M = N*H*W pixels
+  int CB;               // bottleneck width / 64: 1 (64 -> 256, res2) or 2 (128 -> 512, res3); every "64" / "256" above scales with it
 };
 int launch_bneck_tail(const BneckParams& p, hipStream_t stream);
 

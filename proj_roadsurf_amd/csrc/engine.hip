@@ -433,13 +433,13 @@ int rs_engine::build() {
       const int s1 = S.stride_in_1x1 ? stride : 1, s3 = S.stride_in_1x1 ? 1 : stride;
       const int oh = ch / stride, ow = cw / stride;
       Act t1, t2, sc, out;
-      // Fused tail (bneck_fused.hip): identity-shortcut blocks of the 64-wide stage run conv2 + conv3 (+ the next block's conv1)
+      // Fused tail (bneck_fused.hip): identity-shortcut blocks of the 64- and 128-wide stages run conv2 + conv3 (+ the next block's conv1)
       // in one launch -- t2 is never materialised and the next conv1 reads `out` from registers.  fp16 inference engine only.
       // Block 0 of the stage has a projection shortcut from the 64-channel stem output at the same resolution: the tail then adds
       // Wsc . x0 as two more K steps instead of the identity residual (needs the folded conv3sc bias = conv3's + the shortcut's).
       const bool tail0 = !f32 && fuse_bneck && fuse_shortcut && bi == 0 && bott == 64 && cout == 256 && stride == 1 && cur.C == 64 &&
                          findw(wn + ".conv3p") != nullptr && findw(wn + ".shortcut") != nullptr && find(wn + ".conv3sc.b") != nullptr;
-      const bool tail = tail0 || (!f32 && fuse_bneck && bi > 0 && bott == 64 && cout == 256 && stride == 1 && findw(wn + ".conv3p") != nullptr);
+      const bool tail = tail0 || (!f32 && fuse_bneck && bi > 0 && (bott == 64 || bott == 128) && cout == 4 * bott && stride == 1 && findw(wn + ".conv3p") != nullptr);
       const bool tail_next = tail && bi + 1 < S.res_blocks[si] &&
                              findw(bu + "res" + std::to_string(si + 2) + "." + std::to_string(bi + 1) + ".conv1p") != nullptr;
       if (have_t1) t1 = t1_pre;
@@ -466,7 +466,7 @@ int rs_engine::build() {
         const BlobEntry* wsc = tail0 ? findw(wn + ".shortcut") : nullptr;
         const BlobEntry *w1 = tail_next ? findw(bu + nn + ".conv1p") : nullptr, *b1 = tail_next ? find(bu + nn + ".conv1.b") : nullptr;
         RS_CHECK(w2 && b2 && w3 && b3 && (!tail_next || (w1 && b1)), RS_ERR_BLOB, "weights of the fused tail of %s missing", nm.c_str());
-        RS_CHECK(w2->dims[0] == 64 && w2->dims[1] == 576 && w3->dims[0] == 256 && w3->dims[1] == 64 && (!w1 || (w1->dims[0] == 64 && w1->dims[1] == 256)),
+        RS_CHECK(w2->dims[0] == bott && w2->dims[1] == 9 * bott && w3->dims[0] == cout && w3->dims[1] == bott && (!w1 || (w1->dims[0] == bott && w1->dims[1] == cout)),
                  RS_ERR_BLOB, "fused tail of %s: weight shapes", nm.c_str());
         BneckParams bp;
         memset(&bp, 0, sizeof bp);
@@ -479,13 +479,13 @@ int rs_engine::build() {
           bp.x = cur.p;
         }
         if (tail_next) { bp.w1p = (const half_t*)w1->dev; bp.b1 = (const float*)b1->dev; bp.t1n = t1_pre.p; }
-        bp.H = oh; bp.W = ow; bp.Hp = out.Hp(); bp.Wp = out.Wp();
-        RS_CHECK(t1.pad == 1 && cur.pad == 1 && out.pad == 1 && t1.H == oh && cur.H == oh && t1.C == 64 && cur.C == (tail0 ? 64 : 256), RS_ERR_ARG, "fused tail of %s: geometry", nm.c_str());
+        bp.H = oh; bp.W = ow; bp.Hp = out.Hp(); bp.Wp = out.Wp(); bp.CB = bott / 64;
+        RS_CHECK(t1.pad == 1 && cur.pad == 1 && out.pad == 1 && t1.H == oh && cur.H == oh && t1.C == bott && cur.C == (tail0 ? 64 : cout), RS_ERR_ARG, "fused tail of %s: geometry", nm.c_str());
         const int mpi = oh * ow;
         Stage st;
         st.name = nm + (tail_next ? ".conv2+conv3+next.conv1" : ".conv2+conv3");
-        st.flops_per_image = 2.0 * mpi * (576.0 * 64 + 64.0 * 256 + (tail0 ? 64.0 * 256 : 0.0) + (tail_next ? 256.0 * 64 : 0.0));
-        st.bytes_per_image = 2.0 * mpi * (64.0 + (tail0 ? 64.0 : 256.0) + 256 + (tail_next ? 64.0 : 0.0));       // t1 + x (or x0) in, out (+ t1n) out
+        st.flops_per_image = 2.0 * mpi * (9.0 * bott * bott + (double)bott * cout + (tail0 ? 64.0 * cout : 0.0) + (tail_next ? (double)cout * bott : 0.0));
+        st.bytes_per_image = 2.0 * mpi * ((double)bott + (tail0 ? 64.0 : (double)cout) + cout + (tail_next ? (double)bott : 0.0));       // t1 + x (or x0) in, out (+ t1n) out
         st.fn = [bp, mpi](int n, hipStream_t s) mutable { bp.M = n * mpi; g_last_conv_variant = 13; return launch_bneck_tail(bp, s); };
         stages.push_back(st);
         have_t1 = tail_next;
@@ -1381,13 +1381,14 @@ int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const floa
 }
 
 int rs_op_bneck_tail(const void* t1, const void* w2, const float* b2, const void* w3p, const float* b3, const void* x, void* out,
-                     const void* w1p, const float* b1, void* t1n, const void* x0, const void* wsc, int n, int h, int w, void* stream) {
+                     const void* w1p, const float* b1, void* t1n, const void* x0, const void* wsc, int n, int h, int w, int width, void* stream) {
   RS_CHECK(t1 && w2 && b2 && w3p && b3 && out && n > 0 && h > 0 && w > 0, RS_ERR_ARG, "bad argument");
+  RS_CHECK(width == 64 || width == 128, RS_ERR_UNSUPPORTED, "bneck_tail: bottleneck width %d (64 or 128)", width);
   BneckParams p;
   memset(&p, 0, sizeof p);
   p.t1 = (const half_t*)t1; p.w2 = (const half_t*)w2; p.b2 = b2; p.w3p = (const half_t*)w3p; p.b3 = b3; p.x = (const half_t*)x; p.out = (half_t*)out;
   p.w1p = (const half_t*)w1p; p.b1 = b1; p.t1n = (half_t*)t1n; p.x0 = (const half_t*)x0; p.wsc = (const half_t*)wsc;
-  p.M = n * h * w; p.H = h; p.W = w; p.Hp = h + 2; p.Wp = w + 2;
+  p.M = n * h * w; p.H = h; p.W = w; p.Hp = h + 2; p.Wp = w + 2; p.CB = width / 64;
   return launch_bneck_tail(p, (hipStream_t)stream);
 }
 

@@ -109,7 +109,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_tensor_name.argtypes = [vp, i32, C.c_char_p]
     lib.rs_engine_net_shape.argtypes = [vp, i32p, i32p, i32p, i32p]
     lib.rs_op_conv2d.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 17 + [vp]
-    lib.rs_op_bneck_tail.argtypes = [vp] * 12 + [i32, i32, i32, vp]
+    lib.rs_op_bneck_tail.argtypes = [vp] * 12 + [i32, i32, i32, i32, vp]
     lib.rs_op_conv2d_dual.argtypes = [vp, vp, vp, vp, vp] + [i32] * 19 + [vp]
     lib.rs_op_conv2d_dgrad.argtypes = [vp] * 7 + [i32] * 14 + [vp]
     lib.rs_op_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i32] * 13 + [vp]

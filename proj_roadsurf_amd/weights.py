@@ -224,16 +224,18 @@ def _ohwi(w: np.ndarray, cin_pad: int, dtype=np.float16) -> np.ndarray:
     return out.astype(dtype)
 
 
-def _perm_k64(w: np.ndarray) -> np.ndarray:
-    """K columns of a [Cout][K] GEMM weight (K % 64 == 0) in the order csrc/bneck_fused.hip chains GEMMs through registers:
-    inside every group of 64 input channels, logical column 32 s + 8 q + j holds channel 16 q + 8 s + j (s < 2, q < 4, j < 8)
-    -- the channels a lane's accumulators 2s, 2s+1 of the PREVIOUS GEMM hold, in the MFMA B-operand's k order."""
+def _perm_k64(w: np.ndarray, group: int = 64) -> np.ndarray:
+    """K columns of a [Cout][K] GEMM weight (K % group == 0) in the order csrc/bneck_fused.hip chains GEMMs through registers:
+    inside every group of ``group`` input channels (64, or 128 for the conv3 of the 128-wide stage, whose producer leaves
+    group/4 consecutive channels in each lane), logical column 32 s + 8 q + j holds channel (group/4) q + 8 s + j
+    (s < group/32, q < 4, j < 8) -- the channels a lane's accumulators 2s, 2s+1 of the PREVIOUS GEMM hold, in the MFMA
+    B-operand's k order."""
     cout, k = w.shape
-    assert k % 64 == 0
-    kappa = np.arange(64)
+    assert k % group == 0 and group % 32 == 0
+    kappa = np.arange(group)
     s, q, j = kappa // 32, (kappa // 8) % 4, kappa % 8
-    src = 16 * q + 8 * s + j
-    return np.ascontiguousarray(w.reshape(cout, k // 64, 64)[:, :, src].reshape(cout, k))
+    src = (group // 4) * q + 8 * s + j
+    return np.ascontiguousarray(w.reshape(cout, k // group, group)[:, :, src].reshape(cout, k))
 
 
 def _pad_rows(w: np.ndarray, b: np.ndarray, mult: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -283,11 +285,13 @@ def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], w_dtype=np.float1
     # fused bottleneck tails (fp16 path, 64-wide stage = res2): identity blocks run conv2 + conv3 + the next block's conv1 in one
     # launch with the later GEMMs' K columns in the register-chaining order (csrc/bneck_fused.hip)
     if w_dtype == np.float16 and spec.num_groups * spec.width_per_group == 64 and spec.res2_out_channels == 256:
-        for bi in range(spec.res_blocks[0]):
-            blk = f"backbone.bottom_up.res2.{bi}"
-            T[blk + ".conv3p.w"] = _perm_k64(T[blk + ".conv3.w"])        # block 0: beside its projection shortcut (.shortcut.w, natural K order)
-            if bi >= 1:
-                T[blk + ".conv1p.w"] = _perm_k64(T[blk + ".conv1.w"])
+        for si, width in ((0, 64), (1, 128)):          # res2 (64 -> 256) and res3 (128 -> 512)
+            for bi in range(spec.res_blocks[si]):
+                blk = f"backbone.bottom_up.res{si + 2}.{bi}"
+                if bi >= 1 or si == 0:                   # res2.0: beside its projection shortcut (.shortcut.w, natural K order)
+                    T[blk + ".conv3p.w"] = _perm_k64(T[blk + ".conv3.w"], width)
+                if bi >= (1 if si == 0 else 2):
+                    T[blk + ".conv1p.w"] = _perm_k64(T[blk + ".conv1.w"], 64)
     # RPN heads fused into one 1x1 conv: rows [0,A) objectness, [A,5A) deltas (a*4+d), padded to 16
     p = "proposal_generator.rpn_head."
     w = np.concatenate([W[p + "objectness_logits.weight"], W[p + "anchor_deltas.weight"]], 0).astype(np.float32)

@@ -338,38 +338,40 @@ def test_conv_f32_mfma_upsample_add_and_deconv(gpu_required):
 # registers, against the same chain in torch fp32 with the intermediate maps rounded to fp16 where the engine stores or
 # forwards them as fp16 (t2, out).
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,hw,with_next,proj", [(2, (20, 28), True, False), (1, (17, 23), False, False), (3, (8, 8), True, False),
-                                                  (2, (19, 27), True, True), (1, (33, 16), False, True)])
-def test_bneck_tail_fused_vs_torch(gpu_required, n, hw, with_next, proj):
+@pytest.mark.parametrize("n,hw,with_next,proj,width", [(2, (20, 28), True, False, 64), (1, (17, 23), False, False, 64), (3, (8, 8), True, False, 64),
+                                                        (2, (19, 27), True, True, 64), (1, (33, 16), False, True, 64),
+                                                        (2, (18, 22), True, False, 128), (1, (25, 13), False, False, 128)])
+def test_bneck_tail_fused_vs_torch(gpu_required, n, hw, with_next, proj, width):
     from proj_roadsurf_amd.weights import _perm_k64
     lib = load_library()
     dev = torch.device("cuda:0")
     torch.manual_seed(n * 100 + hw[0])
     h, w = hw
-    t1 = _r16(torch.relu(torch.randn(n, 64, h, w)))
-    x = _r16(torch.relu(torch.randn(n, 64 if proj else 256, h, w)))      # proj: the 64-channel input of a projection shortcut
-    wsc = _r16(torch.randn(256, 64, 1, 1) / 8.0)
-    w2 = _r16(torch.randn(64, 64, 3, 3) / 24.0)
-    w3 = _r16(torch.randn(256, 64, 1, 1) / 8.0)
-    w1 = _r16(torch.randn(64, 256, 1, 1) / 16.0)
-    b2, b3, b1 = torch.randn(64) * 0.1, torch.randn(256) * 0.1, torch.randn(64) * 0.1
+    cb, c4 = width, 4 * width
+    t1 = _r16(torch.relu(torch.randn(n, cb, h, w)))
+    x = _r16(torch.relu(torch.randn(n, 64 if proj else c4, h, w)))      # proj: the 64-channel input of a projection shortcut
+    wsc = _r16(torch.randn(c4, 64, 1, 1) / 8.0)
+    w2 = _r16(torch.randn(cb, cb, 3, 3) / (3.0 * cb ** 0.5))
+    w3 = _r16(torch.randn(c4, cb, 1, 1) / cb ** 0.5)
+    w1 = _r16(torch.randn(cb, c4, 1, 1) / c4 ** 0.5)
+    b2, b3, b1 = torch.randn(cb) * 0.1, torch.randn(c4) * 0.1, torch.randn(cb) * 0.1
     t2 = _r16(torch.relu(F.conv2d(t1, w2, b2, padding=1)))
     out = _r16(torch.relu(F.conv2d(t2, w3, b3) + (F.conv2d(x, wsc) if proj else x)))
     t1n = torch.relu(F.conv2d(out, w1, b1))
     t1d = _halo(t1.permute(0, 2, 3, 1).half().contiguous(), 1).to(dev)
     xd = _halo(x.permute(0, 2, 3, 1).half().contiguous(), 1).to(dev)
-    outd = torch.zeros((n, h + 2, w + 2, 256), dtype=torch.float16, device=dev)
-    t1nd = torch.zeros((n, h + 2, w + 2, 64), dtype=torch.float16, device=dev)
-    w2d = torch.from_numpy(_ohwi(w2.numpy(), 64)).to(dev)
-    w3d = torch.from_numpy(_perm_k64(_ohwi(w3.numpy(), 64))).to(dev)
-    w1d = torch.from_numpy(_perm_k64(_ohwi(w1.numpy(), 256))).to(dev)
+    outd = torch.zeros((n, h + 2, w + 2, c4), dtype=torch.float16, device=dev)
+    t1nd = torch.zeros((n, h + 2, w + 2, cb), dtype=torch.float16, device=dev)
+    w2d = torch.from_numpy(_ohwi(w2.numpy(), cb)).to(dev)
+    w3d = torch.from_numpy(_perm_k64(_ohwi(w3.numpy(), cb), cb)).to(dev)
+    w1d = torch.from_numpy(_perm_k64(_ohwi(w1.numpy(), c4), 64)).to(dev)
     wscd = torch.from_numpy(_ohwi(wsc.numpy(), 64)).to(dev)
     b2d, b3d, b1d = b2.to(dev), b3.to(dev), b1.to(dev)
     torch.cuda.synchronize()
     P = lambda t: C.c_void_p(t.data_ptr())
     rc = lib.rs_op_bneck_tail(P(t1d), P(w2d), P(b2d), P(w3d), P(b3d), None if proj else P(xd), P(outd), P(w1d) if with_next else None,
                               P(b1d) if with_next else None, P(t1nd) if with_next else None, P(xd) if proj else None, P(wscd) if proj else None,
-                              n, h, w, None)
+                              n, h, w, width, None)
     _check(lib, rc, "rs_op_bneck_tail")
     torch.cuda.synchronize()
     go = outd.cpu().float()

@@ -67,7 +67,7 @@ def conv_stage_shapes(spec, net_h=800, net_w=800):
             s1 = stride if spec.stride_in_1x1 else 1
             oh, ow = ch // stride, cw // stride
             proj = cur_c != cout
-            tail = bott == 64 and cout == 256 and stride == 1     # fused tail of the 64-wide stage (csrc/bneck_fused.hip), variant 13
+            tail = stride == 1 and ((bott == 64 and cout == 256) or (bott == 128 and cout == 512 and bi > 0))    # fused tails (csrc/bneck_fused.hip), variant 13
             if not have_t1:
                 out.append((nm + ".conv1", (ch // s1) * (cw // s1), cur_c, 1, bott, 0, None))
             have_t1 = False
