@@ -101,6 +101,7 @@ def main():
                          "one batch's latency-bound detection glue overlaps the next batch's convolutions")
     ap.add_argument("--profile-mode", type=int, default=3,
                     help="HIP-event stage timing during the timed steps: 3 = every 4th step (default), 2 = every step, 0 = off")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the reference-precision (fp32 MFMA) measurement")
     ap.add_argument("--sustain-seconds", type=float, default=5.0,
                     help="after the K timed steps, keep stepping for this long and report `sustained_tiles_per_s` (clocks settle "
                          "after a few seconds of load); 0 = skip (profiler runs)")
@@ -214,6 +215,34 @@ def main():
     nprop = eng.tensor("proposal_count", n=B)
     ndet = [len(d) for d in dets]
 
+    # Reference-precision mode (every conv / linear layer in fp32 on v_mfma_f32_16x16x4_f32, csrc/ref_f32.hip): the like-for-like
+    # number against the reference's fp32 arithmetic; rank 0 only, a few steps (a step is ~16x the fp16 step's matrix work).
+    fp32_mode = None
+    if rank == 0 and not args.no_fp32_mode:
+        from proj_roadsurf_amd.engine import Engine
+        pipe.sync()
+        e32 = Engine(spec.replace(precision="fp32"), W, (T, T, C_in), max_batch=B, device=local_rank)
+        try:
+            p32 = e32.upload_tiles(tiles)
+            e32.infer_device(p32, B)
+            e32.sync()
+            e32.set_profiling(2)
+            n32 = 3
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            for _ in range(n32):
+                e32.infer_device(p32, B)
+            e32.sync()
+            d32 = (time.perf_counter() - t32) / n32
+            st32 = [s for s in e32.stage_times() if s["flops"] > 0 and s["calls"] > 0]
+            fl32 = sum(s["flops"] for s in st32)
+            ms32 = sum(s["ms_total"] / s["calls"] for s in st32)
+            fp32_mode = {"tiles_per_s": B / d32, "ms_per_step": d32 * 1e3, "whole_path_tflops": fl32 / d32 / 1e12,
+                         "matrix_stages_tflops": fl32 / (ms32 * 1e-3) / 1e12 if ms32 else None, "peak_tflops": 157.3,
+                         "frac_of_fp32_matrix_peak": (fl32 / (ms32 * 1e-3) / 1e12 / 157.3) if ms32 else None,
+                         "kernel": "conv_f32_mfma_kernel (v_mfma_f32_16x16x4_f32, exact fp32)", "steps": n32}
+        finally:
+            e32.close()
     if rank == 0:
         value = world * B * args.steps / dt
         # dominant kernel: conv_igemm 128x128 variant = every conv stage with Cout % 128 == 0
@@ -278,6 +307,8 @@ def main():
             "sustained_tiles_per_s": sustained["tiles_per_s"] if sustained else None,
             "sustained": sustained,
             "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+            "fp32_mode": fp32_mode,
+            "fp32_mode_tiles_per_s": fp32_mode["tiles_per_s"] if fp32_mode else None,
             "pcie_inclusive_tiles_per_s": pcie_tiles_per_s,
             "top_stages": [{"name": s["name"], "ms_per_step": s["ms_total"] / max(s["calls"], 1)} for s in by_time[:6]],
         }

@@ -198,6 +198,15 @@ int rs_op_bneck_tail(const void* t1, const void* w2, const float* b2, const void
                      const void* w1p, const float* b1, void* t1n, const void* x0, const void* wsc, int n, int h, int w, int width,
                      void* stream);     /* width: 64 (as written above) or 128 (every 64 / 256 / 576 above doubled; no projection form) */
 
+/* Raster voting: the overlay of R:scripts/road_segmentation/determine_class.py:97-120 on the tile grid.
+ * det_masks [n_det][h][ceil(w/8)] and label_masks [n_labels][same] are bit-packed device buffers (rs_dets.masks layout; h*ceil(w/8)
+ * must be a multiple of 4); inter [n_labels][n_det] receives the pixel count of every (label, detection) intersection, label_area
+ * [n_labels] every label's own pixel count (device buffers).  rs_engine_label_overlap runs it on the masks of tile `tile` of the
+ * engine's last forward (n_det = D slots; only the first count[tile] columns are meaningful) on the engine's stream. */
+int rs_op_mask_overlap(const uint8_t* det_masks, int n_det, const uint8_t* label_masks, int n_labels, int h, int w, int32_t* inter,
+                       int32_t* label_area, void* stream);
+int rs_engine_label_overlap(rs_engine* e, int tile, const uint8_t* label_masks_dev, int n_labels, int32_t* inter_dev, int32_t* label_area_dev);
+
 /* The tile variant launch_conv would pick for a conv / linear layer of this shape (no launch, no GPU needed): m = batch *
  * Ho * Wo output pixels, k x k taps over cin channels (+ cin2 channels of a second 1x1 K source, 0 = none), cout channels,
  * deconv2x as in rs_op_conv2d.  The choice depends on m, i.e. on the batch size: tests enumerate it per layer and batch

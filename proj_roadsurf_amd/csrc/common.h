@@ -142,6 +142,9 @@ struct BneckParams {
 };
 int launch_bneck_tail(const BneckParams& p, hipStream_t stream);
 
+// ------------------------------------------------------------------ raster voting (raster_vote.hip)
+int launch_mask_overlap(const uint8_t* det, int n_det, const uint8_t* lab, int n_lab, int h, int w, int* inter, int* lab_area, hipStream_t s);
+
 // ------------------------------------------------------------------ training: weight gradient (conv_wgrad.hip)
 struct WgradParams {
   const half_t* dy;     // gradient of the layer output, [N][Ho+2*dy_pad][Wo+2*dy_pad][dy_Cs] fp16, zero halo

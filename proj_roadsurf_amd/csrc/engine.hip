@@ -1392,6 +1392,19 @@ int rs_op_bneck_tail(const void* t1, const void* w2, const float* b2, const void
   return launch_bneck_tail(p, (hipStream_t)stream);
 }
 
+int rs_op_mask_overlap(const uint8_t* det_masks, int n_det, const uint8_t* label_masks, int n_labels, int h, int w, int32_t* inter,
+                       int32_t* label_area, void* stream) {
+  return launch_mask_overlap(det_masks, n_det, label_masks, n_labels, h, w, inter, label_area, (hipStream_t)stream);
+}
+
+// the same on the detection masks of tile `tile` of the engine's last forward (all D slots; slots >= count hold stale canvases,
+// the caller reads the first count[tile] columns)
+int rs_engine_label_overlap(rs_engine* e, int tile, const uint8_t* label_masks_dev, int n_labels, int32_t* inter_dev, int32_t* label_area_dev) {
+  RS_CHECK(e && e->masks && tile >= 0 && tile < e->max_batch && label_masks_dev && inter_dev && label_area_dev, RS_ERR_ARG, "bad argument");
+  const size_t per = (size_t)e->tile_h * ((e->tile_w + 7) / 8);
+  return launch_mask_overlap(e->masks + (size_t)tile * e->D * per, e->D, label_masks_dev, n_labels, e->tile_h, e->tile_w, inter_dev, label_area_dev, e->stream);
+}
+
 int rs_op_conv2d_dgrad(const void* dy, const void* w_t, void* dx, const void* res, const float* res32, const void* mask,
                        const void* down, int n, int hi, int wi, int cin, int ho, int wo, int cout, int kh, int kw, int stride,
                        int pad, int kpad, int halo, int variant, void* stream) {
