@@ -45,9 +45,10 @@ struct RsDebug {
   int conv_persist = 0;           // RS_CONV_PERSIST          1: shallow-K layers persistent, 2: all (measured: not faster)
   int conv_tuned = 1;             // RS_CONV_TUNED            0: first-round tile rule (128x128 / 256x64 only)
   int conv_deep = 1;              // RS_CONV_DEEP             0: conv_igemm 256x256 instead of conv_deep
+  int conv_wide_px = 128;         // RS_CONV_WIDE_PX          pixels of the all-256-channel tile of the HBM-bound 1x1 layers: 128 (variant 14) or 64 (10)
   int stem_small_tile = 1;        // RS_STEM_SMALL_TILE       0: 256x64 stem tile
   int deep_dbg = 0;               // RS_DEEP_DBG              -DRS_DEEP_CEILING builds only
-  int deconv_variant = 10;        // RS_DECONV_VARIANT        tile of the fused deconv + predictor
+  int deconv_variant = 14;        // RS_DECONV_VARIANT        tile of the fused deconv + predictor: 128x256 (14), 64x256 (10) or 128x128 (0)
   int fuse_mask_predictor = 1;    // RS_FUSE_MASK_PREDICTOR
   int side_stream = 1;            // RS_SIDE_STREAM           detection glue on a side stream
   int narrow_roialign = 0;        // RS_NARROW_ROIALIGN
