@@ -549,8 +549,8 @@ class LanePipeline:
 
     def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], max_batch: int = 16,
                  device: int = 0, lanes: int = 2):
-        if lanes not in (1, 2):
-            raise ValueError("lanes must be 1 or 2")
+        if lanes not in (1, 2, 3, 4):
+            raise ValueError("lanes must be 1..4")
         first = Engine(spec, weights, tile_shape, max_batch, device)
         self.engines = [first] + [Engine(spec, weights, tile_shape, max_batch, device, stream=first.stream) for _ in range(lanes - 1)]
         self.k = 0
