@@ -328,6 +328,12 @@ void rs_trainer_destroy(rs_trainer* t);
 rs_engine* rs_trainer_engine(rs_trainer* t);
 int rs_trainer_forward_trunk(rs_trainer* t, const uint8_t* tiles_dev, int n);
 int rs_trainer_backward_trunk(rs_trainer* t, int n);
+/* Batches of mixed sizes (INPUT.MIN_SIZE_TRAIN with MIN_SIZE_TRAIN_SAMPLING "choice" drawn per image,
+ * R:config/detectron2_config_3bands.yaml:31-38; [EXT d2: data/dataset_mapper.py + structures/image_list.py ImageList.from_tensors]):
+ * image i of the coming batches is resized to new_h[i] x new_w[i] (<= the trainer's network-input size, which is the canvas = the
+ * largest size of the batch), the canvas is zero beyond it, and its proposals are clipped to that size.  n = 0 restores one size
+ * for all.  Ground truth passed to rs_trainer_set_targets is in each image's own resized pixels. */
+int rs_trainer_set_image_sizes(rs_trainer* t, const int32_t* new_h, const int32_t* new_w, int n);
 /* Ground truth of the batch (host pointers): boxes in network-input pixels [n][cap][4], classes [n][cap], counts [n]. */
 int rs_trainer_set_targets(rs_trainer* t, const float* gt_boxes, const int32_t* gt_classes, const int32_t* gt_count, int n, int cap);
 /* RPN of the training forward + RPN.losses + its backward: heads on the current FPN maps, anchor Matcher (0.3/0.7, low-quality

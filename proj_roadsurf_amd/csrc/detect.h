@@ -14,6 +14,7 @@ struct RpnParams {
   int L, A, N, cs;
   int topk;                 // PRE_NMS_TOPK_TEST (<= 1024)
   float img_h, img_w;       // clip size = resized image size
+  const float* img_hw;      // optional [N][2] (h, w): clip size per image (training batches of mixed sizes); null = img_h / img_w
   float wx, wy, ww, wh, scale_clamp, min_size;
   float* cand_boxes;        // [N][L][1024][4]
   float* cand_scores;       // [N][L][1024]

@@ -251,10 +251,11 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
     float d[4] = {dp[0], dp[1], dp[2], dp[3]};
     float b[4];
     apply_deltas(anc, d, p.wx, p.wy, p.ww, p.wh, p.scale_clamp, b);
-    b[0] = clampf(b[0], 0.f, p.img_w);
-    b[1] = clampf(b[1], 0.f, p.img_h);
-    b[2] = clampf(b[2], 0.f, p.img_w);
-    b[3] = clampf(b[3], 0.f, p.img_h);
+    const float ih = p.img_hw ? p.img_hw[2 * n] : p.img_h, iw = p.img_hw ? p.img_hw[2 * n + 1] : p.img_w;
+    b[0] = clampf(b[0], 0.f, iw);
+    b[1] = clampf(b[1], 0.f, ih);
+    b[2] = clampf(b[2], 0.f, iw);
+    b[3] = clampf(b[3], 0.f, ih);
     float* ob4 = p.cand_boxes + (ob + ti) * 4;
     ob4[0] = b[0]; ob4[1] = b[1]; ob4[2] = b[2]; ob4[3] = b[3];
     p.cand_scores[ob + ti] = score;

@@ -172,6 +172,14 @@ struct rs_engine {
   std::vector<Stage> stages;
 
   uint8_t* tiles_dev = nullptr;
+  // per-image resized sizes inside the net_h x net_w canvas (training: INPUT.MIN_SIZE_TRAIN drawn per image, the batch padded to the
+  // largest -- [EXT d2: data/dataset_mapper.py, structures/image_list.py]); empty = every image fills the canvas
+  struct ResizeTab { int* b = nullptr; int* k = nullptr; int ks = 0; };
+  std::map<int, ResizeTab> tab_h, tab_v;   // by output size
+  std::vector<int> img_new_h, img_new_w;
+  float* img_hw_dev = nullptr;             // [max_batch][2] clip size of the proposals per image (h, w)
+  int resize_tab(int in_size, int out_size, std::map<int, ResizeTab>& cache, ResizeTab* out);
+  int set_image_sizes(const int32_t* new_h, const int32_t* new_w, int n);
   // results (device)
   int* det_count = nullptr;
   float* det_boxes = nullptr;
@@ -342,6 +350,48 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
   return RS_OK;
 }
 
+int rs_engine::resize_tab(int in_size, int out_size, std::map<int, ResizeTab>& cache, ResizeTab* out) {
+  auto it = cache.find(out_size);
+  if (it == cache.end()) {
+    ResizeTab t;
+    t.ks = rs_resize_coeffs(in_size, out_size, nullptr, nullptr);
+    std::vector<int32_t> b((size_t)out_size * 2), k((size_t)out_size * t.ks);
+    rs_resize_coeffs(in_size, out_size, b.data(), k.data());
+    int rc;
+    if ((rc = alloc((void**)&t.b, b.size() * 4))) return rc;
+    if ((rc = alloc((void**)&t.k, k.size() * 4))) return rc;
+    RS_HIP(hipMemcpyAsync(t.b, b.data(), b.size() * 4, hipMemcpyHostToDevice, stream));
+    RS_HIP(hipMemcpyAsync(t.k, k.data(), k.size() * 4, hipMemcpyHostToDevice, stream));
+    RS_HIP(hipStreamSynchronize(stream));          // the host vectors go out of scope
+    it = cache.emplace(out_size, t).first;
+  }
+  *out = it->second;
+  return RS_OK;
+}
+
+// n = 0: every image fills the canvas again
+int rs_engine::set_image_sizes(const int32_t* new_h, const int32_t* new_w, int n) {
+  RS_CHECK(n >= 0 && n <= max_batch, RS_ERR_ARG, "set_image_sizes: %d images, engine built for %d", n, max_batch);
+  std::vector<float> hw((size_t)max_batch * 2);
+  for (int i = 0; i < max_batch; ++i) { hw[2 * i] = (float)net_h; hw[2 * i + 1] = (float)net_w; }
+  for (int i = 0; i < n; ++i) {
+    RS_CHECK(new_h[i] >= 1 && new_h[i] <= net_h && new_w[i] >= 1 && new_w[i] <= net_w, RS_ERR_ARG,
+             "image %d: %d x %d does not fit the %d x %d canvas", i, new_h[i], new_w[i], net_h, net_w);
+    hw[2 * i] = (float)new_h[i]; hw[2 * i + 1] = (float)new_w[i];
+  }
+  for (int i = 0; i < n; ++i) {                     // build the tables now: the stage itself must not synchronise
+    ResizeTab t;
+    int rc;
+    if ((rc = resize_tab(tile_w, new_w[i], tab_h, &t))) return rc;
+    if ((rc = resize_tab(tile_h, new_h[i], tab_v, &t))) return rc;
+  }
+  img_new_h.assign(new_h, new_h + n);
+  img_new_w.assign(new_w, new_w + n);
+  RS_HIP(hipMemcpyAsync(img_hw_dev, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, stream));
+  RS_HIP(hipStreamSynchronize(stream));
+  return RS_OK;
+}
+
 int rs_engine::build() {
   const rs_spec& S = spec;
   const int NB = max_batch;
@@ -392,11 +442,34 @@ int rs_engine::build() {
     st.name = "preprocess";
     st.bytes_per_image = (double)tile_h * tile_w * tile_c + (double)net_h * net_w * 8;
     pp.tiles = tiles_dev;
-    st.fn = [pp](int n, hipStream_t s) mutable {
-      pp.N = n;
-      return launch_preprocess(pp, s);
+    const size_t x0_bytes = (size_t)NB * x0.Hp() * x0.Wp() * 4 * (f32 ? 4 : 2);
+    st.fn = [this, pp, x0_bytes](int n, hipStream_t s) mutable {
+      if (img_new_h.empty()) {
+        pp.N = n;
+        return launch_preprocess(pp, s);
+      }
+      // images of different sizes in one canvas: zeros (the padding value of ImageList.from_tensors) outside each image
+      RS_CHECK((int)img_new_h.size() >= n, RS_ERR_ARG, "per-image sizes set for %d images, batch of %d", (int)img_new_h.size(), n);
+      RS_HIP(hipMemsetAsync((void*)pp.out, 0, x0_bytes, s));
+      for (int i = 0; i < n; ++i) {
+        PreprocParams q = pp;
+        ResizeTab th, tv;
+        int rc;
+        if ((rc = resize_tab(tile_w, img_new_w[i], tab_h, &th))) return rc;
+        if ((rc = resize_tab(tile_h, img_new_h[i], tab_v, &tv))) return rc;
+        q.N = 1;
+        q.tiles = pp.tiles + (size_t)i * tile_h * tile_w * tile_c;
+        q.out = (half_t*)((char*)pp.out + (size_t)i * (x0_bytes / max_batch));
+        q.new_h = img_new_h[i]; q.new_w = img_new_w[i];
+        q.need_h = q.new_w != tile_w; q.need_v = q.new_h != tile_h;
+        q.hb = th.b; q.hk = th.k; q.ksh = th.ks; q.vb = tv.b; q.vk = tv.k; q.ksv = tv.ks;
+        if ((rc = launch_preprocess(q, s))) return rc;
+      }
+      return RS_OK;
     };
     stages.push_back(st);
+    if ((rc = alloc((void**)&img_hw_dev, (size_t)NB * 8))) return rc;
+    if ((rc = set_image_sizes(nullptr, nullptr, 0))) return rc;
   }
 
   // ---- stem

@@ -730,6 +730,7 @@ class Trainer:
         lib.rs_trainer_backward_trunk.argtypes = [vp, i32]
         lib.rs_trainer_apply_sgd.argtypes = [vp, C.c_float, C.c_float, C.c_float]
         lib.rs_trainer_set_targets.argtypes = [vp, vp, vp, vp, i32, i32]
+        lib.rs_trainer_set_image_sizes.argtypes = [vp, vp, vp, i32]
         lib.rs_trainer_rpn_step.argtypes = [vp, i32, C.c_uint32, i32]
         lib.rs_trainer_rpn_forward.argtypes = [vp, i32]
         lib.rs_trainer_roi_step.argtypes = [vp, i32, C.c_uint32]
@@ -829,6 +830,27 @@ class Trainer:
         _check(self.lib, self.lib.rs_trainer_set_targets(self._h, bx.ctypes.data_as(C.c_void_p), cl.ctypes.data_as(C.c_void_p),
                                                          cnt.ctypes.data_as(C.c_void_p), n, cap), "rs_trainer_set_targets")
 
+    def set_image_sizes(self, sizes: Optional[Sequence[int]]) -> List[Tuple[int, int]]:
+        """``INPUT.MIN_SIZE_TRAIN`` drawn PER IMAGE (R:config/detectron2_config_3bands.yaml:31-38; [EXT d2: DatasetMapper ->
+        ResizeShortestEdge per record, ImageList.from_tensors pads the batch to its largest image]): image i of the coming
+        batches is resized to shortest edge ``sizes[i]`` inside this trainer's canvas (whose own size must be the largest of the
+        batch), zeros beyond it, proposals clipped to it.  ``None`` / empty: one size for all again.  Returns the (h, w) per
+        image -- ground truth of image i is in THOSE pixels."""
+        from .spec import resize_shortest_edge_shape
+        if not sizes:
+            _check(self.lib, self.lib.rs_trainer_set_image_sizes(self._h, None, None, 0), "rs_trainer_set_image_sizes")
+            self._image_sizes = None
+            return []
+        hw = [resize_shortest_edge_shape(self.tile_h, self.tile_w, int(s), self.spec.max_size_test) for s in sizes]
+        if list(sizes) == getattr(self, "_image_sizes", None):
+            return hw
+        nh = np.asarray([h for h, _ in hw], np.int32)
+        nw = np.asarray([w for _, w in hw], np.int32)
+        _check(self.lib, self.lib.rs_trainer_set_image_sizes(self._h, nh.ctypes.data_as(C.c_void_p), nw.ctypes.data_as(C.c_void_p), len(hw)),
+               "rs_trainer_set_image_sizes")
+        self._image_sizes = list(sizes)
+        return hw
+
     def rpn_step(self, n: int, seed: int = 1, external_labels: bool = False) -> None:
         _check(self.lib, self.lib.rs_trainer_rpn_step(self._h, n, seed & 0xFFFFFFFF, int(external_labels)), "rs_trainer_rpn_step")
 
@@ -868,12 +890,16 @@ class Trainer:
 
     # ------------------------------------------------------------------ a whole step
     def train_step(self, tiles: np.ndarray, gt_boxes: Sequence[np.ndarray], gt_classes: Sequence[np.ndarray],
-                   gt_polygons: Optional[Sequence[Sequence[Sequence[np.ndarray]]]], seed: int, allreduce: bool = False) -> Dict[str, float]:
+                   gt_polygons: Optional[Sequence[Sequence[Sequence[np.ndarray]]]], seed: int, allreduce: bool = False,
+                   sizes: Optional[Sequence[int]] = None) -> Dict[str, float]:
         """Forward + losses + backward of one batch (``SimpleTrainer.run_step`` up to ``losses.backward()``): gradients end
         up in the flat gradient buffer; returns the five losses.  ``gt_*`` in NETWORK-INPUT pixels.  ``allreduce``: enqueue
         the data-parallel gradient all-reduce (``allreduce_gradients``) behind the backward pass before the losses are read
-        back, so that the collectives of the early buckets overlap the rest of the backward."""
+        back, so that the collectives of the early buckets overlap the rest of the backward.  ``sizes``: shortest-edge size
+        per image (``set_image_sizes``); ``None`` keeps whatever was set last."""
         n = int(tiles.shape[0])
+        if sizes is not None:
+            self.set_image_sizes(sizes if any(int(s) != self.spec.min_size_test for s in sizes) else None)
         self.set_targets(gt_boxes, gt_classes)
         self.forward_trunk(self.upload_tiles(tiles), n)
         self.rpn_forward(n)
@@ -1027,9 +1053,10 @@ class Trainer:
 
 class MultiScaleTrainer:
     """``INPUT.MIN_SIZE_TRAIN`` with ``MIN_SIZE_TRAIN_SAMPLING: choice`` (R:31-38): one ``Trainer`` per shortest-edge size,
-    built lazily; each batch runs at one randomly chosen size (detectron2 draws the size per image and pads the batch to the
-    largest -- with the reference's 1 image per GPU, IMS_PER_BATCH 8 on 8 GPUs, that is the same thing) and the optimiser state
-    follows the batch from trainer to trainer (``rs_trainer_copy_state``)."""
+    built lazily.  detectron2 draws the size per image and pads the batch to its largest image: ``select_batch(sizes)`` picks
+    the trainer of the largest drawn size (the canvas) and hands it the per-image sizes (``Trainer.set_image_sizes``); with one
+    image per GPU that is one size per batch.  The optimiser state follows the batch from trainer to trainer
+    (``rs_trainer_copy_state``)."""
 
     def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], sizes: Sequence[int], batch: int = 1,
                  device: int = 0, loss_scale: float = 1024.0):
@@ -1067,7 +1094,15 @@ class MultiScaleTrainer:
         t = self._t[size]
         if self.current is not None and self.current is not t:
             t.copy_state_from(self.current)
+        if getattr(t, "_image_sizes", None):
+            t.set_image_sizes(None)              # one size for the whole batch unless select_batch says otherwise
         self.current = t
+        return t
+
+    def select_batch(self, sizes: Sequence[int]) -> Trainer:
+        """The trainer for a batch whose image i was drawn at shortest edge ``sizes[i]``."""
+        t = self.select(max(int(s) for s in sizes))
+        t.set_image_sizes(list(sizes) if len(set(int(s) for s in sizes)) > 1 else None)
         return t
 
     def net_shape(self, size: int) -> Tuple[int, int]:

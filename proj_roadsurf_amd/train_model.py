@@ -16,8 +16,9 @@ What follows the reference / detectron2 0.6 and where it is pinned:
     checkpoint every CHECKPOINT_PERIOD  [EXT d2: solver/build.py, engine/defaults.py];
   * data parallel: one process per GPU, gradients all-reduced over RCCL/xGMI in one flat 175 MB fp32 buffer and averaged
     (DistributedDataParallel semantics).
-Documented deviations: MIN_SIZE_TRAIN's multi-scale "choice" (R:31-38) is drawn once per BATCH, not per image
-(identical at the reference's one image per GPU), fp16 activations/weights with fp32 master weights and dynamic loss scaling (GradScaler's policy) instead of fp32 everywhere, the
+MIN_SIZE_TRAIN's multi-scale "choice" (R:31-38) is drawn per image and the batch padded to its largest image, as DatasetMapper +
+ImageList.from_tensors do (``MultiScaleTrainer.select_batch``).
+Documented deviations: fp16 activations/weights with fp32 master weights and dynamic loss scaling (GradScaler's policy) instead of fp32 everywhere, the
 model-zoo URL of ``model_weights.model_zoo_checkpoint_url`` cannot be fetched offline (use ``model_weights.pth_file`` or
 ``--synthetic-weights``).  Every TEST.EVAL_PERIOD iterations the validation loss and the COCO bbox / segm AP (coco_eval.py, a
 restatement of pycocotools' COCOeval) of the `val` set are logged to metrics.json.
@@ -393,26 +394,27 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         """One batch of the DatasetMapper (size draw, sampler, decode, flip, scale): runs on a loader thread one iteration ahead
         of the GPU step.  Only this function touches the sampler and the two RNGs, and batches are requested in order, so the
         stream of batches is the same as without the thread."""
-        size = int(sizes[int(size_rng.integers(len(sizes)))])
-        net_hw = ms.net_shape(size)
-        tiles, boxes, classes, polys = [], [], [], []
+        tiles, boxes, classes, polys, drawn = [], [], [], [], []
         for _ in range(per_rank):
+            # ResizeShortestEdge draws per record ([EXT d2: data/transforms/augmentation_impl.py]); ImageList.from_tensors then pads
+            # the batch to its largest image -- MultiScaleTrainer.select_batch
+            size = int(sizes[int(size_rng.integers(len(sizes)))])
             rec = recs[next(sampler)]
             tile = read_tile(rec["file_name"])
             if tile.shape != first.shape:
                 raise SystemExit(f"{rec['file_name']}: tile shape {tile.shape} != {first.shape} (one shape per run)")
-            t, b, c, p = map_record(rec, tile, net_hw, sv["flip"] == "horizontal" and flips.random() < 0.5)
-            tiles.append(t); boxes.append(b); classes.append(c); polys.append(p)
-        return size, np.stack(tiles), boxes, classes, polys
+            t, b, c, p = map_record(rec, tile, ms.net_shape(size), sv["flip"] == "horizontal" and flips.random() < 0.5)
+            tiles.append(t); boxes.append(b); classes.append(c); polys.append(p); drawn.append(size)
+        return drawn, np.stack(tiles), boxes, classes, polys
 
     from concurrent.futures import ThreadPoolExecutor
     loader = ThreadPoolExecutor(max_workers=1)
     pending = loader.submit(load_batch, 0)
     for it in range(max_iter):
-        size, tile_batch, boxes, classes, polys = pending.result()
+        drawn, tile_batch, boxes, classes, polys = pending.result()
         if it + 1 < max_iter:
             pending = loader.submit(load_batch, it + 1)      # decoded while this iteration's step runs on the GPU
-        trainer = ms.select(size)
+        trainer = ms.select_batch(drawn)
         losses = trainer.train_step(tile_batch, boxes, classes, polys, seed=args.seed * 1000003 + it * world + rank,
                                     allreduce=world > 1)      # bucketed all-reduce enqueued behind the backward pass
         # dynamic fp16 loss scale (GradScaler's policy): the previous step's overflow flag is read here, after this step's own

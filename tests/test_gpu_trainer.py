@@ -574,6 +574,75 @@ def test_multi_scale_state_handover(gpu_required):
         ms.close()
 
 
+def test_per_image_sizes_in_one_batch(gpu_required):
+    """MIN_SIZE_TRAIN drawn per image (R:31-38): a batch of two images at shortest edges 320 and 288 in one 320 canvas -- the
+    network input of image 1 is Pillow's 256 -> 288 resize (the 288-px trainer's own input) with zeros beyond, its training
+    proposals are clipped to 288 (oracle's find_top_rpn_proposals with image_sizes per image), a whole step runs, and the
+    uniform batch comes back with ``set_image_sizes(None)``."""
+    from oracle import maskrcnn_oracle as O
+    from proj_roadsurf_amd.engine import MultiScaleTrainer
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=4242)
+    ms = MultiScaleTrainer(spec, Wn, (256, 256, 3), [288, 320], batch=2, loss_scale=64.0)
+    try:
+        ms.set_sampling(256, 0.5, 128, 0.25)
+        small = ms.select(288)
+        small.forward_trunk(small.upload_tiles(tiles), 2)
+        small.sync()
+        want1 = small.tensor("net_input", engine=True)[1].copy()                       # (288, 288, 4)
+        tr = ms.select_batch([320, 288])
+        assert tr is ms.select(320) and tr is not small
+        tr = ms.select_batch([320, 288])
+        hw = tr.set_image_sizes([320, 288])
+        assert hw == [(320, 320), (288, 288)]
+        gt_boxes = [np.array([[20.0, 30.0, 120.0, 160.0]], np.float32), np.array([[100.0, 100.0, 260.0, 280.0], [10.0, 10.0, 60.0, 50.0]], np.float32)]
+        polys = [[[np.array([b[0], b[1], b[2], b[1], b[2], b[3], b[0], b[3]], np.float64)] for b in bs] for bs in gt_boxes]
+        tr.set_targets(gt_boxes, [np.array([0]), np.array([1, 1])])
+        tr.forward_trunk(tr.upload_tiles(tiles), 2)
+        tr.rpn_forward(2)
+        tr.roi_step(2, seed=1)
+        tr.sync()
+        x = tr.tensor("net_input", engine=True)
+        assert x.shape[1:3] == (320, 320)
+        uniform = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=64.0)
+        try:
+            uniform.forward_trunk(uniform.upload_tiles(tiles), 2)
+            uniform.sync()
+            assert np.array_equal(x[0], uniform.tensor("net_input", engine=True)[0])
+        finally:
+            uniform.close()
+        assert np.array_equal(x[1, :288, :288], want1) and float(np.abs(want1).max()) > 0
+        assert float(np.abs(x[1, 288:]).max()) == 0.0 and float(np.abs(x[1, :, 288:]).max()) == 0.0
+        cand, cc = tr.tensor("roi_candidates"), tr.tensor("roi_candidate_count")
+        A = spec.num_anchors
+        logits, deltas = [], []
+        for l in range(2, 7):
+            h = torch.from_numpy(tr.tensor(f"rpn_head{l}", engine=True))
+            logits.append(h[..., :A].permute(0, 3, 1, 2).contiguous())
+            deltas.append(h[..., A:5 * A].permute(0, 3, 1, 2).contiguous())
+        train_spec = spec.replace(rpn_pre_nms_topk_test=2000, rpn_post_nms_topk_test=1000)
+        props = O.rpn_proposals(train_spec, logits, deltas, [(320, 320), (288, 288)], nms_trick=False)
+        for i in range(2):
+            pb = props[i]["boxes"].numpy()
+            k = pb.shape[0]
+            assert int(cc[i]) == k + gt_boxes[i].shape[0]
+            assert float(np.abs(cand[i, :k] - pb).max()) <= 1e-3
+        assert float(cand[1, :int(cc[1]) - 2].max()) <= 288.0 and float(cand[0, :int(cc[0]) - 1].max()) > 300.0
+        losses = tr.train_step(tiles, gt_boxes, [np.array([0]), np.array([1, 1])], polys, seed=9, sizes=[320, 288])
+        assert all(np.isfinite(v) and v > 0 for v in losses.values()), losses
+        tr.apply_sgd(1e-4, 0.9, 1e-4)
+        assert not tr.overflowed()
+        # back to one size for the batch: image 1 fills the canvas again
+        tr.train_step(tiles, gt_boxes, [np.array([0]), np.array([1, 1])], polys, seed=10, sizes=[320, 320])
+        x2 = tr.tensor("net_input", engine=True)
+        assert float(np.abs(x2[1, 288:]).max()) > 0
+        with pytest.raises(Exception):
+            tr.set_image_sizes([352, 320])                                             # larger than the canvas
+    finally:
+        ms.close()
+
+
 def test_training_mode_proposals_match_oracle(gpu_required):
     """RPN proposals of the TRAINING forward (PRE_NMS_TOPK_TRAIN 2000 per level, NMS 0.7, POST_NMS_TOPK_TRAIN 1000 per image, R:245-250:
     the 2048-capacity select / NMS / merge kernels) against the oracle's find_top_rpn_proposals on the engine's own head outputs,
