@@ -55,6 +55,9 @@ struct RsDebug {
   int use_glds = 1;               // RS_USE_GLDS              0: register staging instead of LDS-DMA
   int fuse_shortcut = 1;          // RS_FUSE_SHORTCUT
   int fuse_bneck = 1;             // RS_FUSE_BNECK            conv2 + conv3 + next conv1 of the res2 identity blocks in one launch
+  int deep_tail = 1;              // RS_DEEP_TAIL             conv_deep: split the tiles of a last round that fills at most half the chip
+  int fuse_rpn_heads = 1;         // RS_FUSE_RPN_HEADS        objectness + delta heads inside the epilogue of the merged RPN 3x3 launch
+  int merge_levels = 1;           // RS_MERGE_LEVELS          FPN output convs of all levels / the RPN 3x3 over all levels as one launch each
   int use_graph = 0;              // RS_USE_GRAPH
   int train_roi_side = -1;        // RS_TRAIN_ROI_SIDE        -1: trainer default
   int train_side = -1;            // RS_TRAIN_SIDE            -1: trainer default (on)
@@ -71,6 +74,20 @@ void rs_debug_reload();
 // Activations are NHWC fp16 with a zero halo: a tensor of logical size (N,H,W,C) is stored as
 // [N][H+2*pad][W+2*pad][Cs] and only the interior is ever written, so 3x3/7x7 convolutions need
 // no bounds checks and the loader is a pure strided gather.
+// One map of a multi-map launch (conv_deep only): the FPN output convolutions of all levels, or the shared RPN 3x3 over p2..p6, as ONE
+// grid -- same Cin / Cout / kernel size / channel pitches / halos, own geometry, tensors and weights per map.  Tiles never straddle maps.
+struct ConvSeg {
+  const half_t* in;
+  const half_t* w;
+  const float* bias;
+  void* out;
+  float* head_out;   // fused head (ConvParams::head_w): [N][Ho][Wo][16] fp32 of this map
+  int Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp;
+  int M;         // rows of this map (set per launch: images * Ho * Wo)
+  int tile0;     // first logical tile of this map (set per launch)
+};
+#define RS_MAX_SEGS 5
+
 struct ConvParams {
   const half_t* in;
   const half_t* w;      // [Cout_pad][Kpad] fp16, K = (kh,kw,cin) with cin fastest
@@ -116,6 +133,15 @@ struct ConvParams {
   long long* probe;     // diagnostic builds only (-DRS_CLOCK_PROBE): per workgroup {shader clocks, 100 MHz ticks} around the K loop
   int persist;          // >0: persistent launch with this many workgroups per CU; -1: per-variant default; 0: one per tile
   int stages;           // LDS K-step buffers: 0/2 = double buffered, 1 = single (set by launch_conv for shallow K)
+  // conv_deep, Cout == 256: a 16-row 1x1 head applied to relu(conv + bias) inside the epilogue (RPN objectness + anchor deltas); `out` is
+  // then NOT written.  head_w: [16][256] fp16 with its K columns in the register-chaining order (weights.py _perm_k64), head_b [16].
+  const half_t* head_w;
+  const float* head_b;
+  float* head_out;      // single-map launch: [N][Ho][Wo][16] fp32
+  int nseg;             // > 0: multi-map launch (launch_conv_deep_multi); in / w / bias / out / geometry / M come from seg[]
+  int seg_tiles;        // total logical tiles of all maps
+  int tail_tiles;       // conv_deep: this many of the LAST logical tiles run as two 128-pixel tiles each (set by the launcher's tail rule)
+  ConvSeg seg[RS_MAX_SEGS];
 };
 
 int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant /* -1 auto */, int use_glds);
@@ -190,3 +216,4 @@ int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int H
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu = 0);   // ref_f32.hip: fp32 MFMA (or the VALU cross-check)
 int launch_conv_deep(const ConvParams& p, hipStream_t stream);
+int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const int* m_per_image, int nseg, int images, hipStream_t stream);

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, NT = 512, MI = 4, NJ = 8, WCH = 4;
+constexpr int BM = 256, BN = 256, NT = 512, MI = 4, WCH = 4;   // NJ (16-pixel blocks per wave) = 8: 256-pixel tile; 4: the 128-pixel tiles of a split last round
 constexpr int ASTAGE = BM * 128, WSTAGE = BN * 128;       // 32 KB each
 constexpr int W_BASE = 3 * ASTAGE;
 constexpr int LDS_BYTES = 3 * ASTAGE + 2 * WSTAGE;        // 160 KB
@@ -28,50 +28,41 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// TRAIN: instantiation with the backward-epilogue options down / res32 / mask (conv_igemm.hip), compiled out of the inference kernel
-template <int DBG, bool TRAIN = false>
-__global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// One tile: NJ * 32 pixels x 256 channels.  TRAIN: instantiation with the backward-epilogue options down / res32 / mask (conv_igemm.hip),
+// compiled out of the inference kernel
+template <int DBG, bool TRAIN, int NJ>
+__device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, const half_t* g_in, const half_t* g_w, const float* g_bias, void* g_out,
+                                               float* g_head_out, const int Ho, const int Wo, const int in_Hp, const int in_Wp, const int out_Hp, const int out_Wp,
+                                               const int M, const int m0, const int n0, const int q) {
+  constexpr int APS = NJ / 2;          // activation staging passes of 64 rows = LDS-DMA pieces per wave and stage
+  constexpr int WPX = NJ * 16;         // pixels per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wpx = wave / WCH, wch = wave % WCH;
-
-  int M = p.M;
-  if (p.m_count) {
-    long long mc = (long long)(*p.m_count) * p.m_mul;
-    if (mc < M) M = (int)mc;
-  }
-  const int tiles_n = p.Cout / BN;
-  const int ntiles = tiles_n * ((M + BM - 1) / BM);
-  const int q = blockIdx.x;
-  if (q >= ntiles) return;
-  int m0, n0;
-  {
-    const int qn = ntiles >> 3, r = ntiles & 7, x = q & 7;      // XCD-aware order, see conv_igemm.hip
-    const int L = (x < r ? x * (qn + 1) : r * (qn + 1) + (x - r) * qn) + (q >> 3);
-    n0 = (L % tiles_n) * BN;
-    m0 = (L / tiles_n) * BM;
-  }
+  (void)q;
 
   // ---- staging pointers (identical to conv_igemm<2,4,4,8>): 4 passes of 64 rows for each operand
   const int lrow = lane >> 3, lchk = lane & 7;
-  const half_t* aptr[4];
+  const half_t* aptr[APS];
   const half_t* wptr[4];
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < APS; ++ps) {
     int m = m0 + ps * 64 + wave * 8 + lrow;
     if (m >= M) m = M - 1;
-    const int x = m % p.Wo;
-    const int t = m / p.Wo;
-    const int y = t % p.Ho;
-    const int n = t / p.Ho;
+    const int x = m % Wo;
+    const int t = m / Wo;
+    const int y = t % Ho;
+    const int n = t / Ho;
     const long long base =
-        ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x * p.stride + p.in_off) * p.in_Cs;
-    aptr[ps] = p.in + base + (lchk ^ lrow) * 8;
+        ((long long)(n * in_Hp + y * p.stride + p.in_off) * in_Wp + x * p.stride + p.in_off) * p.in_Cs;
+    aptr[ps] = g_in + base + (lchk ^ lrow) * 8;
+  }
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
     const int row = ps * 64 + wave * 8 + lrow;
     const int key = (row & 3) | (((row >> 4) & 1) << 2);
-    wptr[ps] = p.w + (long long)(n0 + row) * p.Kpad + (lchk ^ key) * 8;
+    wptr[ps] = g_w + (long long)(n0 + row) * p.Kpad + (lchk ^ key) * 8;
   }
   const int nk = p.KH * p.KW * (p.Cin >> 6);
 
@@ -79,14 +70,14 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   // activation walker runs one step ahead of the weight walker
   int akh = 0, akw = 0, ac0 = 0, an = 0;      // an = index of the next activation step to issue
   auto stage_a = [&]() {
-    const int off = (akh * p.in_Wp + akw) * p.in_Cs + ac0;
+    const int off = (akh * in_Wp + akw) * p.in_Cs + ac0;
     if (++akw == p.KW) { akw = 0; if (++akh == p.KH) { akh = 0; ac0 += 64; } }
     char* abase = smem + (an % 3) * ASTAGE;
     ++an;
     if (DBG & 1) return;   // ceiling experiment: no global traffic
     if (DBG & 8) return;   // ... no activation traffic only
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) glds16(aptr[ps] + off, abase + (ps * 64 + wave * 8) * 128);
+    for (int ps = 0; ps < APS; ++ps) glds16(aptr[ps] + off, abase + (ps * 64 + wave * 8) * 128);
   };
   int wkh = 0, wkw = 0, wc0 = 0, wn = 0;
   auto stage_w = [&]() {
@@ -105,7 +96,7 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < MI; ++i) w_off[i] = W_BASE + (wch * 64 + (fi >> 2) * 16 + i * 4 + (fi & 3)) * 128;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) x_off[j] = (wpx * 128 + j * 16 + fi) * 128;
+  for (int j = 0; j < NJ; ++j) x_off[j] = (wpx * WPX + j * 16 + fi) * 128;
   const int c0_off = (fq ^ fkey) * 16, c1_off = ((4 + fq) ^ fkey) * 16;
 
   f32x4 acc[MI][NJ];
@@ -129,14 +120,16 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   half8 wf0[MI], xf0[NJ], wf1[MI], xf1[NJ];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned wrow = (unsigned)(W_BASE + (wch * 64 + (fi >> 2) * 16 + (fi & 3)) * 128);
-  const unsigned xrow = (unsigned)((wpx * 128 + fi) * 128);
+  const unsigned xrow = (unsigned)((wpx * WPX + fi) * 128);
   const unsigned wa0 = lds0 + wrow + c0_off, wa1 = lds0 + wrow + c1_off;
   const unsigned xa0 = lds0 + xrow + c0_off, xa1 = lds0 + xrow + c1_off;
 #define RS_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define RS_READS(wf, xf, wa, xa)                                                        \
   RS_DSR(wf[0], wa, 0); RS_DSR(wf[1], wa, 512); RS_DSR(wf[2], wa, 1024); RS_DSR(wf[3], wa, 1536);   \
   RS_DSR(xf[0], xa, 0); RS_DSR(xf[1], xa, 2048); RS_DSR(xf[2], xa, 4096); RS_DSR(xf[3], xa, 6144);  \
-  RS_DSR(xf[4], xa, 8192); RS_DSR(xf[5], xa, 10240); RS_DSR(xf[6], xa, 12288); RS_DSR(xf[7], xa, 14336);
+  if constexpr (NJ == 8) {                                                                          \
+    RS_DSR(xf[4], xa, 8192); RS_DSR(xf[5], xa, 10240); RS_DSR(xf[6], xa, 12288); RS_DSR(xf[7], xa, 14336);   \
+  }
   auto reads0 = [&](int ab, int wb) {
     if (DBG & 16) return;  // ceiling experiment: no fragment reads (MFMAs on whatever the registers hold)
     const unsigned wa = wa0 + ((DBG & 2) ? 0 : wb) * WSTAGE, xa = xa0 + ((DBG & 2) ? 0 : ab) * ASTAGE;
@@ -156,7 +149,7 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   stage_w();
   stage_a();
   if (nk > 1) stage_a();
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APS) : "memory");       // all but the youngest activation stage (APS pieces)
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -168,7 +161,7 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
     __builtin_amdgcn_sched_barrier(0);
     reads1(abuf, t & 1);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");          // F0 (the 12 older reads) has landed; F1 stays in flight
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4 + NJ) : "memory");   // F0 (the 4 + NJ older reads) has landed; F1 stays in flight
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -179,7 +172,7 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
     const int anext = abuf == 2 ? 0 : abuf + 1;
     if (t + 1 < nk) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // F1 landed = my reads of step t's buffers are done
-      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my pieces of step t+1 (all but acts(t+2))
+      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APS) : "memory");   // my pieces of step t+1 (all but acts(t+2))
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -226,18 +219,65 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   float bias[16];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
+    const f32x4 b4 = *(const f32x4*)(g_bias + crow + i * 4);
     bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
+  }
+  if (!TRAIN && p.head_w) {
+    // Fused 16-row 1x1 head on top of this convolution (RPN: objectness + anchor deltas): the 256-channel output tile never leaves
+    // the CU.  relu(acc + bias), rounded to fp16 exactly as the store would round it, is per lane 16 consecutive channels of a
+    // pixel = the B operand of two 32-deep MFMA steps when the head's K columns are stored in the chaining order (weights.py
+    // _perm_k64, see bneck_fused.hip).  Each wave reduces its 64 channels; the four channel waves are summed through LDS in a
+    // fixed order, so the result is bitwise reproducible.
+    const half_t* hw = p.head_w + (long long)fi * 256 + wch * 64 + fq * 8;
+    const half8 ha0 = *(const half8*)hw, ha1 = *(const half8*)(hw + 32);
+    f32x4 hacc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      half8 b0, b1;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float f = acc[i][j][r] + bias[i * 4 + r];
+          if (p.relu) f = f > 0.f ? f : 0.f;
+          f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+          if (i < 2) b0[i * 4 + r] = (half_t)f; else b1[(i - 2) * 4 + r] = (half_t)f;
+        }
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha0, b0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha1, b1, a, 0, 0, 0);
+      hacc[j] = a;
+    }
+    asm volatile("s_barrier" ::: "memory");          // every wave is past its last fragment reads (lgkmcnt(0) in the last K step): the stage buffers are free
+    float* part = (float*)smem;                      // [4 channel waves][2 WPX pixels][16] partial sums
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) *(f32x4*)(part + ((wch * 2 * WPX + wpx * WPX + j * 16 + fi) * 16 + fq * 4)) = hacc[j];
+    __syncthreads();
+    const int px = tid >> 1, oh = (tid & 1) * 8;
+    const int m = m0 + px;
+    if (px < 2 * WPX && m < M) {
+      f32x4 s0 = *(const f32x4*)(p.head_b + oh), s1 = *(const f32x4*)(p.head_b + oh + 4);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s0 += *(const f32x4*)(part + ((w * 2 * WPX + px) * 16 + oh));
+        s1 += *(const f32x4*)(part + ((w * 2 * WPX + px) * 16 + oh + 4));
+      }
+      const int x = m % Wo, t = m / Wo, y = t % Ho, n = t / Ho;
+      float* op = g_head_out + ((long long)(n * Ho + y) * Wo + x) * 16 + oh;
+      *(f32x4*)op = s0;
+      *(f32x4*)(op + 4) = s1;
+    }
+    return;
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int m = m0 + wpx * 128 + j * 16 + fi;
+    const int m = m0 + wpx * WPX + j * 16 + fi;
     if (m >= M) continue;
-    const int x = m % p.Wo;
-    const int t = m / p.Wo;
-    const int y = t % p.Ho;
-    const int n = t / p.Ho;
-    const long long opix = (long long)(n * p.out_Hp + y + p.out_pad) * p.out_Wp + x + p.out_pad;
+    const int x = m % Wo;
+    const int t = m / Wo;
+    const int y = t % Ho;
+    const int n = t / Ho;
+    const long long opix = (long long)(n * out_Hp + y + p.out_pad) * out_Wp + x + p.out_pad;
     float v[16];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -298,11 +338,11 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
       for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
     }
     if (p.out_f32) {
-      float* op = (float*)p.out + opix * p.out_Cs + crow;
+      float* op = (float*)g_out + opix * p.out_Cs + crow;
 #pragma unroll
       for (int i = 0; i < MI; ++i) *(f32x4*)(op + i * 4) = f32x4{v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
     } else {
-      half_t* op = (half_t*)p.out + opix * p.out_Cs + crow;
+      half_t* op = (half_t*)g_out + opix * p.out_Cs + crow;
 #pragma unroll
       for (int i = 0; i < MI; i += 2) {
         half8 h;
@@ -318,12 +358,84 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   }
 }
 
+
+// Grid: [full 256-pixel tiles in XCD-aware order][the p.tail_tiles last logical tiles again as two 128-pixel tiles each].  One
+// workgroup per CU is resident (160 KB of LDS), so a launch runs in rounds of 256 tiles; when the last round would fill at most half the
+// chip, its tiles are split so that it takes about half a round (launch_conv_deep: tail rule).
+template <int DBG, bool TRAIN = false>
+__global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int M = p.M;
+  if (p.m_count) {
+    long long mc = (long long)(*p.m_count) * p.m_mul;
+    if (mc < M) M = (int)mc;
+  }
+  const int tiles_n = p.Cout / BN;
+  const int ntiles = p.nseg ? p.seg_tiles : tiles_n * ((M + BM - 1) / BM);
+  const int nfull = ntiles - p.tail_tiles;
+  const int q = blockIdx.x;
+  if (q >= nfull + 2 * p.tail_tiles) return;
+  // tensors and geometry of the map this tile belongs to (multi-map launch: p.seg[], selected with static indices -- all scalar)
+  const half_t* g_in = p.in;
+  const half_t* g_w = p.w;
+  const float* g_bias = p.bias;
+  void* g_out = p.out;
+  float* g_head_out = p.head_out;
+  int Ho = p.Ho, Wo = p.Wo, in_Hp = p.in_Hp, in_Wp = p.in_Wp, out_Hp = p.out_Hp, out_Wp = p.out_Wp;
+  int L, half = -1;
+  if (q < nfull) {
+    const int qn = nfull >> 3, r = nfull & 7, x = q & 7;      // XCD-aware order, see conv_igemm.hip
+    L = (x < r ? x * (qn + 1) : r * (qn + 1) + (x - r) * qn) + (q >> 3);
+  } else {
+    L = nfull + ((q - nfull) >> 1);
+    half = (q - nfull) & 1;
+  }
+  if (p.nseg) {
+    int t0 = 0;
+#pragma unroll
+    for (int i = 0; i < RS_MAX_SEGS; ++i)
+      if (i < p.nseg && L >= p.seg[i].tile0) {
+        g_in = p.seg[i].in; g_w = p.seg[i].w; g_bias = p.seg[i].bias; g_out = p.seg[i].out; g_head_out = p.seg[i].head_out;
+        Ho = p.seg[i].Ho; Wo = p.seg[i].Wo; in_Hp = p.seg[i].in_Hp; in_Wp = p.seg[i].in_Wp;
+        out_Hp = p.seg[i].out_Hp; out_Wp = p.seg[i].out_Wp; M = p.seg[i].M; t0 = p.seg[i].tile0;
+      }
+    L -= t0;
+  }
+  const int n0 = (L % tiles_n) * BN;
+  const int m0 = (L / tiles_n) * BM;
+  if (half < 0) {
+    conv_deep_tile<DBG, TRAIN, 8>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0, n0, q);
+  } else {
+    if (m0 + half * (BM / 2) >= M) return;                     // second half of a partial last tile: nothing to do (workgroup-uniform)
+    conv_deep_tile<DBG, TRAIN, 4>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0 + half * (BM / 2), n0, q);
+  }
+}
+
 }  // namespace
 
+// Tail rule.  One workgroup per CU is resident, all tiles of a launch take the same time, so T tiles run in ceil(T / CUs) rounds.
+// If the last round holds r <= CUs / 2 tiles, those r tiles are split into 2 r tiles of 128 pixels, which fit one round of about
+// half the length (625 tiles on 256 CUs: 3 rounds -> ~2.55).  Returns r (0: no split).
+static int deep_tail_tiles(long long tiles) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu = n;
+  }
+  if (!rs_debug().deep_tail) return 0;
+  const int r = (int)(tiles % ncu);
+  return (r > 0 && 2 * r <= ncu) ? r : 0;
+}
+
 // Requirements: mode 0, single K source, Cin % 64 == 0, Cout % 256 == 0.
-int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
+int launch_conv_deep(const ConvParams& p0, hipStream_t stream) {
+  ConvParams p = p0;
+  p.nseg = 0;
   RS_CHECK(p.mode == 0 && !p.in2 && p.Cin % 64 == 0 && p.Cout % BN == 0 && p.M > 0, RS_ERR_ARG,
            "conv_deep: unsupported shape (mode %d, Cin %d, Cout %d)", p.mode, p.Cin, p.Cout);
+  RS_CHECK(!p.head_w || (p.Cout == BN && p.head_b && p.head_out && !p.res && !p.up && !p.down && !p.res32 && !p.mask), RS_ERR_ARG,
+           "conv_deep: the fused head needs Cout == 256, its bias and output, and no other epilogue option");
   static bool done = false;
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -352,8 +464,10 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
 #else
   constexpr int dbg = 0;
 #endif
-  const long long nblk = (long long)(p.Cout / BN) * cdiv(p.M, BM);
-  RS_CHECK(nblk < (1ll << 31), RS_ERR_ARG, "conv_deep: grid too large");
+  long long nblk = (long long)(p.Cout / BN) * cdiv(p.M, BM);
+  RS_CHECK(nblk < (1ll << 30), RS_ERR_ARG, "conv_deep: grid too large");
+  p.tail_tiles = (p.m_count || dbg) ? 0 : deep_tail_tiles(nblk);     // a device-side row count changes the tile count behind the host's back
+  nblk += p.tail_tiles;
 #ifdef RS_DEEP_CEILING
   if (dbg == 1) { hipLaunchKernelGGL(conv_deep_kernel<1>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
   if (dbg == 3) { hipLaunchKernelGGL(conv_deep_kernel<3>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
@@ -365,6 +479,43 @@ int launch_conv_deep(const ConvParams& p, hipStream_t stream) {
   RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
   if (p.down || p.res32 || p.mask) hipLaunchKernelGGL((conv_deep_kernel<0, true>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
   else hipLaunchKernelGGL(conv_deep_kernel<0>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+// The same convolution (kernel size, stride 1, Cin, Cout, channel pitches, halos, ReLU) over up to RS_MAX_SEGS maps with their own
+// geometry, tensors and weights, as one grid: tiles of all maps share the 256 CUs, so the small maps of a feature pyramid fill the
+// partial last round of the large ones instead of each paying a round (and a launch) of their own.
+int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const int* m_per_image, int nseg, int images, hipStream_t stream) {
+  RS_CHECK(nseg >= 1 && nseg <= RS_MAX_SEGS && images >= 1, RS_ERR_ARG, "conv_deep_multi: %d maps", nseg);
+  RS_CHECK(common.mode == 0 && !common.in2 && common.Cin % 64 == 0 && common.Cout % BN == 0 && !common.res && !common.up && !common.m_count &&
+               !common.down && !common.res32 && !common.mask && common.out_stride <= 1,
+           RS_ERR_ARG, "conv_deep_multi: unsupported shape (mode %d, Cin %d, Cout %d) or epilogue option", common.mode, common.Cin, common.Cout);
+  ConvParams p = common;
+  p.nseg = nseg;
+  long long tiles = 0;
+  for (int i = 0; i < nseg; ++i) {
+    RS_CHECK(segs[i].in && segs[i].w && segs[i].bias && segs[i].out && m_per_image[i] > 0, RS_ERR_ARG, "conv_deep_multi: map %d incomplete", i);
+    p.seg[i] = segs[i];
+    p.seg[i].M = images * m_per_image[i];
+    p.seg[i].tile0 = (int)tiles;
+    tiles += (long long)(p.Cout / BN) * cdiv(p.seg[i].M, BM);
+  }
+  RS_CHECK(tiles < (1ll << 30), RS_ERR_ARG, "conv_deep_multi: grid too large");
+  if (p.head_w) {
+    RS_CHECK(p.Cout == BN && p.head_b && !p.out_f32, RS_ERR_ARG, "conv_deep_multi: the fused head needs Cout == 256 and its bias");
+    for (int i = 0; i < nseg; ++i) RS_CHECK(segs[i].head_out, RS_ERR_ARG, "conv_deep_multi: map %d has no head output", i);
+  }
+  p.seg_tiles = (int)tiles;
+  p.tail_tiles = deep_tail_tiles(tiles);
+  tiles += p.tail_tiles;
+  p.in = segs[0].in; p.w = segs[0].w; p.bias = segs[0].bias; p.out = segs[0].out; p.M = p.seg[0].M;
+  static bool done = false;
+  if (!done) {
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    done = true;
+  }
+  hipLaunchKernelGGL(conv_deep_kernel<0>, dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

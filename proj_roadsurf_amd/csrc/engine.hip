@@ -29,7 +29,7 @@ void rs_debug_reload() {
   rd("RS_CONV_SINGLE_STAGE_NK", &d.conv_single_stage_nk); rd("RS_CONV_PERSIST", &d.conv_persist); rd("RS_CONV_TUNED", &d.conv_tuned);
   rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_CONV_WIDE_PX", &d.conv_wide_px); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
   rd("RS_DECONV_VARIANT", &d.deconv_variant); rd("RS_FUSE_MASK_PREDICTOR", &d.fuse_mask_predictor); rd("RS_SIDE_STREAM", &d.side_stream);
-  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_FUSE_BNECK", &d.fuse_bneck);
+  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_FUSE_BNECK", &d.fuse_bneck);
   rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
   rd("RS_TRAIN_SIDE", &d.train_side); rd("RS_WGRAD_TARGET", &d.wgrad_target); rd("RS_WGRAD_CB", &d.wgrad_cb);
   rd("RS_SELECT_DEBUG", &d.select_debug); rd("RS_NMS_DEBUG", &d.nms_debug); rd("RS_ROI_WINDOW", &d.roi_window);
@@ -229,15 +229,18 @@ struct rs_engine {
   const BlobEntry* findw(const std::string& layer) { return find(layer + (f32 ? ".w32" : ".w")); }
   int parse_blob(const void* data, size_t nbytes);
   int build();
+  struct DeferredConv { ConvParams p; int m_per_image = 0; double flops = 0, bytes = 0; };
   int add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k, int stride,
                int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile = 1,
-               const int* m_count = nullptr, const Act* in2 = nullptr, int stride2 = 1);
+               const int* m_count = nullptr, const Act* in2 = nullptr, int stride2 = 1, DeferredConv* defer = nullptr);
+  int add_merged_convs(const std::string& name, const std::vector<DeferredConv>& d);
   int run(const uint8_t* tiles, int n, int phase = -1);
   int run_stages(int n, bool record, int phase = -1);
   int assign_phases();
   int use_graph = 0;
   int fuse_shortcut = 1;
   int fuse_bneck = 1;
+  int merge_levels = 1;   // FPN output convs / RPN 3x3 of all levels as one multi-map launch each (inference engines, fp16 path)
   long long forward_index = 0;
   std::set<int> warmed;
   std::map<int, hipGraphExec_t> graphs;
@@ -283,7 +286,7 @@ int rs_engine::parse_blob(const void* data, size_t nbytes) {
 // `m_count` = optional device-side count of units actually present.
 int rs_engine::add_conv(const std::string& name, const std::string& wname, const Act& in, const Act& out, int k,
                         int stride, int pad, bool relu, const Act* res, const Act* up, int cin_real, int units_per_tile,
-                        const int* m_count, const Act* in2, int stride2) {
+                        const int* m_count, const Act* in2, int stride2, DeferredConv* defer) {
   const BlobEntry* w = findw(wname);
   const BlobEntry* b = find(wname + ".b");
   RS_CHECK(w && b, RS_ERR_BLOB, "weights for %s missing from blob", wname.c_str());
@@ -342,9 +345,42 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
   st.bytes_per_image = 2.0 * (in_px * in.C * units_per_tile + (double)m_per_image * out.C * (1 + (res ? 1 : 0)) +
                               (in2 ? (double)m_per_image * in2->C : 0.0));
   const int glds = use_glds;
+  if (defer) {           // the caller merges this convolution into a multi-map launch (add_merged_convs)
+    defer->p = p; defer->m_per_image = m_per_image; defer->flops = st.flops_per_image; defer->bytes = st.bytes_per_image;
+    return RS_OK;
+  }
   st.fn = [p, m_per_image, glds](int n, hipStream_t s) mutable {
     p.M = n * m_per_image;
     return launch_conv(p, s, -1, glds);
+  };
+  stages.push_back(st);
+  return RS_OK;
+}
+
+// One stage = one conv_deep launch over several maps (launch_conv_deep_multi)
+int rs_engine::add_merged_convs(const std::string& name, const std::vector<DeferredConv>& d) {
+  RS_CHECK(!d.empty() && d.size() <= RS_MAX_SEGS, RS_ERR_ARG, "%s: %d maps", name.c_str(), (int)d.size());
+  ConvParams common = d[0].p;
+  std::vector<ConvSeg> segs(d.size());
+  std::vector<int> mpi(d.size());
+  Stage st;
+  st.name = name;
+  for (size_t i = 0; i < d.size(); ++i) {
+    const ConvParams& q = d[i].p;
+    RS_CHECK(q.Cin == common.Cin && q.Cout == common.Cout && q.KH == common.KH && q.KW == common.KW && q.stride == 1 && q.in_Cs == common.in_Cs &&
+                 q.in_off == common.in_off && q.out_Cs == common.out_Cs && q.out_pad == common.out_pad && q.Kpad == common.Kpad && q.relu == common.relu &&
+                 !q.res && !q.up && !q.in2 && !q.m_count && q.mode == 0 && !q.out_f32,
+             RS_ERR_ARG, "%s: map %d does not share the launch parameters of map 0", name.c_str(), (int)i);
+    RS_CHECK(q.head_w == common.head_w && q.head_b == common.head_b, RS_ERR_ARG, "%s: map %d has another fused head", name.c_str(), (int)i);
+    segs[i].in = q.in; segs[i].w = q.w; segs[i].bias = q.bias; segs[i].out = q.out; segs[i].head_out = q.head_out;
+    segs[i].Ho = q.Ho; segs[i].Wo = q.Wo; segs[i].in_Hp = q.in_Hp; segs[i].in_Wp = q.in_Wp; segs[i].out_Hp = q.out_Hp; segs[i].out_Wp = q.out_Wp;
+    mpi[i] = d[i].m_per_image;
+    st.flops_per_image += d[i].flops;
+    st.bytes_per_image += d[i].bytes;
+  }
+  st.fn = [common, segs, mpi](int n, hipStream_t s) {
+    g_last_conv_variant = 12;
+    return launch_conv_deep_multi(common, segs.data(), mpi.data(), (int)segs.size(), n, s);
   };
   stages.push_back(st);
   return RS_OK;
@@ -579,14 +615,22 @@ int rs_engine::build() {
 
   // ---- FPN
   Act inner[4], P[5];
+  const bool merge = merge_levels && !f32 && rs_debug().conv_deep && use_glds > 0;
+  std::vector<DeferredConv> fpn_out(4), rpn_conv(S.num_levels);
   for (int l = 3; l >= 0; --l) {
     const std::string ln = std::to_string(l + 2);
     if ((rc = new_act(&inner[l], "inner" + ln, NB, res_out[l].H, res_out[l].W, 256, 1))) return rc;
     if ((rc = new_act(&P[l], "p" + ln, NB, res_out[l].H, res_out[l].W, 256, 1))) return rc;
     if ((rc = add_conv("fpn_lateral" + ln, "backbone.fpn_lateral" + ln, res_out[l], inner[l], 1, 1, 0, false, nullptr,
                        l < 3 ? &inner[l + 1] : nullptr, res_out[l].C))) return rc;
-    if ((rc = add_conv("fpn_output" + ln, "backbone.fpn_output" + ln, inner[l], P[l], 3, 1, 1, false, nullptr, nullptr, 256))) return rc;
+    if (merge) {
+      if ((rc = add_conv("fpn_output" + ln, "backbone.fpn_output" + ln, inner[l], P[l], 3, 1, 1, false, nullptr, nullptr, 256, 1, nullptr, nullptr, 1, &fpn_out[l]))) return rc;
+    } else {
+      if ((rc = add_conv("fpn_output" + ln, "backbone.fpn_output" + ln, inner[l], P[l], 3, 1, 1, false, nullptr, nullptr, 256))) return rc;
+    }
   }
+  // the four output convolutions depend on the laterals only: one launch, largest map first
+  if (merge && (rc = add_merged_convs("fpn_output2-5", fpn_out))) return rc;
   {
     const int h6 = (P[3].H - 1) / 2 + 1, w6 = (P[3].W - 1) / 2 + 1;
     if ((rc = new_act(&P[4], "p6", NB, h6, w6, 256, 1))) return rc;
@@ -606,16 +650,44 @@ int rs_engine::build() {
   const int head_cs = (5 * A + 15) / 16 * 16;
   RpnParams rp;
   memset(&rp, 0, sizeof rp);
+  Act rpn_t[RS_MAX_LEVELS];
+  float* rpn_ho[RS_MAX_LEVELS];
+  for (int l = 0; l < L; ++l) {
+    float* ho = nullptr;
+    if ((rc = alloc((void**)&ho, (size_t)NB * P[l].H * P[l].W * head_cs * 4))) return rc;
+    reg("rpn_head" + std::to_string(l + 2), ho, DT_F32, {NB, P[l].H, P[l].W, head_cs}, 0);
+    rpn_ho[l] = ho;
+  }
+  // inference engines: the 16-row head runs inside the epilogue of the merged 3x3 launch (conv_deep.hip, ConvParams::head_w), so the
+  // 256-channel "rpn_conv" maps are never written
+  const BlobEntry* headsp = findw("proposal_generator.rpn_head.headsp");
+  const bool fuse_heads = merge && rs_debug().fuse_rpn_heads && head_cs == 16 && headsp != nullptr;
   for (int l = 0; l < L; ++l) {
     const std::string ln = std::to_string(l + 2);
     Act t;
     if ((rc = new_act(&t, "rpn_conv" + ln, NB, P[l].H, P[l].W, 256, 1))) return rc;   // halo 1: its gradient is the input of a 3x3 (training)
+    if (merge) {
+      if ((rc = add_conv("rpn.conv" + ln, "proposal_generator.rpn_head.conv", P[l], t, 3, 1, 1, true, nullptr, nullptr, 256, 1, nullptr, nullptr, 1, &rpn_conv[l]))) return rc;
+      if (fuse_heads) {
+        const BlobEntry* hb = find("proposal_generator.rpn_head.heads.b");
+        RS_CHECK(hb && (int)headsp->dims[0] == 16 && (int)headsp->dims[1] == 256, RS_ERR_BLOB, "rpn head weights (chained order) missing or not 16 x 256");
+        rpn_conv[l].p.head_w = (const half_t*)headsp->dev; rpn_conv[l].p.head_b = (const float*)hb->dev; rpn_conv[l].p.head_out = rpn_ho[l];
+        rpn_conv[l].flops += 2.0 * P[l].H * P[l].W * 256 * 5 * A;
+        rpn_conv[l].bytes += (double)P[l].H * P[l].W * (head_cs * 4 - 256 * 2);       // the heads' output instead of the 256-channel map
+      }
+      if (l == L - 1 && (rc = add_merged_convs(fuse_heads ? "rpn.conv+heads2-6" : "rpn.conv2-6", rpn_conv))) return rc;
+      rpn_t[l] = t;
+      continue;
+    }
     if ((rc = add_conv("rpn.conv" + ln, "proposal_generator.rpn_head.conv", P[l], t, 3, 1, 1, true, nullptr, nullptr, 256))) return rc;
-    float* ho = nullptr;
-    if ((rc = alloc((void**)&ho, (size_t)NB * P[l].H * P[l].W * head_cs * 4))) return rc;
-    reg("rpn_head" + ln, ho, DT_F32, {NB, P[l].H, P[l].W, head_cs}, 0);
+    rpn_t[l] = t;
+  }
+  for (int l = 0; l < L; ++l) {
+    const std::string ln = std::to_string(l + 2);
+    const Act t = rpn_t[l];
+    float* ho = rpn_ho[l];
     // 1x1 heads (objectness + deltas fused), fp32 out
-    {
+    if (!fuse_heads) {
       const BlobEntry* w = findw("proposal_generator.rpn_head.heads");
       const BlobEntry* b = find("proposal_generator.rpn_head.heads.b");
       RS_CHECK(w && b, RS_ERR_BLOB, "rpn head weights missing");
@@ -1113,7 +1185,8 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   if (e->f32) e->use_glds = -1;
   e->fuse_shortcut = rs_debug().fuse_shortcut;
   e->fuse_bneck = rs_debug().fuse_bneck;
-  if (g_trainer_unfused_shortcut) { e->fuse_shortcut = 0; e->fuse_bneck = 0; }   // the training engine differentiates every convolution separately and needs every layer output
+  e->merge_levels = rs_debug().merge_levels;
+  if (g_trainer_unfused_shortcut) { e->fuse_shortcut = 0; e->fuse_bneck = 0; e->merge_levels = 0; }   // the training engine differentiates every convolution separately and needs every layer output
   e->use_graph = rs_debug().use_graph;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
   else {

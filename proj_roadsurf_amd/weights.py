@@ -298,6 +298,10 @@ def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], w_dtype=np.float1
     b = np.concatenate([W[p + "objectness_logits.bias"], W[p + "anchor_deltas.bias"]], 0).astype(np.float32)
     wp, bp = _pad_rows(_ohwi(w, w.shape[1], w_dtype), b, 16)
     T[p + "heads.w"], T[p + "heads.b"] = wp, bp
+    if w_dtype == np.float16 and wp.shape == (16, 256):
+        # the same 16 x 256 matrix with its K columns in the register-chaining order: the head runs inside the epilogue of the RPN's
+        # 3x3 convolution (csrc/conv_deep.hip, ConvParams::head_w)
+        T[p + "headsp.w"] = _perm_k64(wp, 64)
     # box head: fc1 consumes RoI features laid out [7][7][C] (channels fastest) on the device,
     # detectron2 flattens (C,7,7): permute the K axis once here.
     r = spec.box_pooler_resolution

@@ -555,6 +555,50 @@ def test_engine_launches_the_tabled_variants(gpu_required):
         eng.close()
 
 
+def test_merged_level_launches_and_split_tail_change_no_bit(gpu_required, monkeypatch):
+    """The FPN output convolutions of p2..p5 and the shared RPN 3x3 over p2..p6 run as one multi-map conv_deep launch each, and
+    a last round that fills at most half the chip runs as 128-pixel tiles (csrc/conv_deep.hip).  Neither changes the arithmetic
+    of any output element: every FPN map, every RPN head output and the detections are BIT-identical to the engine built with
+    per-level launches and whole tiles (RS_MERGE_LEVELS=0, RS_DEEP_TAIL=0).  The RPN heads computed inside the epilogue of the
+    merged 3x3 launch (default) sum the same products in another order: fp32 head outputs equal to ~1e-6 of their scale."""
+    spec = EngineSpec(num_classes=2, min_size_test=512, max_size_test=853)
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(3, 512, 512, 3, seed=4321)
+    names = [f"p{l}" for l in range(2, 7)] + [f"rpn_head{l}" for l in range(2, 7)]
+
+    def run():
+        eng = Engine(spec, W, (512, 512, 3), max_batch=3)
+        try:
+            dets = eng.infer(tiles)
+            stages = list(eng.stage_variants())
+            return dets, {n: eng.tensor(n).copy() for n in names}, stages
+        finally:
+            eng.close()
+    df, tf, sf = run()                                         # shipped configuration
+    assert "fpn_output2-5" in sf and "rpn.conv+heads2-6" in sf and not any(s.startswith("rpn.heads") for s in sf)
+    monkeypatch.setenv("RS_FUSE_RPN_HEADS", "0")
+    d1, t1, s1 = run()
+    assert "rpn.conv2-6" in s1 and "rpn.heads2" in s1 and "rpn.conv3" not in s1
+    monkeypatch.setenv("RS_MERGE_LEVELS", "0")
+    monkeypatch.setenv("RS_DEEP_TAIL", "0")
+    d0, t0, s0 = run()
+    assert "fpn_output2" in s0 and "rpn.conv6" in s0 and "rpn.conv2-6" not in s0
+    for n in names:
+        assert np.array_equal(t0[n], t1[n]), n
+        assert float(np.abs(t1[n]).max()) > 0
+        if n.startswith("p"):
+            assert np.array_equal(tf[n], t1[n]), n
+        else:
+            A5 = 5 * spec.num_anchors
+            err = float(np.abs(tf[n][..., :A5] - t1[n][..., :A5]).max())
+            assert err <= 2e-5 * max(1.0, float(np.abs(t1[n]).max())), (n, err)
+    assert all(_same_instances(a, b) for a, b in zip(d0, d1)) and all(len(d) > 0 for d in d1)
+    for a, b in zip(df, d1):                                   # the fused heads move logits by ~1e-6: (nearly) the same detections
+        r = match_detections({"boxes": b.pred_boxes, "scores": b.scores, "classes": b.pred_classes},
+                              {"boxes": a.pred_boxes, "scores": a.scores, "classes": a.pred_classes}, iou_thr=0.9)
+        assert r["frac_matched"] >= 0.9, r
+
+
 def test_config1_batch16_of_512_tiles(gpu_required):
     """BASELINE configs[1], the headline: batch 16 of 512x512x3 tiles, 800x800 network input.
     (a) fp16 production mode: each of the 16 detection sets is BIT-IDENTICAL to the same tile run alone (other tile variants);

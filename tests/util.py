@@ -84,11 +84,12 @@ def conv_stage_shapes(spec, net_h=800, net_w=800):
     res_c = [spec.res2_out_channels * (2 ** i) for i in range(4)]
     for l in (3, 2, 1, 0):
         out.append((f"fpn_lateral{l + 2}", sizes[l][0] * sizes[l][1], res_c[l], 1, 256, 0, None))
-        out.append((f"fpn_output{l + 2}", sizes[l][0] * sizes[l][1], 256, 3, 256, 0, None))
+    # the 3x3 output convolutions of the four levels, and the shared RPN 3x3 over the five, run as ONE multi-map conv_deep launch
+    # each (launch_conv_deep_multi; variant 12 at every batch size)
+    out.append(("fpn_output2-5", sum(a * b for a, b in sizes), 256, 3, 256, 0, 12))
     p6 = ((sizes[3][0] - 1) // 2 + 1, (sizes[3][1] - 1) // 2 + 1)
-    for l, (a, b) in enumerate(sizes + [p6]):
-        out.append((f"rpn.conv{l + 2}", a * b, 256, 3, 256, 0, None))
-        out.append((f"rpn.heads{l + 2}", a * b, 256, 1, 16, 0, 2))
+    # ... with the 16-row objectness + delta head inside its epilogue (ConvParams::head_w): no rpn.heads stages
+    out.append(("rpn.conv+heads2-6", sum(a * b for a, b in sizes + [p6]), 256, 3, 256, 0, 12))
     pr, fc = spec.box_pooler_resolution, spec.box_fc_dim
     out.append(("box.fc1", 1024, pr * pr * 256, 1, fc, 0, None))
     out.append(("box.fc2", 1024, fc, 1, fc, 0, None))
