@@ -55,6 +55,7 @@ struct RsDebug {
   int use_glds = 1;               // RS_USE_GLDS              0: register staging instead of LDS-DMA
   int fuse_shortcut = 1;          // RS_FUSE_SHORTCUT
   int fuse_bneck = 1;             // RS_FUSE_BNECK            conv2 + conv3 + next conv1 of the res2 identity blocks in one launch
+  int deep_tile_px = 1;           // RS_DEEP_TILE_PX          conv_deep with 160 / 192 / 224-pixel tiles where 256 fill the CUs badly (variants 15-17)
   int deep_tail = 1;              // RS_DEEP_TAIL             conv_deep: split the tiles of a last round that fills at most half the chip
   int fuse_rpn_heads = 1;         // RS_FUSE_RPN_HEADS        objectness + delta heads inside the epilogue of the merged RPN 3x3 launch
   int merge_levels = 1;           // RS_MERGE_LEVELS          FPN output convs of all levels / the RPN 3x3 over all levels as one launch each
@@ -215,5 +216,5 @@ int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int 
 int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu = 0);   // ref_f32.hip: fp32 MFMA (or the VALU cross-check)
-int launch_conv_deep(const ConvParams& p, hipStream_t stream);
+int launch_conv_deep(const ConvParams& p, hipStream_t stream, int tile_px = 256);
 int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const int* m_per_image, int nseg, int images, hipStream_t stream);

@@ -18,8 +18,8 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, NT = 512, MI = 4, WCH = 4;   // NJ (16-pixel blocks per wave) = 8: 256-pixel tile; 4: the 128-pixel tiles of a split last round
-constexpr int ASTAGE = BM * 128, WSTAGE = BN * 128;       // 32 KB each
+constexpr int BN = 256, NT = 512, MI = 4, WCH = 4;   // NJ (16-pixel blocks per wave) = 8: 256-pixel tile; 4: the 128-pixel tiles of a split last round
+constexpr int ASTAGE = 256 * 128, WSTAGE = BN * 128;      // 32 KB each
 constexpr int W_BASE = 3 * ASTAGE;
 constexpr int LDS_BYTES = 3 * ASTAGE + 2 * WSTAGE;        // 160 KB
 
@@ -34,7 +34,8 @@ template <int DBG, bool TRAIN, int NJ>
 __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, const half_t* g_in, const half_t* g_w, const float* g_bias, void* g_out,
                                                float* g_head_out, const int Ho, const int Wo, const int in_Hp, const int in_Wp, const int out_Hp, const int out_Wp,
                                                const int M, const int m0, const int n0, const int q) {
-  constexpr int APS = NJ / 2;          // activation staging passes of 64 rows = LDS-DMA pieces per wave and stage
+  constexpr int APS = (NJ + 1) / 2;    // activation staging passes of 64 rows = LDS-DMA pieces per wave and stage (odd NJ: the upper half of the
+                                       // last pass lands in LDS rows nothing reads -- every wave issues the same number of pieces, so one counted wait serves all)
   constexpr int WPX = NJ * 16;         // pixels per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,10 +127,13 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
 #define RS_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define RS_READS(wf, xf, wa, xa)                                                        \
   RS_DSR(wf[0], wa, 0); RS_DSR(wf[1], wa, 512); RS_DSR(wf[2], wa, 1024); RS_DSR(wf[3], wa, 1536);   \
-  RS_DSR(xf[0], xa, 0); RS_DSR(xf[1], xa, 2048); RS_DSR(xf[2], xa, 4096); RS_DSR(xf[3], xa, 6144);  \
-  if constexpr (NJ == 8) {                                                                          \
-    RS_DSR(xf[4], xa, 8192); RS_DSR(xf[5], xa, 10240); RS_DSR(xf[6], xa, 12288); RS_DSR(xf[7], xa, 14336);   \
-  }
+  RS_DSR(xf[0], xa, 0); RS_DSR(xf[1], xa, 2048);                                                    \
+  if constexpr (NJ > 2) { RS_DSR(xf[2], xa, 4096); }                                                \
+  if constexpr (NJ > 3) { RS_DSR(xf[3], xa, 6144); }                                                \
+  if constexpr (NJ > 4) { RS_DSR(xf[4], xa, 8192); }                                                \
+  if constexpr (NJ > 5) { RS_DSR(xf[5], xa, 10240); }                                               \
+  if constexpr (NJ > 6) { RS_DSR(xf[6], xa, 12288); }                                               \
+  if constexpr (NJ > 7) { RS_DSR(xf[7], xa, 14336); }
   auto reads0 = [&](int ab, int wb) {
     if (DBG & 16) return;  // ceiling experiment: no fragment reads (MFMAs on whatever the registers hold)
     const unsigned wa = wa0 + ((DBG & 2) ? 0 : wb) * WSTAGE, xa = xa0 + ((DBG & 2) ? 0 : ab) * ASTAGE;
@@ -362,8 +366,12 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
 // Grid: [full 256-pixel tiles in XCD-aware order][the p.tail_tiles last logical tiles again as two 128-pixel tiles each].  One
 // workgroup per CU is resident (160 KB of LDS), so a launch runs in rounds of 256 tiles; when the last round would fill at most half the
 // chip, its tiles are split so that it takes about half a round (launch_conv_deep: tail rule).
-template <int DBG, bool TRAIN = false>
+// NJF: 16-pixel blocks per wave of a whole tile = tile height / 32 pixels.  8 (256 pixels) is the production tile; 5 / 6 / 7 (160 / 192 /
+// 224 pixels) exist for maps whose pixel count fills the 256 CUs badly in 256-pixel tiles (50 x 50 x 16 images = 40 000 pixels: 157 tiles
+// = 0.61 of a round; 250 tiles of 160 pixels = 0.98 of one) -- launch_conv variants 15 / 16 / 17.
+template <int DBG, bool TRAIN = false, int NJF = 8>
 __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
+  constexpr int BM = 32 * NJF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int M = p.M;
   if (p.m_count) {
@@ -403,11 +411,11 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   }
   const int n0 = (L % tiles_n) * BN;
   const int m0 = (L / tiles_n) * BM;
-  if (half < 0) {
-    conv_deep_tile<DBG, TRAIN, 8>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0, n0, q);
+  if (half < 0 || NJF != 8) {
+    conv_deep_tile<DBG, TRAIN, NJF>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0, n0, q);
   } else {
     if (m0 + half * (BM / 2) >= M) return;                     // second half of a partial last tile: nothing to do (workgroup-uniform)
-    conv_deep_tile<DBG, TRAIN, 4>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0 + half * (BM / 2), n0, q);
+    conv_deep_tile<DBG, TRAIN, NJF == 8 ? 4 : NJF>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0 + half * (BM / 2), n0, q);
   }
 }
 
@@ -428,14 +436,45 @@ static int deep_tail_tiles(long long tiles) {
   return (r > 0 && 2 * r <= ncu) ? r : 0;
 }
 
-// Requirements: mode 0, single K source, Cin % 64 == 0, Cout % 256 == 0.
-int launch_conv_deep(const ConvParams& p0, hipStream_t stream) {
+// Inference kernel with tiles of 32 * NJF pixels (variants 15 / 16 / 17; no training epilogue, no split last round)
+template <int NJF>
+static int launch_deep_nj(ConvParams& p, hipStream_t stream) {
+  static bool done = false;
+  if (!done) {
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, NJF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    done = true;
+  }
+  const long long nblk = (long long)(p.Cout / BN) * cdiv(p.M, 32 * NJF);
+  RS_CHECK(nblk < (1ll << 30), RS_ERR_ARG, "conv_deep: grid too large");
+  p.tail_tiles = 0;
+  hipLaunchKernelGGL((conv_deep_kernel<0, false, NJF>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+// Requirements: mode 0, single K source, Cin % 64 == 0, Cout % 256 == 0.  tile_px: 256 (variant 12), 160 / 192 / 224 (15 / 16 / 17) or
+// 64 / 96 / 128 (18 / 19 / 20).
+int launch_conv_deep(const ConvParams& p0, hipStream_t stream, int tile_px) {
   ConvParams p = p0;
   p.nseg = 0;
   RS_CHECK(p.mode == 0 && !p.in2 && p.Cin % 64 == 0 && p.Cout % BN == 0 && p.M > 0, RS_ERR_ARG,
            "conv_deep: unsupported shape (mode %d, Cin %d, Cout %d)", p.mode, p.Cin, p.Cout);
   RS_CHECK(!p.head_w || (p.Cout == BN && p.head_b && p.head_out && !p.res && !p.up && !p.down && !p.res32 && !p.mask), RS_ERR_ARG,
            "conv_deep: the fused head needs Cout == 256, its bias and output, and no other epilogue option");
+  RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
+  if (tile_px != 256) {
+    RS_CHECK(tile_px >= 64 && tile_px <= 224 && tile_px % 32 == 0 && !p.down && !p.res32 && !p.mask, RS_ERR_ARG,
+             "conv_deep: tile height %d (256, or 64 .. 224 in steps of 32 without training epilogue options)", tile_px);
+    switch (tile_px / 32) {
+      case 2: return launch_deep_nj<2>(p, stream);
+      case 3: return launch_deep_nj<3>(p, stream);
+      case 4: return launch_deep_nj<4>(p, stream);
+      case 5: return launch_deep_nj<5>(p, stream);
+      case 6: return launch_deep_nj<6>(p, stream);
+      default: return launch_deep_nj<7>(p, stream);
+    }
+  }
+  constexpr int BM = 256;
   static bool done = false;
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -476,7 +515,6 @@ int launch_conv_deep(const ConvParams& p0, hipStream_t stream) {
   if (dbg == 17) { hipLaunchKernelGGL(conv_deep_kernel<17>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
 #endif
   (void)dbg;
-  RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
   if (p.down || p.res32 || p.mask) hipLaunchKernelGGL((conv_deep_kernel<0, true>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
   else hipLaunchKernelGGL(conv_deep_kernel<0>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());
@@ -499,7 +537,7 @@ int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const 
     p.seg[i] = segs[i];
     p.seg[i].M = images * m_per_image[i];
     p.seg[i].tile0 = (int)tiles;
-    tiles += (long long)(p.Cout / BN) * cdiv(p.seg[i].M, BM);
+    tiles += (long long)(p.Cout / BN) * cdiv(p.seg[i].M, 256);
   }
   RS_CHECK(tiles < (1ll << 30), RS_ERR_ARG, "conv_deep_multi: grid too large");
   if (p.head_w) {

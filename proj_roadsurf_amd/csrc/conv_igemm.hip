@@ -533,6 +533,26 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
   if (rows <= 16) return 2;
   if (!D.conv_tuned || p.mode != 0 || smallc) return rows % 128 == 0 ? 0 : 1;
   if (rows % 128 != 0) return 8;                                          // Cout = 64: 128x64 beats 256x64 everywhere
+  // Deep K on a map whose pixels fill the 256 CUs badly in 256-pixel tiles (one workgroup per CU, so a launch runs in whole rounds):
+  // conv_deep with 160 / 192 / 224-pixel tiles when that saves a round or shortens the only one.  A round costs about (pixels / 32 + 15)
+  // units -- per K step the barrier chain pays the LDS-DMA latency whatever the tile height (tools/ubench/conv_shapes.py: 50 x 50 x 16
+  // images, 3x3 256 -> 256: 58.8 us on the 64x128 tile, 52.8 in 157 tiles of 256 pixels, 46.0 in 250 tiles of 160).
+  if (rows % 256 == 0 && nkd >= 8 && D.conv_deep && D.deep_tile_px && use_glds > 0 && !p.in2 && !p.m_count && !p.down && !p.res32 && !p.mask && p.out_stride <= 1) {
+    const int ncu = 256;
+    auto cost = [&](int nj) {
+      const long long t = (long long)cdiv(p.M, 32 * nj) * (rows / 256);
+      const long long r = t % ncu;
+      const double rounds = (double)(t / ncu) + (r == 0 ? 0.0 : (nj == 8 && D.deep_tail && 2 * r <= ncu ? 0.75 : 1.0));   // 256-pixel tiles split a short last round
+      return rounds * (nj + 15);
+    };
+    int best = 8;
+    double cb = cost(8);
+    for (int nj = 7; nj >= 5; --nj) {
+      const long long t = (long long)cdiv(p.M, 32 * nj) * (rows / 256);
+      if (4 * t >= 3 * ncu && cost(nj) < 0.95 * cb && cost(nj) < (best == 8 ? 1e30 : cost(best))) best = nj;
+    }
+    if (best != 8) return 10 + best;                                      // 15 / 16 / 17
+  }
   if (rows % 256 == 0 && nkd >= 8 && tiles4 >= 240)                       // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
     return (D.conv_deep && use_glds > 0 && !p.in2 && p.out_stride <= 1) ? 12 : 4;   // conv_deep incl. the backward epilogue (down / res32 / mask)
   // HBM-bound 1x1 layers on big maps: all 256 channels per workgroup, so every activation row is read once; 128 pixels per
@@ -564,11 +584,11 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
   if (p.in2) RS_CHECK(!smallc && p.mode == 0 && p.Cin2 % 64 == 0 && p.Cin2 > 0 && p.stride2 >= 1, RS_ERR_ARG, "conv: bad second K source (Cin2 %d)", p.Cin2);
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   const int v = conv_choose_variant(p, force_variant, use_glds);
-  RS_CHECK(!(train_opts && (p.mode != 0 || (v == 12 && p.out_stride > 1))), RS_ERR_UNSUPPORTED, "conv: training epilogue options need mode 0 (and no scatter on conv_deep)");
-  if (v == 12) {                        // 256x256 with 3 activation stages / 2 weight stages (conv_deep.hip)
-    RS_CHECK(!p.in2, RS_ERR_UNSUPPORTED, "conv: variant 12 has no second K source");
-    g_last_conv_variant = 12;
-    return launch_conv_deep(p, stream);
+  RS_CHECK(!(train_opts && (p.mode != 0 || (v == 12 && p.out_stride > 1) || (v >= 15 && v <= 20))), RS_ERR_UNSUPPORTED, "conv: training epilogue options need mode 0 (and no scatter on conv_deep)");
+  if (v == 12 || (v >= 15 && v <= 20)) {     // 256x256 with 3 activation stages / 2 weight stages (conv_deep.hip); 15 / 16 / 17: 160 / 192 / 224 pixels, 18 / 19 / 20: 64 / 96 / 128
+    RS_CHECK(!p.in2, RS_ERR_UNSUPPORTED, "conv: variant %d has no second K source", v);
+    g_last_conv_variant = v;
+    return launch_conv_deep(p, stream, v == 12 ? 256 : (v <= 17 ? 160 + 32 * (v - 15) : 64 + 32 * (v - 18)));
   }
   RS_CHECK(!(p.mode != 0 && p.Cout % 128 != 0), RS_ERR_ARG, "deconv needs Cout %% 128 == 0");
   RS_CHECK(!(p.mode == 2 && !(p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && (v == 0 || v == 10 || v == 14))), RS_ERR_ARG, "fused mask predictor needs its pointers and the 128x128, 64x256 or 128x256 tile");

@@ -29,7 +29,7 @@ void rs_debug_reload() {
   rd("RS_CONV_SINGLE_STAGE_NK", &d.conv_single_stage_nk); rd("RS_CONV_PERSIST", &d.conv_persist); rd("RS_CONV_TUNED", &d.conv_tuned);
   rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_CONV_WIDE_PX", &d.conv_wide_px); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
   rd("RS_DECONV_VARIANT", &d.deconv_variant); rd("RS_FUSE_MASK_PREDICTOR", &d.fuse_mask_predictor); rd("RS_SIDE_STREAM", &d.side_stream);
-  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_FUSE_BNECK", &d.fuse_bneck);
+  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_DEEP_TILE_PX", &d.deep_tile_px); rd("RS_FUSE_BNECK", &d.fuse_bneck);
   rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
   rd("RS_TRAIN_SIDE", &d.train_side); rd("RS_WGRAD_TARGET", &d.wgrad_target); rd("RS_WGRAD_CB", &d.wgrad_cb);
   rd("RS_SELECT_DEBUG", &d.select_debug); rd("RS_NMS_DEBUG", &d.nms_debug); rd("RS_ROI_WINDOW", &d.roi_window);
@@ -1408,9 +1408,11 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
                                 "conv_igemm_kernel<2,4,4,2> 64x256", "(retired)",
                                 "conv_deep_kernel 256x256 (3 activation + 2 weight LDS stages)",
                                 "bneck_tail_kernel 128 px (conv2 + conv3 + next conv1 chained through registers)",
-                                "conv_igemm_kernel<2,4,4,4> 128x256"};
+                                "conv_igemm_kernel<2,4,4,4> 128x256",
+                                "conv_deep_kernel 160x256", "conv_deep_kernel 192x256", "conv_deep_kernel 224x256",
+                                "conv_deep_kernel 64x256", "conv_deep_kernel 96x256", "conv_deep_kernel 128x256"};
   const int v = e->stages[i].variant;
-  const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 14 ? names[v] : "");
+  const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 20 ? names[v] : "");
   strncpy(name_out, s, 95);
   name_out[95] = 0;
   return RS_OK;

@@ -99,10 +99,12 @@ def test_conv3x3_256(gpu_required, glds, variant):
     _check_close(got, ref)
 
 
-@pytest.mark.parametrize("variant", [4, 12])
+@pytest.mark.parametrize("variant", [4, 12, 15, 16, 17, 18, 19, 20])
 def test_conv3x3_256_big_tiles(gpu_required, variant):
-    """256x256 workgroup tiles (variant 4 = conv_igemm<2,4,4,8>, variant 12 = conv_deep, production for deep-K layers):
-    ragged M (not a multiple of 256), residual + ReLU epilogue."""
+    """256x256 workgroup tiles (variant 4 = conv_igemm<2,4,4,8>, variant 12 = conv_deep, production for deep-K layers; 12 tiles
+    here, so every tile of the conv_deep launch runs as two 128-pixel halves -- the split last round) and conv_deep with tiles of
+    160 / 192 / 224 (15 / 16 / 17: odd numbers of 16-pixel blocks per wave stage a half-used pass) and 64 / 96 / 128 pixels (18 / 19 /
+    20): ragged M (not a multiple of any tile height), residual + ReLU epilogue."""
     g = torch.Generator().manual_seed(10)
     x = _r16(torch.randn(3, 256, 33, 29, generator=g))
     w = _r16(torch.randn(256, 256, 3, 3, generator=g) * 0.03)

@@ -1,43 +1,51 @@
 #!/usr/bin/env python3
-"""Time rs_op_conv2d on the HBM-bound layer shapes of the backbone (batch 16) for a few tile variants."""
-import ctypes as C, os, sys, time
-import numpy as np, torch
+"""Time rs_op_conv2d tile variants on the small-map layers of the batch-16 forward (res4 / res5 / laterals / fc2), where the pixel
+count fills the 256 CUs badly in 256-pixel tiles.  Kernel time by HIP events on the null stream, 200 back-to-back launches after
+a 1 s warm-up.  Usage: conv_shapes.py [variant ...]   (default 7 0 12 15 16 17)"""
+import ctypes as C
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from proj_roadsurf_amd.engine import load_library, _check
-lib = load_library()
+import torch
+from proj_roadsurf_amd import engine as E
+
+lib = E.load_library(os.environ.get("RS_LIB") or None)
 dev = torch.device("cuda:0")
-
-def bench(name, n, hw, cin, cout, k, res, variant, iters=30):
+variants = [int(v) for v in sys.argv[1:]] or [7, 0, 12, 15, 16, 17]
+B = int(os.environ.get("BATCH", "16"))
+shapes = [("res4.x.conv1", B, 50, 50, 1024, 1, 256), ("res4.0.conv1", B, 50, 50, 512, 1, 256), ("res4.x.conv2", B, 50, 50, 256, 3, 256),
+          ("res4.x.conv3", B, 50, 50, 256, 1, 1024), ("fpn_lateral4", B, 50, 50, 1024, 1, 256), ("fpn_lateral3", B, 100, 100, 512, 1, 256),
+          ("res5.x.conv1", B, 25, 25, 2048, 1, 512), ("res5.x.conv2", B, 25, 25, 512, 3, 512), ("res5.x.conv3", B, 25, 25, 512, 1, 2048),
+          ("fpn_lateral5", B, 25, 25, 2048, 1, 256), ("box.fc2", B * 10, 10, 10, 1024, 1, 1024), ("mask.fcn", B * 100, 14, 14, 256, 3, 256)]
+for name, N, H, W, Cin, k, Cout in shapes:
     pad = k // 2
-    x = torch.randn((n, hw + 2, hw + 2, cin), dtype=torch.float16, device=dev)
-    kpad = (k * k * cin + 63) // 64 * 64
-    w = (torch.randn((cout, kpad), dtype=torch.float16, device=dev) * 0.05)
-    b = torch.zeros(cout, dtype=torch.float32, device=dev)
-    out = torch.zeros((n, hw + 2, hw + 2, cout), dtype=torch.float16, device=dev)
-    r = torch.randn((n, hw + 2, hw + 2, cout), dtype=torch.float16, device=dev) if res else None
-    def call():
-        rc = lib.rs_op_conv2d(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()),
-                              C.c_void_p(r.data_ptr()) if r is not None else None, None, n, hw, hw, cin, 1, k, k, 1, pad, cout, kpad, 1, 1, 0, 0, variant, 1, None)
-        _check(lib, rc, "conv")
-    for _ in range(3): call()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters): call()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    m = n * hw * hw
-    by = m * (cin + cout * (2 if res else 1)) * 2
-    fl = 2.0 * m * k * k * cin * cout
-    print(f"{name:34s} v{variant:2d} {ms*1e3:8.1f} us  {by/ms/1e6:7.0f} GB/s  {fl/ms/1e9:7.0f} TFLOP/s", flush=True)
-
-for v in (7, 9, 10):
-    bench("res2.conv3 64->256 +res 200^2", 16, 200, 64, 256, 1, True, v)
-    bench("res2.conv3 64->256 no res", 16, 200, 64, 256, 1, False, v)
-    bench("res2.conv1 256->64... (as 256->256)", 16, 200, 256, 256, 1, False, v)
-    bench("res3.conv3 128->512 +res 100^2", 16, 100, 128, 512, 1, True, v)
-    bench("res4.conv3 256->1024 +res 50^2", 16, 50, 256, 1024, 1, True, v)
-bench("res2.conv1 256->64 200^2", 16, 200, 256, 64, 1, False, 1)
-bench("fpn_out2 3x3 256->256 200^2", 16, 200, 256, 256, 3, False, 0)
-bench("fpn_out2 3x3 256->256 200^2", 16, 200, 256, 256, 3, False, 4)
+    x = torch.randn(N, H + 2 * pad, W + 2 * pad, Cin, device=dev).half()
+    w = (torch.randn(Cout, k * k * Cin, device=dev) * 0.02).half()
+    b = torch.zeros(Cout, device=dev)
+    o = torch.zeros(N, H + 2, W + 2, Cout, device=dev, dtype=torch.float16)
+    flop = 2.0 * N * H * W * k * k * Cin * Cout
+    line = f"{name:13s} M {N * H * W:6d} K {k * k * Cin:5d} N {Cout:4d}:"
+    for v in variants:
+        def launch():
+            return lib.rs_op_conv2d(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(o.data_ptr()), None, None,
+                                    N, H, W, Cin, pad, k, k, 1, pad, Cout, k * k * Cin, 1, 1, 0, 0, v, 1, None)
+        if launch() != 0:
+            line += f"  v{v}: n/a"
+            continue
+        t0 = time.time()
+        while time.time() - t0 < 0.7:
+            for _ in range(50):
+                launch()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 200
+        line += f"  v{v}: {ms * 1e3:6.1f} us {flop / ms / 1e9:6.0f} TF"
+    print(line, flush=True)
