@@ -270,7 +270,12 @@ def main():
             sym = dom.split(" ")[0]                                   # "conv_deep_kernel" or "conv_igemm_kernel<2,4,4,8>"
             want = sym.replace("conv_igemm_kernel<", "").replace(">", "").replace(",", ", ")
             for k in json.load(open(pmc)):
-                hit = (f"conv_igemm_kernel<{want}, false, true" in k["kernel"]) if sym.startswith("conv_igemm") else (sym in k["kernel"])
+                if sym.startswith("conv_igemm"):
+                    hit = f"conv_igemm_kernel<{want}, false, true" in k["kernel"]
+                elif sym == "conv_deep_kernel":                         # the 256-pixel inference instantiation: conv_deep_kernel<0, false, 8> (or <0, false> before the tile height became a parameter)
+                    hit = "conv_deep_kernel<0, false, 8>" in k["kernel"] or "conv_deep_kernel<0, false>" in k["kernel"]
+                else:
+                    hit = sym in k["kernel"]
                 if hit:
                     traffic = k["hbm_bytes_per_launch_corrected"]
                     traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, (2*FETCH+WRITE)*1024 per launch"

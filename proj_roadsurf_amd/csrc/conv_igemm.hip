@@ -553,6 +553,9 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
     }
     if (best != 8) return 10 + best;                                      // 15 / 16 / 17
   }
+  // conv3 + projection shortcut over two K sources (conv_igemm only).  tools/ubench/dual_shapes.py, batch 16: res3.0 (1250 tiles of
+  // 256x256) 106 us on 256x256 vs 129 on 128x128; res4.0 (628) 88 vs 88; res5.0 (320) 91.5 vs 79
+  if (p.in2 && rows % 256 == 0 && nkd >= 6) return tiles4 >= 600 ? 4 : (tiles0 < 1250 ? 7 : 0);
   if (rows % 256 == 0 && nkd >= 8 && tiles4 >= 240)                       // deep K, many rows: 256x256 halves the L2->LDS bytes per FLOP
     return (D.conv_deep && use_glds > 0 && !p.in2 && p.out_stride <= 1) ? 12 : 4;   // conv_deep incl. the backward epilogue (down / res32 / mask)
   // HBM-bound 1x1 layers on big maps: all 256 channels per workgroup, so every activation row is read once; 128 pixels per

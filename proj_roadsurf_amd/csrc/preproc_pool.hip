@@ -81,8 +81,136 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) 
   }
 }
 
+// Tile form of the same arithmetic: a block = 64 output columns x 16 output rows of one tile.  Pillow's tap ranges are monotone in the
+// output coordinate, so the source pixels a block needs are a rectangle; it is staged ONCE into LDS with aligned dword loads and every
+// thread then walks its taps there.  The per-pixel kernel above issues ny * nx * C byte loads from global memory per output pixel and is
+// bound by the texture-address path (0.136 ms per batch of 16 512 -> 800 tiles, 0.7 TB/s); it stays as the fallback for tap tables or
+// resize ratios whose rectangle does not fit the LDS budget below.
+constexpr int PP_ROWS = 16, PP_LDS_BYTES = 40 * 1024, PP_KMAX = 8;
+
+// C (bands), NH / NV (horizontal / vertical pass needed) are compile-time: with run-time values every per-channel statement is a branch
+template <int C, bool NH, bool NV>
+__global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreprocParams p, const long long src_dwords) {
+  __shared__ uint32_t src[PP_LDS_BYTES / 4];
+  const int tid = threadIdx.x, lx = tid & 63;
+  const int ly = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * PP_ROWS, n = blockIdx.z;
+  const int Xl = min(X0 + 63, p.new_w - 1), Yl = min(Y0 + PP_ROWS - 1, p.new_h - 1);
+  // source rectangle of the block (block-uniform)
+  const int cx0 = NH ? p.hb[X0 * 2] : X0;
+  const int cx1 = NH ? p.hb[Xl * 2] + p.hb[Xl * 2 + 1] : Xl + 1;
+  const int ry0 = NV ? p.vb[Y0 * 2] : Y0;
+  const int ry1 = NV ? p.vb[Yl * 2] + p.vb[Yl * 2 + 1] : Yl + 1;
+  const int pitch_dw = (((cx1 - cx0) * C + 3) >> 2) + 1;      // + 1: the row segment starts at any byte of its first dword
+  const int nrows = ry1 - ry0;
+  const long long img0 = (long long)n * p.H * p.W * C;        // byte offset of the tile in the batch buffer (4-byte aligned base)
+  const uint32_t* g32 = (const uint32_t*)p.tiles;
+  for (int i = tid; i < nrows * pitch_dw; i += 256) {
+    const int r = i / pitch_dw, d = i - r * pitch_dw;
+    long long dw = ((img0 + ((long long)(ry0 + r) * p.W + cx0) * C) >> 2) + d;
+    if (dw >= src_dwords) dw = src_dwords - 1;                // slack dwords past the last pixel are never used
+    src[i] = g32[dw];
+  }
+  __syncthreads();
+  const int X = X0 + lx;
+  if (X >= p.new_w) return;
+  int xmin = X, nx = 1;
+  int hkr[PP_KMAX];
+  if (NH) {
+    xmin = p.hb[X * 2]; nx = p.hb[X * 2 + 1];
+    const int* hk = p.hk + (long long)X * p.ksh;
+#pragma unroll
+    for (int t = 0; t < PP_KMAX; ++t) hkr[t] = t < p.ksh ? hk[t] : 0;
+  }
+  const uint8_t* sb = (const uint8_t*)src;
+  const int xoff = (xmin - cx0) * C;
+#pragma unroll 1
+  for (int it = 0; it < PP_ROWS / 4; ++it) {
+    const int Y = Y0 + it * 4 + ly;                           // wave-uniform
+    if (Y >= p.new_h) break;
+    int ymin = Y, ny = 1;
+    if (NV) { ymin = p.vb[Y * 2]; ny = p.vb[Y * 2 + 1]; }
+    const int* vk = p.vk + (long long)Y * p.ksv;
+    int vacc[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+    int val[4] = {0, 0, 0, 0};
+    for (int ty = 0; ty < ny; ++ty) {
+      const int r = ymin + ty - ry0;
+      const int off = (int)((img0 + ((long long)(ymin + ty) * p.W + cx0) * C) & 3);
+      const uint8_t* row = sb + r * pitch_dw * 4 + off + xoff;
+      int h[4] = {0, 0, 0, 0};
+      if (NH) {
+        int ss[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+#pragma unroll
+        for (int tx = 0; tx < PP_KMAX; ++tx) {
+          if (tx >= p.ksh) break;                               // uniform: the tap table's width (3 when enlarging)
+          if (tx < nx) {
+            const uint8_t* px = row + tx * C;
+            const int k = hkr[tx];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < C) ss[c] += __mul24((int)px[c], k);   // 8-bit pixel x 23-bit Pillow coefficient: exact in 24-bit operands
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int v = ss[c] >> 22; h[c] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) h[c] = row[c];
+      }
+      if (NV) {
+        const int k = vk[ty];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vacc[c] += __mul24(h[c], k);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) val[c] = h[c];
+      }
+    }
+    half4 o;
+    float of[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      o[c] = (half_t)0.f;
+      of[c] = 0.f;
+      if (c < C) {
+        const int cs = p.flip ? (C - 1 - c) : c;      // model channel c reads source channel cs
+        int v = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (q == cs) v = NV ? (vacc[q] >> 22) : val[q];
+        if (NV) v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        const float f = ((float)v - p.mean[c]) / p.stdv[c];
+        o[c] = (half_t)f;
+        of[c] = f;
+      }
+    }
+    const long long oidx = (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 4;
+    if (p.out_f32) *(f32x4*)((float*)p.out + oidx) = f32x4{of[0], of[1], of[2], of[3]};
+    else *(half4*)(p.out + oidx) = o;
+  }
+}
+
 int launch_preprocess(const PreprocParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(preprocess_kernel, dim3(cdiv(p.new_w, 64), cdiv(p.new_h, 4), p.N), dim3(256), 0, s, p);
+  // bound of the block's source rectangle: (output extent) * (input / output) + the tap table's width + rounding
+  const long long rows = ((long long)PP_ROWS * p.H + p.new_h - 1) / p.new_h + (p.need_v ? p.ksv : 0) + 2;
+  const long long cols = (64ll * p.W + p.new_w - 1) / p.new_w + (p.need_h ? p.ksh : 0) + 2;
+  const long long lds = rows * (((cols * p.C + 3) >> 2) + 1) * 4;
+  if (lds <= PP_LDS_BYTES && (!p.need_h || p.ksh <= PP_KMAX) && ((uintptr_t)p.tiles & 3) == 0) {
+    // N tiles of the batch live in one allocation rounded up to 256 bytes (rs_engine::alloc): whole dwords up to its end exist
+    const long long src_dwords = ((long long)p.N * p.H * p.W * p.C + 3) >> 2;
+    const dim3 grid(cdiv(p.new_w, 64), cdiv(p.new_h, PP_ROWS), p.N);
+#define RS_PP(Cc, H_, V_) hipLaunchKernelGGL((preprocess_tile_kernel<Cc, H_, V_>), grid, dim3(256), 0, s, p, src_dwords)
+#define RS_PP_C(Cc) do { if (p.need_h) { if (p.need_v) RS_PP(Cc, true, true); else RS_PP(Cc, true, false); } \
+                         else { if (p.need_v) RS_PP(Cc, false, true); else RS_PP(Cc, false, false); } } while (0)
+    switch (p.C) {
+      case 1: RS_PP_C(1); break;
+      case 2: RS_PP_C(2); break;
+      case 3: RS_PP_C(3); break;
+      default: RS_PP_C(4); break;
+    }
+#undef RS_PP_C
+#undef RS_PP
+  } else {
+    hipLaunchKernelGGL(preprocess_kernel, dim3(cdiv(p.new_w, 64), cdiv(p.new_h, 4), p.N), dim3(256), 0, s, p);
+  }
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
