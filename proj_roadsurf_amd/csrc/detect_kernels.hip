@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
 // ---------------------------------------------------------------------------------------------
 #define RS_ROI_WMAX 24   // window rows/cols per bin held in LDS (g <= 22)
 #define RS_ROI_PMAX 14
-__global__ __launch_bounds__(256) void roi_align_win_kernel(const RoiAlignParams p) {
+__global__ __launch_bounds__(256, 6) void roi_align_win_kernel(const RoiAlignParams p) {
   __shared__ float s_w[2][RS_ROI_PMAX][RS_ROI_WMAX];   // [0] = wy[ph][j], [1] = wx[pw][i]
   __shared__ int s_base[2][RS_ROI_PMAX], s_len[2][RS_ROI_PMAX];
   const int entry = blockIdx.x;
