@@ -1,0 +1,92 @@
+"""Tile decode for the drop-in CLIs (the step right before the hot path).
+
+``read_tile`` is the ``cv2.imread`` stand-in.  ``DecodePool`` runs it in worker PROCESSES that write the pixels straight into one
+shared-memory slab of batch-sized groups, so the thread that feeds the GPU gets a ready (n, H, W, C) array per batch without
+touching the pixels and without sharing the interpreter lock with the decoders (decoding in threads, the forward thread spent
+most of its time waiting for that lock: 1 300 tiles/s end to end against 1 900 for the same pipeline fed from memory).
+
+This module imports numpy and Pillow only: the workers are spawned (not forked -- the parent may already hold a HIP context) and
+must start fast."""
+from __future__ import annotations
+
+import multiprocessing as mp
+from multiprocessing import shared_memory
+from typing import Any, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def read_tile(path: str) -> np.ndarray:
+    """``cv2.imread`` stand-in: HWC uint8, channels in BGR(A) order (what DefaultPredictor expects)."""
+    from PIL import Image
+
+    im = np.asarray(Image.open(path))
+    if im.ndim == 2:
+        im = np.stack([im] * 3, axis=-1)
+    if im.dtype != np.uint8:
+        raise ValueError(f"{path}: expected 8-bit tiles, got {im.dtype}")
+    return np.ascontiguousarray(im[:, :, ::-1])
+
+
+_slab: Optional[np.ndarray] = None
+_shm: Optional[shared_memory.SharedMemory] = None
+
+
+def _worker_init(name: str, shape: Tuple[int, ...]) -> None:
+    global _slab, _shm
+    _shm = shared_memory.SharedMemory(name=name)
+    _slab = np.ndarray(shape, np.uint8, buffer=_shm.buf)
+
+
+def _decode_into(slot: int, path: str) -> int:
+    im = read_tile(path)
+    if im.shape != _slab.shape[1:]:
+        raise ValueError(f"{path}: tile shape {im.shape} != {_slab.shape[1:]} (one tile shape per run of the process decoder)")
+    _slab[slot] = im
+    return slot
+
+
+class DecodePool:
+    """``batches(chunks, key)`` yields, per chunk of at most ``batch`` entries, a (n, H, W, C) uint8 view of the slab holding the
+    decoded tiles ``key(entry)`` names; the tiles of the next ``depth`` chunks are being decoded meanwhile.  A view stays valid
+    until two further chunks have been requested (the GPU pipeline has copied a batch into its pinned staging buffer by the time
+    it asks for the next one)."""
+
+    def __init__(self, procs: int, batch: int, tile_shape: Tuple[int, int, int], depth: int = 4):
+        self.batch, self.depth, self.groups = int(batch), int(depth), int(depth) + 2
+        self.tile_shape = tuple(int(x) for x in tile_shape)
+        shape = (self.groups * self.batch,) + self.tile_shape
+        self._shm = shared_memory.SharedMemory(create=True, size=int(np.prod(shape)))
+        self._slab = np.ndarray(shape, np.uint8, buffer=self._shm.buf)
+        self._pool = mp.get_context("spawn").Pool(int(procs), initializer=_worker_init, initargs=(self._shm.name, shape))
+
+    def batches(self, chunks: Sequence[Sequence[Any]], key=lambda e: e) -> Iterator[np.ndarray]:
+        def submit(k: int) -> List[Any]:
+            g = (k % self.groups) * self.batch
+            assert len(chunks[k]) <= self.batch
+            return [self._pool.apply_async(_decode_into, (g + i, key(e))) for i, e in enumerate(chunks[k])]
+        ahead = {k: submit(k) for k in range(min(self.depth, len(chunks)))}
+        for k in range(len(chunks)):
+            for f in ahead.pop(k):
+                f.get()                              # re-raises a worker's exception here
+            if k + self.depth < len(chunks):
+                ahead[k + self.depth] = submit(k + self.depth)
+            g = (k % self.groups) * self.batch
+            yield self._slab[g:g + len(chunks[k])]
+
+    def close(self) -> None:
+        if self._pool is not None:
+            self._pool.terminate()
+            self._pool.join()
+            self._pool = None
+        if self._shm is not None:
+            self._slab = None
+            self._shm.close()
+            self._shm.unlink()
+            self._shm = None
+
+    def __enter__(self) -> "DecodePool":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()

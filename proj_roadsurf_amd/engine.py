@@ -700,7 +700,7 @@ class Predictor:
                     if len(b) > self.max_batch or any(tuple(im.shape) != shape for im in b):
                         carry.append(b)
                         return
-                    yield np.stack(b)
+                    yield b if isinstance(b, np.ndarray) else np.stack(b)      # a decoded batch in shared memory is used in place
                     b = next_batch()
             for res in self._pipe(shape).run(run_of_shape()):
                 yield [{"instances": r} for r in res]

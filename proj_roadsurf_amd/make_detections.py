@@ -26,6 +26,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import yaml
 
+from .decode_pool import DecodePool, read_tile
 from .gpkg import GpkgWriter
 from .shard import run_sharded
 from .spec import load_d2_yaml
@@ -34,18 +35,6 @@ from .weights import infer_num_classes, load_checkpoint, synthetic_weights
 
 SECTION = "make_detections.py"
 log = logging.getLogger("make_detections")
-
-
-def read_tile(path: str) -> np.ndarray:
-    """``cv2.imread`` stand-in: HWC uint8, channels in BGR(A) order (what DefaultPredictor expects)."""
-    from PIL import Image
-
-    im = np.asarray(Image.open(path))
-    if im.ndim == 2:
-        im = np.stack([im] * 3, axis=-1)
-    if im.dtype != np.uint8:
-        raise ValueError(f"{path}: expected 8-bit tiles, got {im.dtype}")
-    return np.ascontiguousarray(im[:, :, ::-1])
 
 
 def tile_extent(meta: Dict[str, Any], file_name: str) -> Tuple[Optional[Sequence[float]], Optional[int]]:
@@ -86,6 +75,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--synthetic-weights", action="store_true",
                     help="use seeded synthetic weights instead of model_weights.pth_file (demo / smoke tests)")
     ap.add_argument("--host-workers", type=int, default=4, help="threads for tile decode / vectorisation around the GPU call")
+    ap.add_argument("--decode-procs", type=int, default=4,
+                    help="worker PROCESSES that decode tiles into shared memory (decode_pool.DecodePool); 0 = decode on the --host-workers threads")
     ap.add_argument("--vector-threads", type=int, default=4, help="threads inside one rs_vectorize_masks call")
     ap.add_argument("--geojson", action="store_true", help="also write <dataset>_detections_..._threshold.geojson (slow: Python feature dicts)")
     ap.add_argument("--tagged-samples", type=int, default=10,
@@ -172,6 +163,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         return res
 
     cur_srs = {"id": -1}
+    pools: Dict[Tuple[int, ...], DecodePool] = {}       # process decoders by tile shape (spawned once, reused by every dataset of that shape)
     for dataset, d in coco.items():
         images = d.get("images", [])
         if args.max_tiles:
@@ -183,8 +175,29 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             if epsg:
                 break
         cur_srs["id"] = int(epsg) if epsg else -1
-        per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
-                               workers=args.host_workers, predict_stream=predict_stream)
+        source = None
+        if args.decode_procs > 0 and images:
+            shape = tuple(read_tile(images[0]["file_name"]).shape)
+            if shape not in pools:
+                pools[shape] = DecodePool(args.decode_procs, args.batch, shape)
+            pool = pools[shape]
+
+            def source(chunks, pool=pool):
+                it = pool.batches(chunks, key=lambda e: os.path.abspath(e["file_name"]))
+                while True:
+                    t = time.perf_counter()
+                    b = next(it, None)
+                    busy["decode"] += time.perf_counter() - t          # here: time the forward thread WAITED for decoded tiles
+                    if b is None:
+                        return
+                    yield b
+        try:
+            per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
+                                   workers=args.host_workers, predict_stream=predict_stream, prepared_source=source)
+        except BaseException:
+            for pl in pools.values():
+                pl.close()
+            raise
         if rank != 0:
             continue
         base = f"{dataset}_detections_at_{thr_tag(thr)}_threshold"
@@ -217,6 +230,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 png = os.path.join(sub, f"{dataset}_det_{os.path.splitext(os.path.basename(e['file_name']))[0]}.png")
                 draw_instances(rgb, inst.pred_boxes, inst.pred_classes, inst.scores, inst.pred_masks, names or None).save(png)
             log.info("%s: %d tagged sample images -> %s/", dataset, min(len(images), args.tagged_samples), sub)
+    for pl in pools.values():
+        pl.close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -81,8 +81,9 @@ def test_run_sharded_single_process():
 
 
 def test_run_sharded_three_stage_pipeline_keeps_order_and_overlaps():
-    """prepare / predict / finish: results come back in item order, every stage sees every batch exactly once, and
-    prepare of batch k+1 has started before predict of batch k returns."""
+    """prepare / predict / finish: results come back in item order, prepare sees every ITEM exactly once (one pool task per item,
+    up to four batches ahead), predict and finish see every batch exactly once, and prepare of batch k+1 has started before
+    predict of batch k returns."""
     import threading, time
     items = list(range(23))
     log, lock = [], threading.Lock()
@@ -106,13 +107,14 @@ def test_run_sharded_three_stage_pipeline_keeps_order_and_overlaps():
 
     out = run_sharded(items, predict, batch=4, prepare=prepare, finish=finish, workers=3)
     assert out == [(x, x * 10 + 1) for x in items]
-    for tag in ("prep", "gpu", "fin"):
+    assert sorted(v for t, v in log if t == "prep") == items
+    for tag in ("gpu", "fin"):
         assert sorted(v for t, v in log if t == tag) == [0, 4, 8, 12, 16, 20]
     assert log.index(("prep", 4)) < log.index(("gpu", 4)) and log.index(("prep", 8)) < log.index(("fin", 4)) + 3
 
 
 def test_run_sharded_streaming_form_keeps_order_and_pulls_lazily():
-    """``predict_stream``: the batches reach the predictor as ONE lazy iterator (at most two prepared batches ahead of what it has
+    """``predict_stream``: the batches reach the predictor as ONE lazy iterator (decoded up to four batches ahead of what it has
     consumed) and the per-item results come back in item order, ragged last batch included."""
     from proj_roadsurf_amd.shard import run_sharded
     items = list(range(23))

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--host-workers", type=int, default=4)
     ap.add_argument("--vector-threads", type=int, default=4)
+    ap.add_argument("--decode-procs", type=int, default=4)
     ap.add_argument("--weights", choices=["random", "trained"], default="random",
                     help="random: synthetic_weights (speckle masks, ~1900 polygons per tile); trained: synthetic.train_trained_like on "
                          "synthetic scenes (a handful of clean objects per tile, like a trained detector on real tiles)")
@@ -66,7 +67,8 @@ def main():
         cwd = os.getcwd()
         t0 = time.time()
         rc = make_detections.main([os.path.join(td, "config.yaml"), *extra, "--batch", str(args.batch),
-                                   "--host-workers", str(args.host_workers), "--vector-threads", str(args.vector_threads)])
+                                   "--host-workers", str(args.host_workers), "--vector-threads", str(args.vector_threads),
+                                   "--decode-procs", str(args.decode_procs)])
         dt = time.time() - t0
         os.chdir(cwd)
         size = os.path.getsize(os.path.join(wd, "oth_detections_at_0dot05_threshold.gpkg"))
