@@ -54,6 +54,7 @@ struct RsDebug {
   int narrow_roialign = 0;        // RS_NARROW_ROIALIGN
   int use_glds = 1;               // RS_USE_GLDS              0: register staging instead of LDS-DMA
   int fuse_shortcut = 1;          // RS_FUSE_SHORTCUT
+  int fuse_stem = 1;              // RS_FUSE_STEM             stem conv + ReLU + max-pool in one launch (stem_fused.hip)
   int fuse_bneck = 1;             // RS_FUSE_BNECK            conv2 + conv3 + next conv1 of the res2 identity blocks in one launch
   int deep_tile_px = 1;           // RS_DEEP_TILE_PX          conv_deep with 160 / 192 / 224-pixel tiles where 256 fill the CUs badly (variants 15-17)
   int deep_tail = 1;              // RS_DEEP_TAIL             conv_deep: split the tiles of a last round that fills at most half the chip
@@ -148,6 +149,19 @@ struct ConvParams {
 int launch_conv(const ConvParams& p, hipStream_t stream, int force_variant /* -1 auto */, int use_glds);
 int conv_choose_variant(ConvParams& p, int force_variant, int use_glds);   // the dispatch rule (also sets p.stages / p.persist)
 extern thread_local int g_last_conv_variant;
+
+// ------------------------------------------------------------------ fused stem (stem_fused.hip): conv 7x7 s2 + ReLU + max-pool 3x3 s2
+struct StemPoolParams {
+  const half_t* in;     // [N][in_Hp][in_Wp][4] fp16, halo 3
+  const half_t* wf;     // the [64][256] stem matrix (k = kh*32 + kw*4 + c: 8 taps per filter row, the 8th zero) in MFMA A-fragment order:
+                        // [kh 7][16-row block 4][lane 64][8] (weights.py "stem.conv1f")
+  const float* bias;    // [64]
+  half_t* out;          // pooled map [N][Hq+2][Wq+2][64], halo 1
+  int N, in_Hp, in_Wp;
+  int Hc, Wc;           // conv output size
+  int Hq, Wq;           // pooled size
+};
+int launch_stem_pool(const StemPoolParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------ fused bottleneck tail (bneck_fused.hip)
 // conv2 (3x3 64->64) + conv3 (1x1 64->256, + residual + ReLU) [+ the next block's conv1 (1x1 256->64)] of an identity-shortcut

@@ -29,7 +29,7 @@ void rs_debug_reload() {
   rd("RS_CONV_SINGLE_STAGE_NK", &d.conv_single_stage_nk); rd("RS_CONV_PERSIST", &d.conv_persist); rd("RS_CONV_TUNED", &d.conv_tuned);
   rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_CONV_WIDE_PX", &d.conv_wide_px); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
   rd("RS_DECONV_VARIANT", &d.deconv_variant); rd("RS_FUSE_MASK_PREDICTOR", &d.fuse_mask_predictor); rd("RS_SIDE_STREAM", &d.side_stream);
-  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_DEEP_TILE_PX", &d.deep_tile_px); rd("RS_FUSE_BNECK", &d.fuse_bneck);
+  rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_DEEP_TILE_PX", &d.deep_tile_px); rd("RS_FUSE_BNECK", &d.fuse_bneck); rd("RS_FUSE_STEM", &d.fuse_stem);
   rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
   rd("RS_TRAIN_SIDE", &d.train_side); rd("RS_WGRAD_TARGET", &d.wgrad_target); rd("RS_WGRAD_CB", &d.wgrad_cb);
   rd("RS_SELECT_DEBUG", &d.select_debug); rd("RS_NMS_DEBUG", &d.nms_debug); rd("RS_ROI_WINDOW", &d.roi_window);
@@ -240,6 +240,7 @@ struct rs_engine {
   int use_graph = 0;
   int fuse_shortcut = 1;
   int fuse_bneck = 1;
+  int fuse_stem = 1;      // stem conv + ReLU + max-pool as one launch (inference engines, fp16 path)
   int merge_levels = 1;   // FPN output convs / RPN 3x3 of all levels as one multi-map launch each (inference engines, fp16 path)
   long long forward_index = 0;
   std::set<int> warmed;
@@ -514,6 +515,23 @@ int rs_engine::build() {
   Act stem, c1;
   if ((rc = new_act(&stem, "stem_conv", NB, h2, w2, S.stem_out_channels, 1))) return rc;
   if ((rc = new_act(&c1, "stem", NB, h4, w4, S.stem_out_channels, 1))) return rc;
+  const BlobEntry* stem_w = findw(bu + "stem.conv1f");          // fragment-ordered copy of the 64 x 256 stem matrix
+  const BlobEntry* stem_b = find(bu + "stem.conv1.b");
+  if (fuse_stem && !f32 && use_glds > 0 && S.stem_out_channels == 64 && x0.C == 4 && x0.pad == 3 && stem_w && stem_b &&
+      (long long)stem_w->dims[0] * stem_w->dims[1] == 7 * 4 * 64 * 8 && (pad_h & 3) == 0 && (pad_w & 3) == 0) {
+    // conv 7x7 s2 + FrozenBN + ReLU + max-pool 3x3 s2 in one launch (stem_fused.hip): the 400 x 400 x 64 map never reaches HBM
+    StemPoolParams sp;
+    memset(&sp, 0, sizeof sp);
+    sp.in = x0.p; sp.wf = (const half_t*)stem_w->dev; sp.bias = (const float*)stem_b->dev; sp.out = c1.p;
+    sp.in_Hp = x0.Hp(); sp.in_Wp = x0.Wp();
+    sp.Hc = h2; sp.Wc = w2; sp.Hq = h4; sp.Wq = w4;
+    Stage st;
+    st.name = "stem.conv1+maxpool";
+    st.flops_per_image = 2.0 * h2 * w2 * 49.0 * S.in_channels * 64;
+    st.bytes_per_image = 2.0 * ((double)pad_h * pad_w * 4 + (double)h4 * w4 * 64);
+    st.fn = [sp](int n, hipStream_t s) mutable { sp.N = n; g_last_conv_variant = 21; return launch_stem_pool(sp, s); };
+    stages.push_back(st);
+  } else {
   if ((rc = add_conv("stem.conv1", bu + "stem.conv1", x0, stem, 7, 2, 3, true, nullptr, nullptr, S.in_channels))) return rc;
   {
     Stage st;
@@ -525,6 +543,7 @@ int rs_engine::build() {
                : launch_maxpool(stem.p, c1.p, n, stem.H, stem.W, c1.H, c1.W, c1.C, s);
     };
     stages.push_back(st);
+  }
   }
 
   // ---- res2..res5
@@ -1185,8 +1204,9 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   if (e->f32) e->use_glds = -1;
   e->fuse_shortcut = rs_debug().fuse_shortcut;
   e->fuse_bneck = rs_debug().fuse_bneck;
+  e->fuse_stem = rs_debug().fuse_stem;
   e->merge_levels = rs_debug().merge_levels;
-  if (g_trainer_unfused_shortcut) { e->fuse_shortcut = 0; e->fuse_bneck = 0; e->merge_levels = 0; }   // the training engine differentiates every convolution separately and needs every layer output
+  if (g_trainer_unfused_shortcut) { e->fuse_shortcut = 0; e->fuse_bneck = 0; e->merge_levels = 0; e->fuse_stem = 0; }   // the training engine differentiates every convolution separately and needs every layer output
   e->use_graph = rs_debug().use_graph;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
   else {
@@ -1410,9 +1430,10 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
                                 "bneck_tail_kernel 128 px (conv2 + conv3 + next conv1 chained through registers)",
                                 "conv_igemm_kernel<2,4,4,4> 128x256",
                                 "conv_deep_kernel 160x256", "conv_deep_kernel 192x256", "conv_deep_kernel 224x256",
-                                "conv_deep_kernel 64x256", "conv_deep_kernel 96x256", "conv_deep_kernel 128x256"};
+                                "conv_deep_kernel 64x256", "conv_deep_kernel 96x256", "conv_deep_kernel 128x256",
+                                "stem_pool_kernel (conv 7x7 s2 + ReLU + max-pool 3x3 s2, 8x8 pooled pixels per workgroup)"};
   const int v = e->stages[i].variant;
-  const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 20 ? names[v] : "");
+  const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 21 ? names[v] : "");
   strncpy(name_out, s, 95);
   name_out[95] = 0;
   return RS_OK;

@@ -268,6 +268,16 @@ def engine_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], w_dtype=np.float1
             wpad = np.zeros(w.shape[:3] + (STEM_KW_PAD,), np.float32)
             wpad[..., : w.shape[3]] = w
             T[name + ".w"] = _ohwi(wpad, STEM_CIN_PAD, w_dtype)
+            if w_dtype == np.float16 and T[name + ".w"].shape[0] == 64 and w.shape[2] == 7:
+                # the same matrix in MFMA A-fragment order for the fused stem (csrc/stem_fused.hip): fragment (kh, mi) = 64 lanes x 8
+                # values, lane l = row mi*16 + (l & 15), k = kh*32 + (l >> 4)*8 .. +7 -- a linear 28 KB copy into LDS
+                m = T[name + ".w"]
+                lane = np.arange(64)
+                frag = np.empty((7, 4, 64, 8), m.dtype)
+                for kh in range(7):
+                    for mi in range(4):
+                        frag[kh, mi] = m[(mi * 16 + (lane & 15))[:, None], (kh * 32 + (lane >> 4) * 8)[:, None] + np.arange(8)[None, :]]
+                T[name[: -len("conv1")] + "conv1f.w"] = np.ascontiguousarray(frag.reshape(7 * 4 * 64, 8))
         else:
             T[name + ".w"] = _ohwi(w, cin, w_dtype)
         T[name + ".b"] = b.astype(np.float32)

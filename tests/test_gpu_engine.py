@@ -555,6 +555,31 @@ def test_engine_launches_the_tabled_variants(gpu_required):
         eng.close()
 
 
+def test_fused_stem_changes_no_bit(gpu_required, monkeypatch):
+    """conv 7x7 s2 + ReLU + max-pool in one launch (csrc/stem_fused.hip: conv outputs of an 8x8 pooled patch kept in LDS) against the
+    stand-alone stem conv followed by the pooling kernel (RS_FUSE_STEM=0): the pooled map and the detections are bit-identical -- same
+    MFMA K order, same fp16 rounding before the max.  3-band and 4-band tiles, up- and down-scaling, a non-square input."""
+    for shape, kw in (((512, 512, 3), {}), ((1024, 1024, 4), {}), ((300, 420, 3), dict(min_size_test=320, max_size_test=533))):
+        spec = EngineSpec(num_classes=2, **kw)
+        if shape[2] == 4:
+            spec = spec.replace(pixel_mean=(103.53, 116.28, 123.675, 110.0), pixel_std=(1.0, 1.0, 1.0, 1.0))
+        W = synthetic_weights(spec, seed=0)
+        tiles = synthetic_tiles(2, *shape, seed=11)
+        outs = []
+        for env in ("1", "0"):
+            monkeypatch.setenv("RS_FUSE_STEM", env)
+            eng = Engine(spec, W, shape, max_batch=2)
+            try:
+                dets = eng.infer(tiles)
+                outs.append((dets, eng.tensor("stem").copy(), list(eng.stage_variants())))
+            finally:
+                eng.close()
+        (d1, s1, n1), (d0, s0, n0) = outs
+        assert "stem.conv1+maxpool" in n1 and "stem.conv1" in n0
+        assert float(np.abs(s1.astype(np.float32)).max()) > 0 and np.array_equal(s1, s0), shape
+        assert all(_same_instances(a, b) for a, b in zip(d0, d1))
+
+
 def test_merged_level_launches_and_split_tail_change_no_bit(gpu_required, monkeypatch):
     """The FPN output convolutions of p2..p5 and the shared RPN 3x3 over p2..p6 run as one multi-map conv_deep launch each, and
     a last round that fills at most half the chip runs as 128-pixel tiles (csrc/conv_deep.hip).  Neither changes the arithmetic

@@ -57,7 +57,7 @@ def conv_stage_shapes(spec, net_h=800, net_w=800):
     tile-dispatch tests enumerate.  Output pixels per tile times the batch size is the GEMM's M."""
     out = []
     h2, w2, h4, w4 = net_h // 2, net_w // 2, net_h // 4, net_w // 4
-    out.append(("stem.conv1", h2 * w2, 4, 7, spec.stem_out_channels, 0, None))
+    out.append(("stem.conv1+maxpool", h2 * w2, 4, 7, spec.stem_out_channels, 0, 21))     # csrc/stem_fused.hip
     cur_c, bott, cout, ch, cw = spec.stem_out_channels, 64, spec.res2_out_channels, h4, w4
     have_t1 = False
     for si, nb in enumerate(spec.res_blocks):
