@@ -560,7 +560,8 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
     return (D.conv_deep && use_glds > 0 && !p.in2 && p.out_stride <= 1) ? 12 : 4;   // conv_deep incl. the backward epilogue (down / res32 / mask)
   // HBM-bound 1x1 layers on big maps: all 256 channels per workgroup, so every activation row is read once; 128 pixels per
   // workgroup restage the 128 KB weight matrix half as often as 64 (fpn_lateral2 0.241 -> 0.210 ms, fused deconv 0.338 -> 0.267 ms)
-  if (rows % 256 == 0 && nkd <= 4 && p.M >= 100000) return D.conv_wide_px == 64 ? 10 : 14;
+  // (res4.x.conv3 at batch 16, 40 000 pixels: 38.9 us against 44.0 on the 64x128 tile, tools/ubench/conv_shapes.py)
+  if (rows % 256 == 0 && nkd <= 4 && p.M >= 40000) return D.conv_wide_px == 64 ? 10 : 14;
   if (nkd <= 4 || tiles0 < 1250) return 7;                                // few tiles or shallow K: 64x128 keeps more workgroups in flight
   return 0;
 }
