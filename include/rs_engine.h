@@ -135,6 +135,10 @@ int rs_engine_phase_count(void);
  * rs_engine_fetch_wait returns. */
 void* rs_host_alloc(size_t nbytes);
 void rs_host_free(void* p);
+/* Pin / unpin an existing host allocation (e.g. a shared-memory slab that decoder processes fill) so that rs_engine_upload_async
+ * copies straight out of it; the caller keeps the bytes unchanged until the forward that consumes them has delivered its results. */
+int rs_host_register(void* p, size_t bytes);
+int rs_host_unregister(void* p);
 int rs_engine_upload_async(rs_engine* e, const uint8_t* tiles_host, int n);
 int rs_engine_fetch_async(rs_engine* e, int n, rs_dets* out_host);
 int rs_engine_fetch_wait(rs_engine* e);

@@ -1296,6 +1296,19 @@ void* rs_host_alloc(size_t nbytes) {
 }
 void rs_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+// Pin an existing host allocation (the CLI's shared-memory slab of decoded tiles) so that rs_engine_upload_async can copy straight out
+// of it: a pageable source makes hipMemcpyAsync stage the bytes through the runtime on the calling thread.
+int rs_host_register(void* p, size_t bytes) {
+  RS_CHECK(p && bytes > 0, RS_ERR_ARG, "bad argument");
+  RS_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return RS_OK;
+}
+int rs_host_unregister(void* p) {
+  RS_CHECK(p, RS_ERR_ARG, "bad argument");
+  RS_HIP(hipHostUnregister(p));
+  return RS_OK;
+}
+
 int rs_engine_upload_async(rs_engine* e, const uint8_t* tiles_host, int n) {
   RS_CHECK(e && tiles_host && n >= 1 && n <= e->max_batch, RS_ERR_ARG, "bad argument");
   RS_HIP(hipMemcpyAsync(e->tiles_dev, tiles_host, (size_t)n * e->tile_h * e->tile_w * e->tile_c, hipMemcpyHostToDevice, e->stream));

@@ -49,11 +49,14 @@ def _decode_into(slot: int, path: str) -> int:
 class DecodePool:
     """``batches(chunks, key)`` yields, per chunk of at most ``batch`` entries, a (n, H, W, C) uint8 view of the slab holding the
     decoded tiles ``key(entry)`` names; the tiles of the next ``depth`` chunks are being decoded meanwhile.  A view stays valid
-    until two further chunks have been requested (the GPU pipeline has copied a batch into its pinned staging buffer by the time
-    it asks for the next one)."""
+    until ``spare`` further chunks have been requested."""
 
-    def __init__(self, procs: int, batch: int, tile_shape: Tuple[int, int, int], depth: int = 4):
-        self.batch, self.depth, self.groups = int(batch), int(depth), int(depth) + 2
+    def __init__(self, procs: int, batch: int, tile_shape: Tuple[int, int, int], depth: int = 4, spare: int = 2):
+        # spare: groups a consumer may still be reading when a chunk's group is handed back to the decoders.  2 for a consumer that
+        # copies a batch before asking for the next one; lanes + 2 for engine.LanePipeline reading the (registered) slab directly:
+        # with L lanes, asking for chunk k + spare means batch k + spare - 1 - L has delivered its results, so the upload of chunk k,
+        # which precedes it on the stream, has completed.
+        self.batch, self.depth, self.groups = int(batch), int(depth), int(depth) + int(spare)
         self.tile_shape = tuple(int(x) for x in tile_shape)
         shape = (self.groups * self.batch,) + self.tile_shape
         self._shm = shared_memory.SharedMemory(create=True, size=int(np.prod(shape)))
@@ -73,6 +76,11 @@ class DecodePool:
                 ahead[k + self.depth] = submit(k + self.depth)
             g = (k % self.groups) * self.batch
             yield self._slab[g:g + len(chunks[k])]
+
+    @property
+    def slab(self) -> np.ndarray:
+        """The whole shared-memory array ((groups * batch, H, W, C) uint8) -- what engine.register_host_buffer pins."""
+        return self._slab
 
     def close(self) -> None:
         if self._pool is not None:

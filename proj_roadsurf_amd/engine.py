@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import time
 from typing import Any, Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -263,6 +264,34 @@ class Instances:
         return d
 
 
+_REGISTERED_HOST: List[Tuple[int, int]] = []        # [lo, hi) address ranges pinned with rs_host_register
+
+
+def register_host_buffer(buf: np.ndarray, lib_path: Optional[str] = None) -> bool:
+    """Pin the memory behind ``buf`` (e.g. ``decode_pool.DecodePool.slab``, a shared-memory array that decoder processes fill) so
+    that ``Engine.upload_async`` / ``LanePipeline.run`` copy batches that are views of it straight to the device instead of
+    staging them through the engine's own pinned buffer (a 12.6 MB memcpy per batch of 16 512x512 tiles on the thread that feeds
+    the GPU).  The caller must leave a batch untouched until the forward that consumed it has delivered its results.  Returns
+    False (and changes nothing) if the runtime refuses to pin the range."""
+    lib = load_library(lib_path)
+    lib.rs_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lo = buf.ctypes.data
+    if lib.rs_host_register(C.c_void_p(lo), buf.nbytes) != 0:
+        return False
+    _REGISTERED_HOST.append((lo, lo + buf.nbytes))
+    return True
+
+
+def unregister_host_buffer(buf: np.ndarray, lib_path: Optional[str] = None) -> None:
+    lib = load_library(lib_path)
+    lib.rs_host_unregister.argtypes = [C.c_void_p]
+    lo = buf.ctypes.data
+    for r in list(_REGISTERED_HOST):
+        if r[0] == lo:
+            _REGISTERED_HOST.remove(r)
+            lib.rs_host_unregister(C.c_void_p(lo))
+
+
 class Engine:
     """One engine = one process, one GPU, one tile shape, batches up to ``max_batch``."""
 
@@ -384,6 +413,11 @@ class Engine:
         n = tiles.shape[0]
         if tiles.dtype != np.uint8 or tiles.shape[1:] != (self.tile_h, self.tile_w, self.tile_c) or not 1 <= n <= self.max_batch:
             raise ValueError(f"tiles must be uint8 (<= {self.max_batch},{self.tile_h},{self.tile_w},{self.tile_c}), got {tiles.dtype} {tiles.shape}")
+        addr = tiles.ctypes.data
+        if tiles.flags.c_contiguous and any(lo <= addr and addr + tiles.nbytes <= hi for lo, hi in _REGISTERED_HOST):
+            # the batch already sits in pinned memory (a registered slab, see register_host_buffer): copy straight out of it
+            _check(self.lib, self.lib.rs_engine_upload_async(self._h, C.c_void_p(addr), n), "rs_engine_upload_async")
+            return self.tensor_ptr("tiles")[0]
         self._stage_tiles[:n] = tiles
         _check(self.lib, self.lib.rs_engine_upload_async(self._h, self._stage_tiles.ctypes.data_as(C.c_void_p), n), "rs_engine_upload_async")
         return self.tensor_ptr("tiles")[0]
@@ -590,7 +624,16 @@ class LanePipeline:
             submit(k): upload(k), phase0(k), phase2(k-1) + fetch_async(k-1), phase1(k);   then collect + yield batch k-2."""
         L = len(self.engines)
         inflight = []                               # (lane, n) of submitted batches not yet yielded
-        for tiles in batches:
+        T = self.timing = {"pull": 0.0, "wait_results": 0.0, "upload": 0.0, "enqueue": 0.0, "collect": 0.0, "batches": 0}
+        clock = time.perf_counter
+        it = iter(batches)
+        while True:
+            t0 = clock()
+            tiles = next(it, None)                  # the source's time (decode wait) is not the pipeline's
+            T["pull"] += clock() - t0
+            if tiles is None:
+                break
+            T["batches"] += 1
             n = int(tiles.shape[0])
             lane = self.k % L
             e = self.engines[lane]
@@ -605,9 +648,14 @@ class LanePipeline:
                 # this lane's previous batch: its result copy was enqueued one submit ago; once it has landed the lane's pinned
                 # staging buffer (upload) is free again.  The other lane's batch keeps the GPU busy meanwhile.
                 ol, on = inflight.pop(0)
+                t0 = clock()
                 self.engines[ol].wait_results()
+                T["wait_results"] += clock() - t0
                 done = (ol, on)
+            t0 = clock()
             ptr = e.upload_async(np.ascontiguousarray(tiles))
+            t1 = clock()
+            T["upload"] += t1 - t0
             e.infer_phase(ptr, n, 0)
             if self._pending is not None:
                 pl, pp, pn = self._pending
@@ -615,10 +663,14 @@ class LanePipeline:
                 self.engines[pl].fetch_async(pn)
                 self._pending = None
             e.infer_phase(ptr, n, 1)
+            T["enqueue"] += clock() - t1
             self._pending = (lane, ptr, n)
             inflight.append((lane, n))
             if done is not None:                    # host-side collection overlaps the batches just enqueued; this lane's next
-                yield self.engines[done[0]].collect_results(done[1])      # fetch_async comes one submit later
+                t0 = clock()
+                res = self.engines[done[0]].collect_results(done[1])      # fetch_async comes one submit later
+                T["collect"] += clock() - t0
+                yield res
         if self._pending is not None:
             pl, pp, pn = self._pending
             self.engines[pl].infer_phase(pp, pn, 2)

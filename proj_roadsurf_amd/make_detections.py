@@ -179,7 +179,10 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         if args.decode_procs > 0 and images:
             shape = tuple(read_tile(images[0]["file_name"]).shape)
             if shape not in pools:
-                pools[shape] = DecodePool(args.decode_procs, args.batch, shape)
+                from .engine import register_host_buffer
+                pools[shape] = DecodePool(args.decode_procs, args.batch, shape, spare=predictor.lanes + 2)
+                if not register_host_buffer(pools[shape].slab):      # pinned: batches go from the slab to the device without a staging copy
+                    log.info("the decode slab could not be pinned; batches are staged through the engine's own pinned buffer")
             pool = pools[shape]
 
             def source(chunks, pool=pool):
@@ -196,7 +199,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                                    workers=args.host_workers, predict_stream=predict_stream, prepared_source=source)
         except BaseException:
             for pl in pools.values():
-                pl.close()
+                pl.close()           # (the pinned registration dies with the process)
             raise
         if rank != 0:
             continue
@@ -216,6 +219,11 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                  len(images) / max(dt, 1e-9), base)
         log.info("%s: stage busy time (summed over threads) decode %.2f s, predict %.2f s, vectorise %.2f s, write %.2f s",
                  dataset, busy["decode"], busy["predict"], busy["vectorise"], dt_write)
+        for shp, pl in getattr(predictor, "_pipes", {}).items():
+            tm = getattr(pl, "timing", None)
+            if tm and tm["batches"]:
+                log.info("%s: forward thread per batch of %s tiles: wait for input %.2f ms, wait for results %.2f, upload %.2f, enqueue %.2f, collect %.2f (%d batches)",
+                         dataset, shp, *(1e3 * tm[k] / tm["batches"] for k in ("pull", "wait_results", "upload", "enqueue", "collect")), tm["batches"])
         busy.update({k: 0.0 for k in busy})
         sub = cfg.get("sample_tagged_img_subfolder")
         if sub and args.tagged_samples > 0:
@@ -231,6 +239,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 draw_instances(rgb, inst.pred_boxes, inst.pred_classes, inst.scores, inst.pred_masks, names or None).save(png)
             log.info("%s: %d tagged sample images -> %s/", dataset, min(len(images), args.tagged_samples), sub)
     for pl in pools.values():
+        from .engine import unregister_host_buffer
+        unregister_host_buffer(pl.slab)
         pl.close()
     if world > 1:
         import torch.distributed as dist

@@ -54,3 +54,17 @@ def test_run_sharded_with_a_prepared_source(tmp_path):
         out = run_sharded(paths, None, 4, finish=lambda items, raw: list(zip(items, raw)), predict_stream=stream,
                           prepared_source=lambda chunks: pool.batches(chunks))
     assert out == [(p, int(read_tile(p).sum())) for p in paths]
+
+
+def test_register_host_buffer_without_a_device_is_a_clean_no():
+    """engine.register_host_buffer pins the decode slab for direct uploads; where the runtime cannot pin (no HIP device here) it
+    says False and the engine keeps staging through its own pinned buffer."""
+    from proj_roadsurf_amd import engine as E
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a device is present: covered by the GPU CLI test")
+    except ImportError:
+        pass
+    a = np.zeros((4, 8, 8, 3), np.uint8)
+    assert E.register_host_buffer(a) is False and not E._REGISTERED_HOST
