@@ -8,7 +8,6 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 bash $ROOT/tools/profile_bench.sh > $OUT/profile_bench.log 2>&1
 cd $ROOT
-python3 tools/pmc_summary.py --help > /dev/null 2>&1 || true
 cp $OUT/pmc_hbm_per_kernel.json $ROOT/profiles/pmc_latest.json          # bench.py reads the traffic of the dominant kernel from here
 python3 bench.py > $OUT/bench_b16.json 2> $OUT/bench_b16.err
 python3 bench.py --no-cpu-baseline --no-fp32-mode --lanes 1 --stages > $OUT/bench_b16_lane1.json 2> $OUT/bench_b16_stage_table.txt
