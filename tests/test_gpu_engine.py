@@ -624,6 +624,24 @@ def test_merged_level_launches_and_split_tail_change_no_bit(gpu_required, monkey
         assert r["frac_matched"] >= 0.9, r
 
 
+def test_every_batch_size_gives_the_same_detections(gpu_required):
+    """The tile dispatch, the split last round of conv_deep, the multi-map launches and the tile heights all depend on the batch
+    size.  Every batch size from 1 to 16 must give each tile the detections it gets alone, bit for bit."""
+    spec = EngineSpec(num_classes=2)
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(16, 512, 512, 3, seed=2468)
+    eng = Engine(spec, W, (512, 512, 3), max_batch=16)
+    try:
+        alone = [eng.infer(tiles[i:i + 1])[0] for i in range(16)]
+        assert all(len(d) > 0 for d in alone)
+        for b in range(2, 17):
+            got = eng.infer(tiles[:b])
+            for i in range(b):
+                assert _same_instances(alone[i], got[i]), f"batch {b}: tile {i} differs from the tile run alone"
+    finally:
+        eng.close()
+
+
 def test_config1_batch16_of_512_tiles(gpu_required):
     """BASELINE configs[1], the headline: batch 16 of 512x512x3 tiles, 800x800 network input.
     (a) fp16 production mode: each of the 16 detection sets is BIT-IDENTICAL to the same tile run alone (other tile variants);
