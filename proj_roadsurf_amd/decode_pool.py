@@ -28,6 +28,20 @@ def read_tile(path: str) -> np.ndarray:
     return np.ascontiguousarray(im[:, :, ::-1])
 
 
+class TileShapeError(ValueError):
+    """A tile whose (H, W, C) differs from the slab's: the process decoder serves one tile shape per run."""
+
+
+def tile_header_shape(path: str) -> Tuple[int, int, int]:
+    """(H, W, C) as ``read_tile`` would return it, from the file header only (no pixel decode)."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        w, h = im.size
+        bands = len(im.getbands())
+    return (h, w, 3 if bands == 1 else bands)
+
+
 _slab: Optional[np.ndarray] = None
 _shm: Optional[shared_memory.SharedMemory] = None
 
@@ -41,7 +55,7 @@ def _worker_init(name: str, shape: Tuple[int, ...]) -> None:
 def _decode_into(slot: int, path: str) -> int:
     im = read_tile(path)
     if im.shape != _slab.shape[1:]:
-        raise ValueError(f"{path}: tile shape {im.shape} != {_slab.shape[1:]} (one tile shape per run of the process decoder)")
+        raise TileShapeError(f"{path}: tile shape {im.shape} != {_slab.shape[1:]} (one tile shape per run of the process decoder)")
     _slab[slot] = im
     return slot
 

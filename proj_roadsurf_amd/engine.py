@@ -8,6 +8,7 @@ device is missing the constructor raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import math
 import os
 import time
@@ -264,7 +265,19 @@ class Instances:
         return d
 
 
-_REGISTERED_HOST: List[Tuple[int, int]] = []        # [lo, hi) address ranges pinned with rs_host_register
+_REGISTERED_HOST: List[Tuple[int, int, Any]] = []        # ([lo, hi) address range pinned with rs_host_register, weak reference to the array)
+
+
+def _registered_view(a: np.ndarray) -> bool:
+    """Is ``a`` (a view of) an array pinned by ``register_host_buffer``?  Address AND object identity: an unrelated array that
+    happens to sit at the address of a slab that has gone away must not pass for pinned."""
+    if not a.flags.c_contiguous:
+        return False
+    addr = a.ctypes.data
+    for lo, hi, buf in _REGISTERED_HOST:
+        if lo <= addr and addr + a.nbytes <= hi and buf() is not None and (a is buf() or a.base is buf()):
+            return True
+    return False
 
 
 def register_host_buffer(buf: np.ndarray, lib_path: Optional[str] = None) -> bool:
@@ -278,7 +291,7 @@ def register_host_buffer(buf: np.ndarray, lib_path: Optional[str] = None) -> boo
     lo = buf.ctypes.data
     if lib.rs_host_register(C.c_void_p(lo), buf.nbytes) != 0:
         return False
-    _REGISTERED_HOST.append((lo, lo + buf.nbytes))
+    _REGISTERED_HOST.append((lo, lo + buf.nbytes, weakref.ref(buf)))
     return True
 
 
@@ -414,7 +427,7 @@ class Engine:
         if tiles.dtype != np.uint8 or tiles.shape[1:] != (self.tile_h, self.tile_w, self.tile_c) or not 1 <= n <= self.max_batch:
             raise ValueError(f"tiles must be uint8 (<= {self.max_batch},{self.tile_h},{self.tile_w},{self.tile_c}), got {tiles.dtype} {tiles.shape}")
         addr = tiles.ctypes.data
-        if tiles.flags.c_contiguous and any(lo <= addr and addr + tiles.nbytes <= hi for lo, hi in _REGISTERED_HOST):
+        if _registered_view(tiles):
             # the batch already sits in pinned memory (a registered slab, see register_host_buffer): copy straight out of it
             _check(self.lib, self.lib.rs_engine_upload_async(self._h, C.c_void_p(addr), n), "rs_engine_upload_async")
             return self.tensor_ptr("tiles")[0]

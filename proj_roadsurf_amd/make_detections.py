@@ -26,7 +26,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import yaml
 
-from .decode_pool import DecodePool, read_tile
+from .decode_pool import DecodePool, TileShapeError, read_tile, tile_header_shape
 from .gpkg import GpkgWriter
 from .shard import run_sharded
 from .spec import load_d2_yaml
@@ -62,6 +62,19 @@ def tile_extent(meta: Dict[str, Any], file_name: str) -> Tuple[Optional[Sequence
             epsg = int(digits) if digits else None
             break
     return (list(map(float, ext)) if ext is not None else None), epsg
+
+
+def _close_pools(pools: Dict[Tuple[int, ...], DecodePool]) -> None:
+    """Unpin every decode slab BEFORE its shared memory goes away (a registered range that outlives its mapping would let a later
+    array at a recycled address pass for pinned -- engine.Engine.upload_async), then stop the workers.  Error and normal path."""
+    from .engine import unregister_host_buffer
+    for pl in pools.values():
+        try:
+            if pl.slab is not None:
+                unregister_host_buffer(pl.slab)
+        finally:
+            pl.close()
+    pools.clear()
 
 
 def thr_tag(thr: float) -> str:
@@ -176,16 +189,25 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 break
         cur_srs["id"] = int(epsg) if epsg else -1
         source = None
+        # The process decoder serves ONE tile shape per dataset (its slab is a fixed (n, H, W, C) array); the thread path groups runs of
+        # equal shape as the reference's per-tile cv2.imread loop effectively does.  Decide before starting: COCO width/height when every
+        # entry carries them, the file headers otherwise; a dataset of mixed shapes keeps the thread path.
         if args.decode_procs > 0 and images:
             shape = tuple(read_tile(images[0]["file_name"]).shape)
-            if shape not in pools:
+            if all("width" in e and "height" in e for e in images):
+                uniform = all((int(e["height"]), int(e["width"])) == shape[:2] for e in images)
+            else:
+                uniform = all(tile_header_shape(e["file_name"]) == shape for e in images)
+            if not uniform:
+                log.info("%s: tiles of several shapes -- decoding on the %d host threads instead of the process decoder", dataset, args.host_workers)
+            elif shape not in pools:
                 from .engine import register_host_buffer
                 pools[shape] = DecodePool(args.decode_procs, args.batch, shape, spare=predictor.lanes + 2)
                 if not register_host_buffer(pools[shape].slab):      # pinned: batches go from the slab to the device without a staging copy
                     log.info("the decode slab could not be pinned; batches are staged through the engine's own pinned buffer")
-            pool = pools[shape]
+            pool = pools.get(shape) if uniform else None
 
-            def source(chunks, pool=pool):
+            def pool_source(chunks, pool=pool):
                 it = pool.batches(chunks, key=lambda e: os.path.abspath(e["file_name"]))
                 while True:
                     t = time.perf_counter()
@@ -194,12 +216,20 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                     if b is None:
                         return
                     yield b
+            source = pool_source if pool is not None else None
         try:
-            per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
-                                   workers=args.host_workers, predict_stream=predict_stream, prepared_source=source)
+            try:
+                per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
+                                       workers=args.host_workers, predict_stream=predict_stream, prepared_source=source)
+            except TileShapeError as ex:
+                # the COCO sizes (or the band count of the first tile) did not hold for every file: this dataset again on the thread path
+                log.warning("%s: %s -- running the dataset again with thread decoding", dataset, ex)
+                predictor.close()
+                predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank)
+                per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
+                                       workers=args.host_workers, predict_stream=predict_stream, prepared_source=None)
         except BaseException:
-            for pl in pools.values():
-                pl.close()           # (the pinned registration dies with the process)
+            _close_pools(pools)
             raise
         if rank != 0:
             continue
@@ -238,10 +268,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 png = os.path.join(sub, f"{dataset}_det_{os.path.splitext(os.path.basename(e['file_name']))[0]}.png")
                 draw_instances(rgb, inst.pred_boxes, inst.pred_classes, inst.scores, inst.pred_masks, names or None).save(png)
             log.info("%s: %d tagged sample images -> %s/", dataset, min(len(images), args.tagged_samples), sub)
-    for pl in pools.values():
-        from .engine import unregister_host_buffer
-        unregister_host_buffer(pl.slab)
-        pl.close()
+    _close_pools(pools)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

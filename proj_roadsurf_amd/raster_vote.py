@@ -9,8 +9,8 @@ above 0.05, and ``determine_detected_class`` sums, per road and class, weighted 
 rows, the detection masks never leave HBM), everything after the counts is restated line by line on the host.
 
 Differences from the vector form, by construction: areas are counted in whole pixels of the tile grid (0.4 m at z18,
-R:config/config_obj_detec.yaml:20,45), and RDP simplification (ε 0.75 px) does not enter.  ``overlap_counts_host`` is the numpy
-statement of the device kernel (the oracle of its test)."""
+R:config/config_obj_detec.yaml:20,45), and RDP simplification (ε 0.75 px) does not enter.  The numpy statement of the device kernel (the
+oracle of its test) is ``oracle/host_tail_oracle.py::overlap_counts``."""
 from __future__ import annotations
 
 import ctypes as C
@@ -32,13 +32,6 @@ def label_rasters(label_polygons: Sequence[Sequence[np.ndarray]], h: int, w: int
         m = rasterize_polygons_within_box(polys, np.array([0.0, 0.0, float(w), float(h)]), h)
         out[i] = np.packbits(m, axis=1, bitorder="little")
     return out
-
-
-def overlap_counts_host(det_packed: np.ndarray, lab_packed: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """numpy statement of ``rs_op_mask_overlap``: (inter [n_lab][n_det], label_area [n_lab]) in pixels."""
-    d = np.unpackbits(det_packed.reshape(det_packed.shape[0], -1), axis=1).astype(np.int64)
-    l = np.unpackbits(lab_packed.reshape(lab_packed.shape[0], -1), axis=1).astype(np.int64)
-    return (l @ d.T).astype(np.int32), l.sum(1).astype(np.int32)
 
 
 def overlap_counts_device(lib, det_dev_ptr: int, n_det: int, lab_packed: np.ndarray, h: int, w: int) -> Tuple[np.ndarray, np.ndarray]:

@@ -9,7 +9,8 @@ import pytest
 from scipy import ndimage
 
 from proj_roadsurf_amd.gpkg import read_gpkg, write_gpkg
-from proj_roadsurf_amd.vectorize import instances_to_features, mask_to_polygons, rdp, ring_area, vectorize_masks_native
+from oracle.host_tail_oracle import instances_to_features as oracle_features, mask_to_polygons, rdp, ring_area
+from proj_roadsurf_amd.vectorize import instances_to_features, vectorize_masks_native
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -133,8 +134,8 @@ def test_native_vectorizer_in_features_path():
     masks = np.stack([ndimage.gaussian_filter(rng.random((h, w)), 4) > 0.5 for _ in range(n)])
     inst = Instances((h, w), rng.random((n, 4)).astype(np.float32), rng.random(n).astype(np.float32), np.arange(n) % 2,
                      np.packbits(masks, axis=2, bitorder="little"), None)
-    a = instances_to_features(inst, "t.tif", (0.0, 0.0, 120.0, 96.0), True, 0.75, native=True)
-    b = instances_to_features(inst, "t.tif", (0.0, 0.0, 120.0, 96.0), True, 0.75, native=False)
+    a = instances_to_features(inst, "t.tif", (0.0, 0.0, 120.0, 96.0), True, 0.75)
+    b = oracle_features(inst, "t.tif", (0.0, 0.0, 120.0, 96.0), True, 0.75)
     assert a == b and len(a) >= n
 
 
@@ -152,7 +153,7 @@ def test_native_gpkg_rows_equal_python_writer(tmp_path):
     inst = Instances((h, w), rng.random((n, 4)).astype(np.float32), rng.random(n).astype(np.float32), np.arange(n) % 2,
                      np.packbits(masks, axis=2, bitorder="little"), None)
     for extent, srs in [((2600000.0, 1200000.0, 2600104.6, 1200083.7), 2056), (None, -1)]:
-        feats = instances_to_features(inst, "18_1_2.tif", extent, True, 0.75, native=False)
+        feats = oracle_features(inst, "18_1_2.tif", extent, True, 0.75)
         rows, bbox = instances_to_gpkg_rows(inst, "18_1_2.tif", extent, True, 0.75, srs_id=srs)
         assert len(rows) == len(feats) > n - 1
         for f, (blob, score, cls, image) in zip(feats, rows):
@@ -168,7 +169,7 @@ def test_native_gpkg_rows_equal_python_writer(tmp_path):
     gw.add_rows(rows2, bbox2)
     assert gw.close() == len(rows2)
     back = read_gpkg(p, "t")
-    want = instances_to_features(inst, "18_1_2.tif", (2600000.0, 1200000.0, 2600104.6, 1200083.7), True, 0.75, native=False)
+    want = oracle_features(inst, "18_1_2.tif", (2600000.0, 1200000.0, 2600104.6, 1200083.7), True, 0.75)
     assert [b["geometry"]["coordinates"] for b in back] == [f["geometry"]["coordinates"] for f in want] and back[0]["srs_id"] == 2056
     empty = Instances((h, w), np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int64), np.zeros((0, h, (w + 7) // 8), np.uint8), None)
     assert instances_to_gpkg_rows(empty, "x.tif") == ([], None)
@@ -244,6 +245,56 @@ def test_make_detections_cli_end_to_end(gpu_required, tmp_path):
     assert pngs and all(p.startswith("val_det_") and p.endswith(".png") for p in pngs)
     from PIL import Image
     assert Image.open(wd / "sample_detection_images" / pngs[0]).size == (128, 128) or Image.open(wd / "sample_detection_images" / pngs[0]).size[0] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("coco_sizes", ["true", "absent", "wrong"])
+def test_make_detections_cli_with_one_odd_sized_tile(gpu_required, tmp_path, coco_sizes):
+    """A dataset with one tile of another shape at the DEFAULT --decode-procs: the reference reads tile by tile (cv2.imread) and
+    copes with any mix.  The process decoder serves one shape per dataset, so the CLI decides up front from the COCO sizes
+    ("true"), from the file headers when the COCO entries carry none ("absent"), and falls back to thread decoding when a worker
+    meets a tile the COCO sizes did not announce ("wrong").  Every tile must come out in all three cases."""
+    from PIL import Image
+    import yaml
+    from proj_roadsurf_amd import make_detections
+    from tests.util import synthetic_tiles
+
+    wd = tmp_path / "outputs" / "obj_detector"
+    (wd / "val-images").mkdir(parents=True)
+    tiles = synthetic_tiles(6, 128, 128, 3, seed=9)
+    images = []
+    for i in range(6):
+        fn = f"val-images/18_{100 + i}_200.tif"
+        t = tiles[i][:96] if i == 3 else tiles[i]                          # tile 3 is 96 x 128
+        Image.fromarray(t[:, :, ::-1]).save(str(wd / fn))
+        e = {"id": i, "file_name": fn}
+        if coco_sizes == "true":
+            e.update(width=128, height=int(t.shape[0]))
+        elif coco_sizes == "wrong":
+            e.update(width=128, height=128)
+        images.append(e)
+    json.dump({"images": images, "annotations": [], "categories": [{"id": 1, "name": "artificial"}, {"id": 2, "name": "natural"}]},
+              open(wd / "COCO_val.json", "w"))
+    d2 = {"INPUT": {"FORMAT": "RGB", "MIN_SIZE_TEST": 192, "MAX_SIZE_TEST": 320},
+          "MODEL": {"RPN": {"PRE_NMS_TOPK_TEST": 200, "POST_NMS_TOPK_TEST": 200}, "ROI_HEADS": {"NUM_CLASSES": 1}},
+          "TEST": {"DETECTIONS_PER_IMAGE": 20}}
+    yaml.safe_dump(d2, open(tmp_path / "d2.yaml", "w"))
+    cfg = {"make_detections.py": {"working_directory": str(wd), "log_subfolder": "logs",
+                                  "COCO_files": {"val": "COCO_val.json"}, "detectron2_config_file": str(tmp_path / "d2.yaml"),
+                                  "model_weights": {"pth_file": "logs/model_0005999.pth"}, "score_lower_threshold": 0.05}}
+    yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
+    cwd = os.getcwd()
+    try:
+        assert make_detections.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--batch", "2", "--tagged-samples", "0"]) == 0
+    finally:
+        os.chdir(cwd)
+    feats = read_gpkg(str(wd / "val_detections_at_0dot05_threshold.gpkg"), "val_detections_at_0dot05_threshold")
+    seen = {f["properties"]["image"] for f in feats}
+    assert seen == {f"18_{100 + i}_200.tif" for i in range(6)}, seen
+    odd = [f for f in feats if f["properties"]["image"] == "18_103_200.tif"]
+    assert max(p[1] for f in odd for p in f["geometry"]["coordinates"][0]) <= 96.0          # pixel coordinates of the 96-row tile
+    from proj_roadsurf_amd.engine import _REGISTERED_HOST
+    assert not _REGISTERED_HOST                                            # the slab was unpinned before its memory went away
 
 
 def test_cropped_vectoriser_equals_full_canvas(lib_path_ok=None):
