@@ -19,8 +19,8 @@ What follows the reference / detectron2 0.6 and where it is pinned:
 MIN_SIZE_TRAIN's multi-scale "choice" (R:31-38) is drawn per image and the batch padded to its largest image, as DatasetMapper +
 ImageList.from_tensors do (``MultiScaleTrainer.select_batch``).
 Documented deviations: fp16 activations/weights with fp32 master weights and dynamic loss scaling (GradScaler's policy) instead of fp32 everywhere, the
-model-zoo URL of ``model_weights.model_zoo_checkpoint_url`` cannot be fetched offline (use ``model_weights.pth_file`` or
-``--synthetic-weights``).  Every TEST.EVAL_PERIOD iterations the validation loss and the COCO bbox / segm AP (coco_eval.py, a
+model-zoo name of ``model_weights.model_zoo_checkpoint_url`` is resolved in detectron2's local cache layout
+(``weights.resolve_zoo_checkpoint``: no download; else ``model_weights.pth_file`` or ``--synthetic-weights``).  Every TEST.EVAL_PERIOD iterations the validation loss and the COCO bbox / segm AP (coco_eval.py, a
 restatement of pycocotools' COCOeval) of the `val` set are logged to metrics.json.
 """
 from __future__ import annotations
@@ -277,8 +277,24 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     elif mw.get("pth_file"):
         W = load_checkpoint(mw["pth_file"])
         spec = load_d2_yaml(cfg["detectron2_config_file"], num_classes=infer_num_classes(W))
+    elif mw.get("model_zoo_checkpoint_url"):
+        # the reference's unchanged YAML (R:config/config_obj_detec.yaml:71-72): no download here, but a machine that has run the
+        # reference (or whose iopath cache was filled by hand) already holds the file -- weights.resolve_zoo_checkpoint
+        from .weights import adapt_num_classes, resolve_zoo_checkpoint, zoo_cache_roots
+        zoo = str(mw["model_zoo_checkpoint_url"])
+        path = resolve_zoo_checkpoint(zoo)
+        if path is None:
+            raise SystemExit(f"model_weights.model_zoo_checkpoint_url {zoo!r}: no network access and no cached copy under "
+                             f"{[os.path.join(r, 'detectron2') for r in zoo_cache_roots()]} (detectron2's own cache layout, $FVCORE_CACHE "
+                             "to relocate); give model_weights.pth_file or --synthetic-weights")
+        W = load_checkpoint(path)
+        k = max(len(cats), 1)
+        W, redone = adapt_num_classes(W, k, seed=args.seed)
+        log.info("initial weights: %s (model-zoo cache)%s", path,
+                 f"; re-initialised for {k} classes (shape mismatch, as DetectionCheckpointer skips them): {redone}" if redone else "")
+        spec = load_d2_yaml(cfg["detectron2_config_file"], num_classes=k)
     else:
-        raise SystemExit("model_weights.model_zoo_checkpoint_url needs network access; give model_weights.pth_file or --synthetic-weights")
+        raise SystemExit("model_weights needs pth_file or model_zoo_checkpoint_url (or --synthetic-weights)")
 
     from .engine import MultiScaleTrainer      # fails loudly without librs_engine.so / a HIP device
     from .make_detections import read_tile

@@ -14,8 +14,9 @@
 from __future__ import annotations
 
 import math
+import os
 import struct
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -195,6 +196,79 @@ def load_zoo_pkl(path: str) -> Dict[str, np.ndarray]:
         raise ValueError(f"{path}: keys are not detectron2 names (Caffe2-style checkpoints need detectron2's c2_model_loading "
                          "renaming, which is not restated here)")
     return out
+
+
+# detectron2's model-zoo table for the entries the reference's YAMLs can name ([EXT d2: model_zoo/model_zoo.py]
+# ``_ModelZooUrls.CONFIG_PATH_TO_URL_SUFFIX``; R:config/config_obj_detec.yaml:71-72, R:config/detectron2_config_3bands.yaml:265)
+ZOO_URL_SUFFIX = {
+    "COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_1x": "137260431/model_final_a54504.pkl",
+    "COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x": "137849600/model_final_f10217.pkl",
+}
+ZOO_S3_PREFIX = "https://dl.fbaipublicfiles.com/detectron2/"
+
+
+def zoo_cache_roots() -> List[str]:
+    """Where iopath / fvcore keep downloaded files ([EXT iopath: common/file_io.py get_cache_dir]): ``$FVCORE_CACHE``, else
+    ``~/.torch/iopath_cache`` (older fvcore: ``~/.torch/fvcore_cache``)."""
+    roots = []
+    if os.environ.get("FVCORE_CACHE"):
+        roots.append(os.path.expanduser(os.environ["FVCORE_CACHE"]))
+    roots += [os.path.expanduser("~/.torch/iopath_cache"), os.path.expanduser("~/.torch/fvcore_cache")]
+    return roots
+
+
+def resolve_zoo_checkpoint(name_or_url: str) -> Optional[str]:
+    """Local file of a model-zoo checkpoint WITHOUT network access: ``model_zoo.get_checkpoint_url(name)`` would download
+    ``https://dl.fbaipublicfiles.com/detectron2/<name>/<id>/model_final_<hash>.pkl`` once and iopath's HTTP handler keeps it at
+    ``<cache root>/detectron2/<name>/<id>/model_final_<hash>.pkl`` (the URL's path under the cache root).  A machine that ran
+    the reference once -- or whose cache was populated by hand -- therefore already holds the file.  ``name_or_url`` is the YAML's
+    zoo config name (``COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_1x.yaml``) or the full https URL (``MODEL.WEIGHTS``).
+    Returns the path or None."""
+    import glob
+
+    s = name_or_url.strip()
+    if s.startswith("http://") or s.startswith("https://"):
+        rel = s.split("://", 1)[1].split("/", 1)[1] if "/" in s.split("://", 1)[1] else ""
+        cands = [rel]
+    else:
+        name = s[:-5] if s.endswith(".yaml") else s
+        cands = []
+        if name in ZOO_URL_SUFFIX:
+            cands.append(f"detectron2/{name}/{ZOO_URL_SUFFIX[name]}")
+        cands.append(f"detectron2/{name}/*/model_final_*.pkl")
+    for root in zoo_cache_roots():
+        for c in cands:
+            hits = sorted(glob.glob(os.path.join(root, c)))
+            if len(hits) == 1 or (hits and "*" not in c):
+                return hits[0]
+            if len(hits) > 1:
+                raise ValueError(f"several cached checkpoints match {name_or_url!r} under {root}: {hits}")
+    return None
+
+
+# layers whose shape follows ROI_HEADS.NUM_CLASSES, with detectron2's own initial scale
+# ([EXT d2: modeling/roi_heads/fast_rcnn.py FastRCNNOutputLayers.__init__, mask_head.py MaskRCNNConvUpsampleHead.__init__])
+_CLASS_SHAPED = (("roi_heads.box_predictor.cls_score", 0.01, lambda k: k + 1), ("roi_heads.box_predictor.bbox_pred", 0.001, lambda k: 4 * k),
+                 ("roi_heads.mask_head.predictor", 0.001, lambda k: k))
+
+
+def adapt_num_classes(W: Dict[str, np.ndarray], num_classes: int, seed: int = 0) -> Tuple[Dict[str, np.ndarray], List[str]]:
+    """What ``DetectionCheckpointer.load`` does with a COCO (80-class) zoo checkpoint and ``ROI_HEADS.NUM_CLASSES = K``
+    ([EXT fvcore: common/checkpoint.py ``_load_model``: "Skip loading parameter ... due to incompatible shapes"]): tensors whose
+    shape differs from the model's are NOT loaded and keep the model's fresh initialisation -- normal(0, 0.01) class scores,
+    normal(0, 0.001) box deltas and mask predictor (``nn.init.normal_``; here numpy's generator, seeded), zero biases.
+    Returns (weights, names of the re-initialised layers)."""
+    out = dict(W)
+    redone: List[str] = []
+    rng = np.random.default_rng(seed + 4242)
+    for name, std, rows in _CLASS_SHAPED:
+        w = out.get(name + ".weight")
+        if w is None or w.shape[0] == rows(num_classes):
+            continue
+        out[name + ".weight"] = (rng.standard_normal((rows(num_classes),) + tuple(w.shape[1:])) * std).astype(np.float32)
+        out[name + ".bias"] = np.zeros(rows(num_classes), np.float32)
+        redone.append(name)
+    return out, redone
 
 
 def infer_num_classes(W: Dict[str, np.ndarray]) -> int:

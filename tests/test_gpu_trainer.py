@@ -402,16 +402,12 @@ def test_full_training_step_five_losses_match_autograd(gpu_required):
         tr.close()
 
 
-def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
-    """train_model.py drop-in: same YAML section/keys as the reference (R:config/config_obj_detec.yaml:62-72); a few iterations on
-    a tiny synthetic COCO set write metrics.json and model_final.pth in detectron2's checkpoint layout, which make_detections.py
-    then consumes through model_weights.pth_file; the weights moved and the losses are finite."""
+def _tiny_training_workdir(tmp_path):
+    """Four 128x128 synthetic tiles with two boxes each, COCO JSON, a small detectron2 YAML and the reference's two YAML sections
+    (R:config/config_obj_detec.yaml:62-90) -- train_model.py section UNCHANGED in its model_weights key (zoo name only)."""
     import json
-    import os
     import yaml
     from PIL import Image
-    from proj_roadsurf_amd import make_detections, train_model
-    from proj_roadsurf_amd.weights import load_checkpoint
 
     wd = tmp_path / "outputs" / "obj_detector"
     (wd / "trn-images").mkdir(parents=True)
@@ -444,6 +440,21 @@ def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
                                   "model_weights": {"pth_file": "logs/model_final.pth"}, "rdp_simplification": {"enabled": True, "epsilon": 0.75},
                                   "score_lower_threshold": 0.05}}
     yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
+    return wd
+
+
+def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
+    """train_model.py drop-in: same YAML section/keys as the reference (R:config/config_obj_detec.yaml:62-72); a few iterations on
+    a tiny synthetic COCO set write metrics.json and model_final.pth in detectron2's checkpoint layout, which make_detections.py
+    then consumes through model_weights.pth_file; the weights moved and the losses are finite."""
+    import json
+    import os
+    import yaml
+    from PIL import Image
+    from proj_roadsurf_amd import make_detections, train_model
+    from proj_roadsurf_amd.weights import load_checkpoint
+
+    wd = _tiny_training_workdir(tmp_path)
     cwd = os.getcwd()
     try:
         assert train_model.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--log-period", "1", "--loss-scale", "256"]) == 0
@@ -470,6 +481,43 @@ def test_train_model_cli_then_make_detections(gpu_required, tmp_path):
         assert make_detections.main([str(tmp_path / "config.yaml"), "--batch", "2"]) == 0
         os.chdir(cwd)
         assert (wd / "trn_detections_at_0dot05_threshold.gpkg").exists()
+    finally:
+        os.chdir(cwd)
+
+
+def test_train_model_starts_from_the_unchanged_yaml_with_a_cached_zoo_checkpoint(gpu_required, tmp_path, monkeypatch):
+    """R:config/config_obj_detec.yaml:71-72 names only ``model_zoo_checkpoint_url``.  With the 80-class COCO checkpoint present in
+    detectron2's cache layout ($FVCORE_CACHE/detectron2/<name>/<id>/model_final_<hash>.pkl) the CLI starts WITHOUT an edited YAML
+    and without --synthetic-weights: backbone / FPN / RPN / heads loaded, class-shaped layers re-initialised for the two classes."""
+    import json
+    import os
+    import pickle
+    from proj_roadsurf_amd import train_model
+    from proj_roadsurf_amd.weights import load_checkpoint
+
+    wd = _tiny_training_workdir(tmp_path)
+    zoo = synthetic_weights(EngineSpec(num_classes=80), seed=3)
+    d = tmp_path / "cache" / "detectron2" / "COCO-InstanceSegmentation" / "mask_rcnn_R_50_FPN_1x" / "137260431"
+    d.mkdir(parents=True)
+    with open(d / "model_final_a54504.pkl", "wb") as f:
+        pickle.dump({"model": zoo, "__author__": "Detectron2 Model Zoo"}, f, protocol=2)
+    monkeypatch.setenv("FVCORE_CACHE", str(tmp_path / "cache"))
+    cwd = os.getcwd()
+    try:
+        assert train_model.main([str(tmp_path / "config.yaml"), "--max-iter", "2", "--log-period", "1", "--loss-scale", "256", "--tagged-samples", "0"]) == 0
+    finally:
+        os.chdir(cwd)
+    lines = [json.loads(l) for l in open(wd / "logs" / "metrics.json")]
+    assert [l["iteration"] for l in lines] == [0, 1] and all(np.isfinite(l["total_loss"]) for l in lines)
+    W1 = load_checkpoint(str(wd / "logs" / "model_final.pth"))
+    assert W1["roi_heads.box_predictor.cls_score.weight"].shape == (3, 1024) and W1["roi_heads.mask_head.predictor.weight"].shape[0] == 2
+    assert np.array_equal(W1["backbone.bottom_up.res2.0.conv1.weight"], zoo["backbone.bottom_up.res2.0.conv1.weight"])       # loaded, frozen
+    monkeypatch.setenv("FVCORE_CACHE", str(tmp_path / "empty"))
+    monkeypatch.setenv("HOME", str(tmp_path / "nohome"))
+    try:
+        with pytest.raises(SystemExit) as ex:
+            train_model.main([str(tmp_path / "config.yaml"), "--max-iter", "1"])
+        assert "no cached copy" in str(ex.value)
     finally:
         os.chdir(cwd)
 

@@ -184,6 +184,45 @@ def test_zoo_pkl_reader_accepts_arrays_only(tmp_path):
         load_zoo_pkl(str(p))
 
 
+def test_zoo_checkpoint_resolves_in_detectron2_cache_layout(tmp_path, monkeypatch):
+    """The reference's unchanged YAML names a model-zoo config (R:config/config_obj_detec.yaml:71-72); detectron2 would download
+    https://dl.fbaipublicfiles.com/detectron2/<name>/<id>/model_final_<hash>.pkl into iopath's cache, at the URL's path under the
+    cache root.  Offline the file is looked up there ($FVCORE_CACHE or ~/.torch/iopath_cache), read by the restricted unpickler, and
+    the class-shaped layers of the 80-class COCO heads are re-initialised for K classes as DetectionCheckpointer leaves them."""
+    import pickle
+
+    from proj_roadsurf_amd.weights import adapt_num_classes, load_checkpoint, resolve_zoo_checkpoint
+
+    name = "COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_1x.yaml"
+    monkeypatch.setenv("FVCORE_CACHE", str(tmp_path / "cache"))
+    monkeypatch.setenv("HOME", str(tmp_path / "home"))
+    assert resolve_zoo_checkpoint(name) is None
+    d = tmp_path / "cache" / "detectron2" / "COCO-InstanceSegmentation" / "mask_rcnn_R_50_FPN_1x" / "137260431"
+    d.mkdir(parents=True)
+    model = {"backbone.bottom_up.stem.conv1.weight": np.ones((64, 3, 7, 7), np.float32),
+             "roi_heads.box_predictor.cls_score.weight": np.ones((81, 1024), np.float32), "roi_heads.box_predictor.cls_score.bias": np.ones(81, np.float32),
+             "roi_heads.box_predictor.bbox_pred.weight": np.ones((320, 1024), np.float32), "roi_heads.box_predictor.bbox_pred.bias": np.ones(320, np.float32),
+             "roi_heads.mask_head.predictor.weight": np.ones((80, 256, 1, 1), np.float32), "roi_heads.mask_head.predictor.bias": np.ones(80, np.float32)}
+    (d / "model_final_a54504.pkl").write_bytes(pickle.dumps({"model": model, "__author__": "Detectron2 Model Zoo"}, protocol=2))
+    path = resolve_zoo_checkpoint(name)
+    assert path == str(d / "model_final_a54504.pkl")
+    assert resolve_zoo_checkpoint("https://dl.fbaipublicfiles.com/detectron2/COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_1x/137260431/model_final_a54504.pkl") == path
+    # the older default location, and a zoo entry that is not in the table (found by its directory)
+    monkeypatch.delenv("FVCORE_CACHE")
+    d2 = tmp_path / "home" / ".torch" / "iopath_cache" / "detectron2" / "COCO-Detection" / "faster_rcnn_R_50_FPN_1x" / "137257794"
+    d2.mkdir(parents=True)
+    (d2 / "model_final_b275ba.pkl").write_bytes(b"x")
+    assert resolve_zoo_checkpoint("COCO-Detection/faster_rcnn_R_50_FPN_1x.yaml") == str(d2 / "model_final_b275ba.pkl")
+    W, redone = adapt_num_classes(load_checkpoint(path), 2, seed=0)
+    assert sorted(redone) == ["roi_heads.box_predictor.bbox_pred", "roi_heads.box_predictor.cls_score", "roi_heads.mask_head.predictor"]
+    assert W["roi_heads.box_predictor.cls_score.weight"].shape == (3, 1024) and W["roi_heads.box_predictor.bbox_pred.weight"].shape == (8, 1024)
+    assert W["roi_heads.mask_head.predictor.weight"].shape == (2, 256, 1, 1) and not W["roi_heads.mask_head.predictor.bias"].any()
+    assert 0.008 < W["roi_heads.box_predictor.cls_score.weight"].std() < 0.012 and 0.0008 < W["roi_heads.box_predictor.bbox_pred.weight"].std() < 0.0012
+    assert np.array_equal(W["backbone.bottom_up.stem.conv1.weight"], model["backbone.bottom_up.stem.conv1.weight"])
+    same, none = adapt_num_classes(W, 2)
+    assert none == [] and same["roi_heads.box_predictor.cls_score.weight"] is W["roi_heads.box_predictor.cls_score.weight"]
+
+
 def test_conv_variant_table(lib):
     """The conv tile dispatch depends on M = batch * pixels, i.e. on the batch size (csrc/conv_igemm.hip
     conv_choose_variant).  Enumerate it per layer at batch 1 / 3 / 8 / 16 of the 800x800 network input and compare with
