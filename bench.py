@@ -5,17 +5,27 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --train                      # training step of BASELINE configs[4] as its own JSON line
 
 One process per GPU; tiles shard across ranks with no data-path collective (each rank runs its
 own batch -> "weak" scaling); torch.distributed (RCCL) is used only for the barrier and the
 max-over-ranks of the timed region.  A step = one pass of the whole hot path (resize+normalise,
 backbone, FPN, RPN, box head, NMS, mask head, mask paste) over one batch of 16 tiles that is
-already resident in HBM; results stay in HBM (PCIe-inclusive rate: DESIGN.md).
+already resident in HBM; results stay in HBM (PCIe-inclusive rate: `pcie_inclusive_tiles_per_s`).
 
-Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the conv kernel symbol with the largest share
-of the step, HIP-event timed on the engine's stream during the timed steps) and `cpu_baseline` (the
-oracle = CPU restatement of detectron2's path, on the host cores, bounded sample).  `--gpus N` without a
-launcher (WORLD_SIZE unset) starts the N ranks itself before touching the GPU.
+Prints ONE JSON line on rank 0.  Beside the contract's keys it carries
+  * `roofline`            dominant kernel (the conv kernel symbol with the largest share of the step), HIP-event timed on the
+                          engine's stream during the timed steps;
+  * `reference_precision` the SAME K-step region run by the reference-precision engine (every matrix stage in exact fp32 on
+                          v_mfma_f32_16x16x4_f32): the like-for-like figure against the reference's fp32 arithmetic;
+  * `parity`              detections of the fp16 engine matched against the reference-precision engine's on the benched batch
+                          (GPU vs GPU: no oracle in any timed path), SURVEY 8d matching;
+  * `trained_like`        the same two measurements on a detector trained here for a few hundred steps (scores separate, a handful
+                          of detections per tile -- what a deployed model looks like; the headline workload is the saturated
+                          random-weight worst case);
+  * `training`            one data-parallel training step (BASELINE configs[4]) at batch 8 and at 1 image per GPU;
+  * `cpu_baseline`        the oracle (CPU restatement of detectron2's path) on the host cores, bounded sample.
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself before touching the GPU.
 """
 import argparse
 import json
@@ -30,7 +40,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def cpu_baseline(spec, W, tiles, max_seconds=25.0):
@@ -44,19 +59,19 @@ def cpu_baseline(spec, W, tiles, max_seconds=25.0):
     cores = max(1, min(cores, int(os.environ.get("RS_CPU_BASELINE_THREADS", "16"))))   # a 1-GPU box's CPU share is 16
     torch.set_num_threads(cores)
     m = OracleModel(spec, W)
-    print(f"[bench] cpu_baseline: oracle on {cores} threads ...", file=sys.stderr, flush=True)
+    log(f"cpu_baseline: oracle on {cores} threads ...")
     n_warm = 3
     for i in range(n_warm):
         m([tiles[i % len(tiles)]])
     t0 = time.time()
     n = 0
-    while n < 10 or (time.time() - t0) < 0.0:
+    while n < 10:
         m([tiles[(n_warm + n) % len(tiles)]])
         n += 1
         if time.time() - t0 > max_seconds:
             break
     dt = time.time() - t0
-    print(f"[bench] cpu_baseline: batch 1: {n} tiles in {dt:.1f} s", file=sys.stderr, flush=True)
+    log(f"cpu_baseline: batch 1: {n} tiles in {dt:.1f} s")
     out = {"value": n / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
            "sample": f"{n_warm} warm-up + {n} timed synthetic {tiles[0].shape[0]}x{tiles[0].shape[1]}x{tiles[0].shape[2]} tile(s), "
                      f"batch 1 as DefaultPredictor does, torch CPU fp32 (oneDNN), {dt:.1f} s"}
@@ -66,7 +81,7 @@ def cpu_baseline(spec, W, tiles, max_seconds=25.0):
         d16 = time.time() - t1
         out["value_batch16"] = 16 / d16
         out["sample"] += f"; then one batch of 16 in {d16:.1f} s"
-        print(f"[bench] cpu_baseline: batch 16: {d16:.1f} s", file=sys.stderr, flush=True)
+        log(f"cpu_baseline: batch 16: {d16:.1f} s")
     return out
 
 
@@ -86,6 +101,158 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def as_sets(dets):
+    return [{"boxes": d.pred_boxes, "scores": d.scores, "classes": d.pred_classes, "masks": d.pred_masks} for d in dets]
+
+
+def parity_object(got, ref, what):
+    """SURVEY 8d matching (same class, box IoU >= 0.95, reference score >= 0.1) of two detection lists of the same tiles, pooled over
+    the tiles, both directions, with the 95 % Wilson lower bound of each matched fraction."""
+    from proj_roadsurf_amd.matching import match_detections, wilson_lower
+    tot = {"fw_n": 0, "fw_m": 0, "bw_n": 0, "bw_m": 0}
+    dscore, inter_u, miou = 0.0, [], 1.0
+    agg = []
+    for g, r in zip(as_sets(got), as_sets(ref)):
+        fw, bw = match_detections(r, g), match_detections(g, r)
+        tot["fw_n"] += fw["n_ref"]; tot["fw_m"] += round(fw["frac_matched"] * fw["n_ref"])
+        tot["bw_n"] += bw["n_ref"]; tot["bw_m"] += round(bw["frac_matched"] * bw["n_ref"])
+        dscore = max(dscore, fw["max_dscore"])
+        miou = min(miou, float(fw["min_mask_iou"]))
+        agg.append(float(fw["agg_mask_iou"]))
+    return {"of": what, "criterion": "same class, box IoU >= 0.95, detections with score >= 0.1 (SURVEY 8d); stated tolerance: >= 0.98 both ways, |dscore| <= 0.02, mask IoU >= 0.95",
+            "matched_fw": tot["fw_m"] / max(tot["fw_n"], 1), "matched_bw": tot["bw_m"] / max(tot["bw_n"], 1),
+            "n_fw": tot["fw_n"], "n_bw": tot["bw_n"],
+            "wilson95_lower_fw": wilson_lower(tot["fw_m"], tot["fw_n"]), "wilson95_lower_bw": wilson_lower(tot["bw_m"], tot["bw_n"]),
+            "max_dscore": dscore, "agg_mask_iou": float(np.mean(agg)) if agg else 1.0, "min_mask_iou": miou}
+
+
+def timed_steps(pipe, ptrs, B, steps, warmup, barrier, sync):
+    """W untimed + exactly K timed submissions, bracketed by barrier + device sync on both sides; returns seconds of the K steps."""
+    L = len(pipe.engines)
+    for _ in range(warmup):
+        pipe.submit(ptrs[pipe.k % L], B)
+    pipe.sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.submit(ptrs[pipe.k % L], B)
+    pipe.sync()
+    sync()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def reference_precision_leg(spec, W, tiles, B, steps, warmup, device):
+    """The K-step region on the reference-precision engine (rs_spec.precision = 1: fp32 activations and weights, every conv / linear
+    layer on v_mfma_f32_16x16x4_f32, csrc/ref_f32.hip), same tiles resident in HBM.  Returns (json object, detections)."""
+    import torch
+    from proj_roadsurf_amd.engine import Engine
+    T, C_in = tiles.shape[1], tiles.shape[3]
+    e32 = Engine(spec.replace(precision="fp32"), W, (T, T, C_in), max_batch=B, device=device)
+    try:
+        p32 = e32.upload_tiles(tiles)
+        for _ in range(max(1, warmup)):
+            e32.infer_device(p32, B)
+        e32.sync()
+        e32.set_profiling(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e32.infer_device(p32, B)
+        e32.sync()
+        torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t0) / steps
+        st32 = [s for s in e32.stage_times() if s["flops"] > 0 and s["calls"] > 0]
+        fl32 = sum(s["flops"] for s in st32)
+        ms32 = sum(s["ms_total"] / s["calls"] for s in st32)
+        e32.set_profiling(0)
+        dets = e32.fetch(B)
+        mt = fl32 / (ms32 * 1e-3) / 1e12 if ms32 else None
+        return {"tiles_per_s": B / d32, "ms_per_step": d32 * 1e3, "steps": steps, "warmup": max(1, warmup), "dtype": "f32",
+                "whole_path_tflops": fl32 / d32 / 1e12, "matrix_stages_tflops": mt, "peak_tflops": F32_MFMA_PEAK_TFLOPS,
+                "frac": (mt / F32_MFMA_PEAK_TFLOPS) if mt else None,
+                "kernel": "conv_f32_mfma_kernel (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate)"}, dets
+    finally:
+        e32.close()
+
+
+def training_leg(spec, W, device, steps=12, warmup=3):
+    """One training step (BASELINE configs[4]: 2-class fine-tune, YAML samplers: 256 anchors / 1024 RoIs per image, 2000/1000 train
+    proposals) on 1 GPU: forward + five losses + backward + SGD + refold, host-side mask-target rasterisation included; batch 8
+    (the YAML's IMS_PER_BATCH on one GPU) and batch 1 (its per-GPU share on 8 GPUs).  Per-stage HIP events give the share and rate of
+    the weight-gradient / input-gradient GEMMs; in a one-rank RCCL group the bucketed all-reduce runs for real (what is exposed of
+    it on one GPU is its launch + wait cost, the xGMI time is not)."""
+    import torch
+    import torch.distributed as dist
+    from proj_roadsurf_amd.engine import Trainer
+    from proj_roadsurf_amd.synthetic import synthetic_scenes
+    T = 512
+    out = {"workload": "Mask R-CNN R50-FPN training step, 512x512x3 tiles -> 800x800, FREEZE_AT 2, fp16 operands / fp32 master weights "
+                       "(BASELINE configs[4] on one GPU)", "steps": steps, "warmup": warmup}
+    own_pg = False
+    if not dist.is_initialized():
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        try:
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            own_pg = True
+        except Exception as ex:                                  # the figures without a collective are still valid
+            log(f"training leg: no RCCL group ({ex})")
+    for B in (8, 1):
+        tiles, boxes, classes, polys = synthetic_scenes(B, T, T, 3, seed=4321)
+        s = 800.0 / T
+        nb = [b * np.float32(s) for b in boxes]
+        npoly = [[[p * s for p in inst] for inst in img] for img in polys]
+        tr = Trainer(spec, W, (T, T, 3), batch=B, device=device, loss_scale=1024.0)
+        try:
+            def run(n, allreduce):
+                for it in range(n):
+                    tr.train_step(tiles, nb, classes, npoly, seed=100 + it, allreduce=allreduce)
+                    tr.apply_sgd(1e-5, 0.9, 1e-4)
+                tr.sync()
+                torch.cuda.synchronize()
+            run(warmup, False)
+            t0 = time.perf_counter(); run(steps, False); dt = (time.perf_counter() - t0) / steps
+            rec = {"batch": B, "ms_per_step": dt * 1e3, "images_per_s": B / dt, "trainable_values_M": tr.param_count / 1e6}
+            if dist.is_initialized() and dist.get_backend() == "nccl":
+                _orig = tr.allreduce_gradients
+                tr.allreduce_gradients = lambda force=False: _orig(force=True)      # a one-rank group: run the collectives anyway
+                run(2, True)
+                t0 = time.perf_counter(); run(steps, True); dta = (time.perf_counter() - t0) / steps
+                rec["ms_per_step_with_bucketed_allreduce_1rank"] = dta * 1e3
+                rec["exposed_allreduce_ms_1rank"] = (dta - dt) * 1e3
+                tr.allreduce_gradients = _orig
+            tr.set_profiling(True)
+            run(4, False)
+            st = [x for x in tr.stage_times() if x["calls"]]
+            tr.set_profiling(False)
+            groups = {}
+            for x in st:
+                nm = x["name"]
+                g = ("weight gradients (conv_wgrad_kernel, side stream)" if nm.endswith(".w") else
+                     "input gradients (conv_igemm / conv_deep on the transposed weights)" if nm.endswith(".x") else
+                     "forward GEMMs" if x["flops"] > 0 else "RoIAlign forward / backward" if "roi_align" in nm else "other (losses, sampling, NMS, bias gradients, pooling)")
+                a = groups.setdefault(g, {"ms_per_step": 0.0, "flops_per_step": 0.0})
+                a["ms_per_step"] += x["ms_total"] / x["calls"]
+                a["flops_per_step"] += x["flops"]
+            for g, a in groups.items():
+                a["tflops"] = a["flops_per_step"] / (a["ms_per_step"] * 1e-3) / 1e12 if a["ms_per_step"] and a["flops_per_step"] else None
+                a["frac_of_mfma_peak"] = a["tflops"] / MFMA_PEAK_TFLOPS if a["tflops"] else None
+            rec["stage_groups"] = groups
+            rec["note"] = "stage times are HIP events on the stream each stage runs on; the weight-gradient side stream overlaps the chain, so the groups add up to more than ms_per_step"
+            tot_fl = sum(a["flops_per_step"] for a in groups.values())
+            rec["whole_step_tflops"] = tot_fl / dt / 1e12
+            out[f"batch{B}"] = rec
+        finally:
+            tr.close()
+    if own_pg:
+        dist.destroy_process_group()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +261,11 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--bands", type=int, default=3, help="3 = BASELINE configs[1] (headline); 4 = RGB+NIR tiles (configs[3], with --tile 1024 --batch 8)")
+    ap.add_argument("--weights", choices=["random", "trained"], default="random",
+                    help="workload of the headline `value`: random = seeded synthetic weights, 1000 proposals / 100 detections per tile "
+                         "(the saturated worst case BASELINE's FLOP count is quoted on); trained = a detector trained here for --train-steps "
+                         "steps on synthetic scenes (a handful of detections per tile)")
+    ap.add_argument("--train-steps", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-stage table to stderr")
     ap.add_argument("--lanes", type=int, default=2,
@@ -101,7 +273,11 @@ def main():
                          "one batch's latency-bound detection glue overlaps the next batch's convolutions")
     ap.add_argument("--profile-mode", type=int, default=3,
                     help="HIP-event stage timing during the timed steps: 3 = every 4th step (default), 2 = every step, 0 = off")
-    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the reference-precision (fp32 MFMA) measurement")
+    ap.add_argument("--no-fp32-mode", "--no-reference-precision", dest="no_ref", action="store_true",
+                    help="skip the reference-precision (fp32 MFMA) leg and the parity object")
+    ap.add_argument("--no-trained-leg", action="store_true", help="skip the trained-like leg of the default run")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step leg of the default run")
+    ap.add_argument("--train", action="store_true", help="ONLY the training-step leg, as its own JSON line (BASELINE configs[4])")
     ap.add_argument("--sustain-seconds", type=float, default=5.0,
                     help="after the K timed steps, keep stepping for this long and report `sustained_tiles_per_s` (clocks settle "
                          "after a few seconds of load); 0 = skip (profiler runs)")
@@ -128,124 +304,137 @@ def main():
     from proj_roadsurf_amd.engine import LanePipeline
     from proj_roadsurf_amd.spec import EngineSpec
     from proj_roadsurf_amd.weights import synthetic_weights
-    from proj_roadsurf_amd.synthetic import synthetic_tiles
+    from proj_roadsurf_amd.synthetic import synthetic_scenes, synthetic_tiles, train_trained_like
 
     spec = EngineSpec(num_classes=2)      # R:config/detectron2_config_3bands.yaml defaults, 2 classes (artificial/natural)
     if args.bands == 4:                   # no 4-band YAML exists in the reference: PIXEL_MEAN/STD extended by a NIR entry
         spec = spec.replace(pixel_mean=spec.pixel_mean + (110.0,), pixel_std=spec.pixel_std + (1.0,))
-    W = synthetic_weights(spec, seed=0)
-    B, T = args.batch, args.tile
-    # rank r owns tiles r*B .. r*B+B-1 of the synthetic tileset (seed = 1234 + tile id)
-    C_in = args.bands
-    tiles = synthetic_tiles(B, T, T, C_in, seed=1234 + rank * B)
-    L = max(1, args.lanes)
-    pipe = LanePipeline(spec, W, (T, T, C_in), max_batch=B, device=local_rank, lanes=L)
-    engs = pipe.engines
-    ptrs = [e.upload_tiles(tiles) for e in engs]
-    eng = engs[0]
+    B, T, C_in = args.batch, args.tile, args.bands
+
+    if args.train:
+        if world != 1:
+            raise SystemExit("--train measures one GPU (the 8-GPU data-parallel run is the driver's)")
+        tl = training_leg(spec, synthetic_weights(spec, seed=0), local_rank, steps=args.steps, warmup=args.warmup)
+        b8 = tl["batch8"]
+        print(json.dumps({"metric": "train_images_per_sec_512x512x3", "value": b8["images_per_s"], "unit": "images/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": b8["ms_per_step"], "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands / f32 accumulate, f32 master weights", "data": "synthetic",
+                          "config": {"workload": tl["workload"], "batch_per_gpu": 8}, "training": tl}))
+        return
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for k in range(args.warmup):
-        pipe.submit(ptrs[k % L], B)
-    pipe.sync()
-    for e in engs:
-        e.set_profiling(args.profile_mode)   # HIP events around the launches, on each lane's stream, no host wait
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):              # step k = one batch of B tiles, on lane k mod L
-        pipe.submit(ptrs[pipe.k % L], B)
-    pipe.sync()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    # Sustained rate: the K-step region above is what the contract times (`value`); a 10k-tile job runs for seconds, by which
-    # time the chip has settled at its clock under load.  Same loop, no stage events, >= --sustain-seconds, max over ranks.
-    stages = eng.stage_times()               # the stage events of the timed region (set_profiling(0) would clear them)
-    for e in engs[1:]:                       # same stage list on every lane: pool the HIP-event totals
-        for a, b in zip(stages, e.stage_times()):
-            a["ms_total"] += b["ms_total"]
-            a["calls"] += b["calls"]
-    sustained = None
-    if args.sustain_seconds > 0:
-        for e in engs:
-            e.set_profiling(0)
-        barrier()
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        n_sus = 0
-        while True:
-            for _ in range(32):
-                pipe.submit(ptrs[pipe.k % L], B)
-            n_sus += 32
-            pipe.sync()
-            stop = torch.tensor([1.0 if time.perf_counter() - ts >= args.sustain_seconds else 0.0], device="cuda")
-            if world > 1:
-                dist.all_reduce(stop, op=dist.ReduceOp.MAX)    # every rank leaves the loop after the same number of steps
-            if float(stop.item()) > 0:
-                break
-        torch.cuda.synchronize()
-        barrier()
-        dts = time.perf_counter() - ts
-        if world > 1:
-            tm = torch.tensor([dts], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            dts = float(tm.item())
-        sustained = {"tiles_per_s": world * B * n_sus / dts, "steps": n_sus, "seconds": dts}
-    for e in engs:
-        e.set_profiling(0)
-    # PCIe-inclusive rate of the streaming host interface (pinned H2D of the tiles + forward + D2H of boxes/scores/packed
-    # masks + host-side collection into Instances, LanePipeline.run); reported beside the headline, never as `value`
-    nb = 8
-    for _ in pipe.run(tiles for _ in range(2)):
-        pass
-    t1 = time.perf_counter()
-    for res in pipe.run(tiles for _ in range(nb)):
-        pass
-    pcie_tiles_per_s = nb * B / (time.perf_counter() - t1)
-    eng.infer_device(ptrs[0], B)
-    dets = eng.fetch(B)
-    nprop = eng.tensor("proposal_count", n=B)
-    ndet = [len(d) for d in dets]
-
-    # Reference-precision mode (every conv / linear layer in fp32 on v_mfma_f32_16x16x4_f32, csrc/ref_f32.hip): the like-for-like
-    # number against the reference's fp32 arithmetic; rank 0 only, a few steps (a step is ~16x the fp16 step's matrix work).
-    fp32_mode = None
-    if rank == 0 and not args.no_fp32_mode:
-        from proj_roadsurf_amd.engine import Engine
-        pipe.sync()
-        e32 = Engine(spec.replace(precision="fp32"), W, (T, T, C_in), max_batch=B, device=local_rank)
+    def measure(W, tiles, want_stage_events):
+        """headline-style measurement of one (weights, tiles) workload: K-step region on the lane pipeline + detections of batch 0"""
+        L = max(1, args.lanes)
+        pipe = LanePipeline(spec, W, (T, T, C_in), max_batch=B, device=local_rank, lanes=L)
         try:
-            p32 = e32.upload_tiles(tiles)
-            e32.infer_device(p32, B)
-            e32.sync()
-            e32.set_profiling(2)
-            n32 = 3
-            torch.cuda.synchronize()
-            t32 = time.perf_counter()
-            for _ in range(n32):
-                e32.infer_device(p32, B)
-            e32.sync()
-            d32 = (time.perf_counter() - t32) / n32
-            st32 = [s for s in e32.stage_times() if s["flops"] > 0 and s["calls"] > 0]
-            fl32 = sum(s["flops"] for s in st32)
-            ms32 = sum(s["ms_total"] / s["calls"] for s in st32)
-            fp32_mode = {"tiles_per_s": B / d32, "ms_per_step": d32 * 1e3, "whole_path_tflops": fl32 / d32 / 1e12,
-                         "matrix_stages_tflops": fl32 / (ms32 * 1e-3) / 1e12 if ms32 else None, "peak_tflops": 157.3,
-                         "frac_of_fp32_matrix_peak": (fl32 / (ms32 * 1e-3) / 1e12 / 157.3) if ms32 else None,
-                         "kernel": "conv_f32_mfma_kernel (v_mfma_f32_16x16x4_f32, exact fp32)", "steps": n32}
+            engs = pipe.engines
+            ptrs = [e.upload_tiles(tiles) for e in engs]
+            for k in range(args.warmup):
+                pipe.submit(ptrs[k % L], B)
+            pipe.sync()
+            if want_stage_events:
+                for e in engs:
+                    e.set_profiling(args.profile_mode)   # HIP events around the launches, on each lane's stream, no host wait
+            dt = timed_steps(pipe, ptrs, B, args.steps, 0, barrier, torch.cuda.synchronize)
+            if world > 1:
+                tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            stages = None
+            if want_stage_events:
+                stages = engs[0].stage_times()           # the stage events of the timed region (set_profiling(0) would clear them)
+                for e in engs[1:]:                       # same stage list on every lane: pool the HIP-event totals
+                    for a, b in zip(stages, e.stage_times()):
+                        a["ms_total"] += b["ms_total"]
+                        a["calls"] += b["calls"]
+            # Sustained rate: the K-step region above is what the contract times (`value`); a 10k-tile job runs for seconds, by which
+            # time the chip has settled at its clock under load.  Same loop, no stage events, >= --sustain-seconds, max over ranks.
+            sustained = None
+            if want_stage_events and args.sustain_seconds > 0:
+                for e in engs:
+                    e.set_profiling(0)
+                barrier()
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                n_sus = 0
+                while True:
+                    for _ in range(32):
+                        pipe.submit(ptrs[pipe.k % L], B)
+                    n_sus += 32
+                    pipe.sync()
+                    stop = torch.tensor([1.0 if time.perf_counter() - ts >= args.sustain_seconds else 0.0], device="cuda")
+                    if world > 1:
+                        dist.all_reduce(stop, op=dist.ReduceOp.MAX)    # every rank leaves the loop after the same number of steps
+                    if float(stop.item()) > 0:
+                        break
+                torch.cuda.synchronize()
+                barrier()
+                dts = time.perf_counter() - ts
+                if world > 1:
+                    tm = torch.tensor([dts], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                    dts = float(tm.item())
+                sustained = {"tiles_per_s": world * B * n_sus / dts, "steps": n_sus, "seconds": dts}
+            for e in engs:
+                e.set_profiling(0)
+            # PCIe-inclusive rate of the streaming host interface (pinned H2D of the tiles + forward + D2H of boxes/scores/packed
+            # mask crops + host-side collection into Instances, LanePipeline.run); reported beside the headline, never as `value`
+            nb = 8
+            for _ in pipe.run(tiles for _ in range(2)):
+                pass
+            t1 = time.perf_counter()
+            for _res in pipe.run(tiles for _ in range(nb)):
+                pass
+            pcie = nb * B / (time.perf_counter() - t1)
+            eng = engs[0]
+            eng.infer_device(ptrs[0], B)
+            dets = eng.fetch(B)
+            nprop = eng.tensor("proposal_count", n=B)
+            return {"dt": dt, "stages": stages, "sustained": sustained, "pcie": pcie, "dets": dets, "nprop": float(np.mean(nprop)),
+                    "ndet": float(np.mean([len(d) for d in dets])), "lanes": L}
         finally:
-            e32.close()
+            pipe.close()
+
+    W_rand = synthetic_weights(spec, seed=0)
+    # rank r owns tiles r*B .. r*B+B-1 of the synthetic tileset (seed = 1234 + tile id)
+    tiles_rand = synthetic_tiles(B, T, T, C_in, seed=1234 + rank * B)
+    W_tr = tiles_tr = None
+    need_trained = args.weights == "trained" or (rank == 0 and world == 1 and not args.no_trained_leg and C_in == 3)
+    if need_trained:
+        t0 = time.time()
+        W_tr, curve = train_trained_like(spec, T, steps=args.train_steps, seed=rank)
+        tiles_tr = synthetic_scenes(B, T, T, C_in, seed=555000 + rank, objects=(4, 12))[0]
+        log(f"trained-like detector: {args.train_steps} steps in {time.time() - t0:.1f} s, loss {curve[0]:.2f} -> {np.mean(curve[-20:]):.2f}")
+    W, tiles = (W_tr, tiles_tr) if args.weights == "trained" else (W_rand, tiles_rand)
+    H = measure(W, tiles, True)
+    dt, stages = H["dt"], H["stages"]
+
+    ref = par = None
+    if rank == 0 and not args.no_ref:
+        ref, dets32 = reference_precision_leg(spec, W, tiles, B, args.steps, args.warmup, local_rank)
+        par = parity_object(H["dets"], dets32, "fp16-operand engine vs reference-precision (fp32 MFMA) engine, the benched batch of this line, GPU vs GPU")
+        log(f"reference precision: {ref['tiles_per_s']:.0f} tiles/s; parity {par['matched_fw']:.3f} / {par['matched_bw']:.3f} of {par['n_fw']}")
+    trained = None
+    if rank == 0 and world == 1 and args.weights == "random" and W_tr is not None:
+        Ht = measure(W_tr, tiles_tr, False)
+        trained = {"workload": f"detector trained here ({args.train_steps} SGD steps on synthetic scenes, two classes), batch {B} of fresh {T}x{T}x{C_in} scenes with 4-12 objects",
+                   "tiles_per_s": B * args.steps / Ht["dt"], "ms_per_step": Ht["dt"] / args.steps * 1e3, "steps": args.steps,
+                   "proposals_per_tile": Ht["nprop"], "detections_per_tile": Ht["ndet"], "pcie_inclusive_tiles_per_s": Ht["pcie"]}
+        if not args.no_ref:
+            rt, d32t = reference_precision_leg(spec, W_tr, tiles_tr, B, max(3, args.steps // 4), 1, local_rank)
+            trained["reference_precision_tiles_per_s"] = rt["tiles_per_s"]
+            trained["parity"] = parity_object(Ht["dets"], d32t, "fp16-operand engine vs reference-precision engine on the trained-like batch, GPU vs GPU")
+            log(f"trained-like: {trained['tiles_per_s']:.0f} tiles/s; parity {trained['parity']['matched_fw']:.3f} / {trained['parity']['matched_bw']:.3f} of {trained['parity']['n_fw']}")
+    training = None
+    if rank == 0 and world == 1 and not args.no_train_leg and C_in == 3 and T == 512:
+        training = training_leg(spec, W_rand, local_rank)
+
     if rank == 0:
         value = world * B * args.steps / dt
-        # dominant kernel: conv_igemm 128x128 variant = every conv stage with Cout % 128 == 0
         conv = [s for s in stages if s["flops"] > 0 and s["calls"] > 0]
         by_time = sorted(stages, key=lambda s: -s["ms_total"])
         tot_ms = sum(s["ms_total"] for s in stages)
@@ -266,7 +455,7 @@ def main():
         total_flops_step = sum(s["flops"] for s in conv)
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")     # written by tools/pmc_summary.py from two --pmc passes
-        if os.path.exists(pmc) and B == 16 and T == 512:
+        if os.path.exists(pmc) and B == 16 and T == 512 and args.weights == "random":
             sym = dom.split(" ")[0]                                   # "conv_deep_kernel" or "conv_igemm_kernel<2,4,4,8>"
             want = sym.replace("conv_igemm_kernel<", "").replace(">", "").replace(",", ", ")
             for k in json.load(open(pmc)):
@@ -297,30 +486,33 @@ def main():
                     mc = s["ms_total"] / s["calls"]
                     print(f"{s['name']:28s} {mc:9.4f} {s['flops'] / mc / 1e9 if mc else 0:9.1f} {s['bytes'] / mc / 1e6 if mc else 0:9.1f}", file=sys.stderr)
             print(f"sum of stage times {tot_ms / max(stages[0]['calls'], 1):.3f} ms/batch; wall {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr)
+        wl = ("seeded synthetic weights, saturated: 1000 proposals and 100 detections per tile" if args.weights == "random"
+              else f"detector trained here for {args.train_steps} steps, synthetic scenes with 4-12 objects")
         out = {
             "metric": f"tiles_per_sec_{T}x{T}x{C_in}", "value": value, "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16 operands / f32 accumulate", "data": "synthetic",
             "config": {"workload": f"Mask R-CNN R50-FPN inference, batch {B} of {T}x{T} {C_in}-band tiles per GPU "
-                                   f"(BASELINE configs[{1 if C_in == 3 else 3}]), 800x800 network input",
-                       "batch_per_gpu": B, "lanes": L, "tile": [T, T, C_in], "num_classes": 2,
-                       "proposals_per_tile": float(np.mean(nprop)), "detections_per_tile": float(np.mean(ndet)),
+                                   f"(BASELINE configs[{1 if C_in == 3 else 3}]), 800x800 network input; {wl}",
+                       "batch_per_gpu": B, "lanes": H["lanes"], "tile": [T, T, C_in], "num_classes": 2, "weights": args.weights,
+                       "proposals_per_tile": H["nprop"], "detections_per_tile": H["ndet"],
                        "sharding": "tiles across ranks, no data-path collective"},
             "roofline": roofline,
+            "reference_precision": ref,
+            "parity": par,
+            "trained_like": trained,
+            "training": training,
             "value_is": f"the {args.steps} timed steps after {args.warmup} warm-up steps (driver contract); sustained_tiles_per_s = the same loop "
-                        "run for >= --sustain-seconds right after it",
-            "sustained_tiles_per_s": sustained["tiles_per_s"] if sustained else None,
-            "sustained": sustained,
+                        "run for >= --sustain-seconds right after it; reference_precision = the same K-step region on the fp32-MFMA engine",
+            "sustained_tiles_per_s": H["sustained"]["tiles_per_s"] if H["sustained"] else None,
+            "sustained": H["sustained"],
             "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
-            "fp32_mode": fp32_mode,
-            "fp32_mode_tiles_per_s": fp32_mode["tiles_per_s"] if fp32_mode else None,
-            "pcie_inclusive_tiles_per_s": pcie_tiles_per_s,
+            "pcie_inclusive_tiles_per_s": H["pcie"],
             "top_stages": [{"name": s["name"], "ms_per_step": s["ms_total"] / max(s["calls"], 1)} for s in by_time[:6]],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, W, tiles)
         print(json.dumps(out))
-    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

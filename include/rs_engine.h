@@ -395,6 +395,14 @@ void* rs_trainer_grad_buffer(rs_trainer* t);
  * bucket i's all-reduce overlaps the rest of the backward pass.  rs_trainer_bucket_sync(i): the host-side form (collectives
  * through host memory).  rs_trainer_wait_stream(stream): the trainer's own stream waits for everything enqueued on `stream` so
  * far; call it after the last collective and before rs_trainer_apply_sgd. */
+/* Per-stage timing of the training step (bench.py --train): HIP events around every stage -- the forward stages of the training
+ * step, then the box / mask / RPN / trunk backward lists -- on the stream the stage runs on, no host wait.  on = 1 clears the
+ * accumulators and starts; rs_trainer_stage_count() resolves what has been recorded (it synchronises the trainer's streams).
+ * flops = algorithmic FLOP of the stage's last execution (0 for non-GEMM stages); on_side_stream = 1 for weight / bias gradients
+ * and RoIAlign backward, which run next to the input-gradient chain. */
+int rs_trainer_set_profiling(rs_trainer* t, int on);
+int rs_trainer_stage_count(rs_trainer* t);
+int rs_trainer_stage_info(rs_trainer* t, int i, char* name_out /* >= 96 bytes */, double* ms_total, int* calls, double* flops, int* on_side_stream);
 int rs_trainer_bucket_count(rs_trainer* t);
 int rs_trainer_bucket_info(rs_trainer* t, int i, char* name_out /* >= 96 bytes */, int64_t* offset, int64_t* count);
 int rs_trainer_bucket_wait(rs_trainer* t, int i, void* stream);

@@ -203,6 +203,7 @@ struct WgradParams {
   int m_mul;
   int splits;           // pixel-range splits (gridDim.z); wgrad_splits() proposes one
   int accumulate;       // 1: grad += result
+  int f32;              // 1: dy and x point to fp32 data (reference-precision trainer): conv_wgrad_f32_kernel
 };
 int wgrad_splits(const WgradParams& p);
 int launch_conv_wgrad(const WgradParams& p, hipStream_t stream);

@@ -569,7 +569,6 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
 int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, int use_glds) {
   if (use_glds < 0) {                   // fp32 reference-precision mode (ref_f32.hip)
     RS_CHECK(!p_in.in2, RS_ERR_UNSUPPORTED, "conv: the fp32 kernel has no second K source");
-    RS_CHECK(!(p_in.down || p_in.res32 || p_in.mask || p_in.out_stride > 1), RS_ERR_UNSUPPORTED, "conv: the fp32 kernel has no training epilogue options");
     g_last_conv_variant = -1;
     return launch_conv_f32(p_in, stream, use_glds == -2);      // -2: the VALU cross-check kernel
   }

@@ -264,6 +264,68 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
   grad[i] = accumulate ? grad[i] + s : s;
 }
 
+
+// ------------------------------------------------------------------------------------------------ reference precision (fp32)
+// Weight gradient with fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate) for the reference-precision
+// trainer (rs_spec.precision = 1; the reference trains in fp32, R:config/detectron2_config_3bands.yaml:268-305 has no AMP key).
+// One wave = a 64-channel x 64-K-column tile of dW, reduction over pixels four at a time: lane (c = lane & 15, q = lane >> 4) loads
+// 16 bytes of pixel m + q from each operand -- channels co0 + 4c .. 4c+3 of dY, columns ci0 + 4c .. 4c+3 of X -- and MFMA (t, j) multiplies
+// element t of the first with element j of the second, i.e. accumulator (t, j) holds rows co0 + 4r + t x columns ci0 + 4c + j: both
+// operands are read straight from global memory in 256-byte runs, no LDS and no transposition.  The four waves of a workgroup take
+// four adjacent K-column tiles (same dY rows: L1 hits).  Pixel range split over gridDim.z into the same fp32 partial planes as the
+// fp16 kernel, summed by wgrad_reduce_kernel in a fixed order.
+__global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slices = p.Cin >> 6;
+  const int units = p.KH * p.KW * slices;
+  const int unit = blockIdx.y * 4 + wave;
+  if (unit >= units) return;
+  int M = p.M;
+  if (p.m_count) {
+    const long long mc = (long long)(*p.m_count) * p.m_mul;
+    if (mc < M) M = (int)mc;
+  }
+  const int co0 = blockIdx.x * 64;
+  const int tap = unit / slices, ci0 = (unit - tap * slices) * 64, kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int steps = (M + 3) >> 2;
+  const int per = (steps + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int s0 = blockIdx.z * per;
+  const int s1 = s0 + per < steps ? s0 + per : steps;
+  const int lq = lane >> 4, lc = lane & 15;
+  const float* dy = (const float*)p.dy;
+  const float* x = (const float*)p.x;
+  const bool cok = co0 + 4 * lc + 4 <= p.dy_Cs;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int s = s0; s < s1; ++s) {
+    const int m = s * 4 + lq;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      const int xx = m % p.Wo, tt = m / p.Wo, y = tt % p.Ho, n = tt / p.Ho;
+      if (cok) a = *(const f32x4*)(dy + ((long long)(n * p.dy_Hp + y + p.dy_pad) * p.dy_Wp + xx + p.dy_pad) * p.dy_Cs + co0 + 4 * lc);
+      b = *(const f32x4*)(x + ((long long)(n * p.in_Hp + y * p.stride + kh + p.in_off) * p.in_Wp + xx * p.stride + kw + p.in_off) * p.in_Cs + ci0 + 4 * lc);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[j], acc[t][j], 0, 0, 0);
+  }
+  float* out = p.partial + (long long)blockIdx.z * p.Cout * p.Kpad;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = co0 + 4 * (4 * lq + e) + t;
+      if (co < p.Cout)
+        *(f32x4*)(out + (long long)co * p.Kpad + unit * 64 + 4 * lc) = f32x4{acc[t][0][e], acc[t][1][e], acc[t][2][e], acc[t][3][e]};
+    }
+}
+
 }  // namespace
 
 // 256-wide tile (CB 4) where it pays: more than 128 output channels, at least 4 K-column tiles, and a pixel range per
@@ -297,6 +359,20 @@ int wgrad_splits(const WgradParams& p) {
 }
 
 int launch_conv_wgrad(const WgradParams& p, hipStream_t stream) {
+  if (p.f32) {
+    RS_CHECK(p.dy && p.x && p.partial && p.grad, RS_ERR_ARG, "wgrad: null pointer");
+    const int units = p.KH * p.KW * (p.Cin >> 6);
+    RS_CHECK(p.M > 0 && p.Cin % 64 == 0 && p.dy_Cs % 4 == 0 && p.in_Cs % 4 == 0 && p.Cout >= 1 && units * 64 == p.Kpad && p.splits >= 1, RS_ERR_ARG,
+             "wgrad (fp32): Cin %d must be a multiple of 64 and K = %d unpadded", p.Cin, p.Kpad);
+    dim3 grid(cdiv(p.Cout, 64), cdiv(units, 4), p.splits);
+    hipLaunchKernelGGL(conv_wgrad_f32_kernel, grid, dim3(256), 0, stream, p);
+    RS_HIP(hipGetLastError());
+    const long long n_el = (long long)p.Cout * p.Kpad;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n_el, 64)), dim3(256), 0, stream, p.partial, p.splits, n_el, p.Kpad,
+                       p.scale, p.grad, p.accumulate);
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+  }
   RS_CHECK(p.dy && p.x && p.partial && p.grad && p.zeros, RS_ERR_ARG, "wgrad: null pointer");
   RS_CHECK(p.M > 0 && p.Cin % 64 == 0 && p.dy_Cs % 8 == 0 && p.Cout >= 1 && p.Cout <= p.dy_Cs, RS_ERR_ARG, "wgrad: Cin %d must be a multiple of 64, Cout %d <= gradient row width %d", p.Cin, p.Cout, p.dy_Cs);
   RS_CHECK(p.KH * p.KW * p.Cin <= p.Kpad && p.splits >= 1, RS_ERR_ARG, "wgrad: K exceeds Kpad");

@@ -744,6 +744,7 @@ __global__ __launch_bounds__(256, 6) void roi_align_win_kernel(const RoiAlignPar
 // (gather over the bins that reach the cell, then one atomic per channel), see below.
 // ---------------------------------------------------------------------------------------------
 #define RS_ROI_CELLS 320   // rows/cols of a whole RoI window the gather form handles (14 bins x 22 samples + 2 at most)
+template <typename G>     // G: storage type of the incoming gradient (half_t, or float in the reference-precision trainer)
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams p) {
   __shared__ float s_w[2][RS_ROI_PMAX][RS_ROI_WMAX];
   __shared__ int s_base[2][RS_ROI_PMAX], s_len[2][RS_ROI_PMAX];
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
   const int slot = p.slot_list ? p.slot_list[entry] : entry;
   const int n = slot / p.slots_per_image;
   const int P = p.P, PP = P + 2 * p.out_pad;
-  const half_t* gout = p.out + (long long)entry * PP * PP * 256;
+  const G* gout = (const G*)p.out + (long long)entry * PP * PP * 256;
   const int l32 = tid & 31;
   if (p.per_image_count && (slot - n * p.slots_per_image) >= p.per_image_count[n]) return;
   const float* r = p.rois + (long long)slot * 4;
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
           if (jx < 0 || jx >= s_len[1][pw]) continue;
           const float wgt = wy * s_w[1][pw][jx];
           if (wgt == 0.f) continue;
-          const half_t* gp = gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + ln;
+          const G* gp = gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + ln;
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[c] += wgt * ((float)gp[c * 64] / count);
         }
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
     const int b = b0 + wv;
     if (b >= P * P) break;                        // uniform per wave; no barrier below
     const int ph = b / P, pw = b - ph * P;
-    const half_t* gp = gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + ln;
+    const G* gp = gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + ln;
     float gsc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) gsc[c] = (float)gp[c * 64] / count;
@@ -1320,10 +1321,11 @@ int launch_roi_align(const RoiAlignParams& p, hipStream_t s) {
 }
 
 int launch_roi_align_bwd(const RoiAlignParams& p, hipStream_t s) {
-  RS_CHECK(p.C == 256 && !p.f32 && p.P <= RS_ROI_PMAX, RS_ERR_UNSUPPORTED, "roi_align backward: C must be 256, fp16, P <= %d", RS_ROI_PMAX);
+  RS_CHECK(p.C == 256 && p.P <= RS_ROI_PMAX, RS_ERR_UNSUPPORTED, "roi_align backward: C must be 256, P <= %d", RS_ROI_PMAX);
   RS_CHECK(p.S > 0, RS_ERR_ARG, "roi_align backward: S");
   for (int l = 0; l < p.nlevels; ++l) RS_CHECK(p.dfeat[l] != nullptr, RS_ERR_ARG, "roi_align backward: null gradient map");
-  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(p.S), dim3(256), 0, s, p);
+  if (p.f32) hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(p.S), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(roi_align_bwd_kernel<half_t>, dim3(p.S), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

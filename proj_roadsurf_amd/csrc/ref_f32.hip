@@ -38,7 +38,9 @@ struct TileF {
   static constexpr int LDS = 2 * STAGE;
 };
 
-template <int WPX, int WCH, int MI, int NJ>
+// TRAIN: instantiation with the backward-epilogue options of the input-gradient convolutions (ConvParams::down / res32 / mask /
+// out_stride -- every tensor fp32 here), compiled out of the inference instantiation.
+template <int WPX, int WCH, int MI, int NJ, bool TRAIN = false>
 __global__ __launch_bounds__(WPX* WCH * 64) void conv_f32_mfma_kernel(const ConvParams p) {
   using T = TileF<WPX, WCH, MI, NJ>;
   constexpr int NW = T::NW, BM = T::BM, BN = T::BN;
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_f32_mfma_kernel(const Conv
     const int x = m % p.Wo, t = m / p.Wo, y = t % p.Ho, n = t / p.Ho;
     int oy = y, ox = x;
     if (p.mode != 0) { oy = 2 * y + (g >> 1); ox = 2 * x + (g & 1); }
+    else if (TRAIN && p.out_stride > 1) { oy = y * p.out_stride; ox = x * p.out_stride; }
     const long long opix = (long long)(n * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad;
     float* op = (float*)p.out + opix * p.out_Cs + cb;
     const float* rp = p.res ? (const float*)p.res + opix * p.out_Cs + cb : nullptr;
@@ -184,6 +187,19 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_f32_mfma_kernel(const Conv
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias[i * 4 + r];
       if (rp) { const f32x4 h = *(const f32x4*)(rp + i * 4); v += h; }
       if (up) { const f32x4 h = *(const f32x4*)(up + i * 4); v += h; }
+      if (TRAIN && p.down) {      // backward of the nearest 2x upsample: add the 2x2 block of the finer gradient map
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          const long long dpix = (long long)(n * p.down_Hp + 2 * y + (dd >> 1) + p.down_pad) * p.down_Wp + 2 * x + (dd & 1) + p.down_pad;
+          v += *(const f32x4*)((const float*)p.down + dpix * p.down_Cs + cb + i * 4);
+        }
+      }
+      if (TRAIN && p.res32) v += *(const f32x4*)(p.res32 + opix * p.out_Cs + cb + i * 4);
+      if (TRAIN && p.mask) {      // ReLU backward: zero where the saved forward activation is not positive
+        const f32x4 h = *(const f32x4*)((const float*)p.mask + opix * p.out_Cs + cb + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = h[r] > 0.f ? v[r] : 0.f;
+      }
       if (p.relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
@@ -193,13 +209,13 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_f32_mfma_kernel(const Conv
   }
 }
 
-template <int WPX, int WCH, int MI, int NJ>
+template <int WPX, int WCH, int MI, int NJ, bool TRAIN = false>
 int launch_f32_variant(const ConvParams& p, hipStream_t stream) {
   using T = TileF<WPX, WCH, MI, NJ>;
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   const long long nblk = (long long)cdiv(rows, T::BN) * cdiv(p.M, T::BM);
   RS_CHECK(nblk > 0 && nblk < (1ll << 31), RS_ERR_ARG, "conv_f32: bad grid %lld", nblk);
-  const void* k = (const void*)conv_f32_mfma_kernel<WPX, WCH, MI, NJ>;
+  const void* k = (const void*)conv_f32_mfma_kernel<WPX, WCH, MI, NJ, TRAIN>;
   static bool attr = false;
   if (!attr) {
     RS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS));
@@ -316,7 +332,14 @@ int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu) {
   const bool rowmode = p.Cin < 32 && p.Cin * p.KW == 32 && p.in_Cs == p.Cin && p.Kpad % 32 == 0;
   const bool mfma_ok = !force_valu && (p.Cin % 32 == 0 || rowmode) && p.Kpad % 32 == 0 && p.in_Cs % 4 == 0 && p.out_Cs % 4 == 0 &&
                        rows % 16 == 0 && (p.mode == 0 || p.Cout % 16 == 0) && (!p.up || p.up_Cs % 4 == 0);
+  const bool train = p.down || p.res32 || p.mask || p.out_stride > 1;
+  RS_CHECK(!train || (mfma_ok && p.mode == 0), RS_ERR_UNSUPPORTED, "conv_f32: the backward epilogue needs the MFMA kernel's shape rules and mode 0");
   if (mfma_ok) {
+    if (train) {
+      if (rows % 128 == 0) return launch_f32_variant<2, 2, 4, 4, true>(p, stream);
+      if (rows % 64 == 0) return launch_f32_variant<4, 1, 4, 2, true>(p, stream);
+      return launch_f32_variant<4, 1, 1, 4, true>(p, stream);
+    }
     if (rows % 128 == 0) return launch_f32_variant<2, 2, 4, 4>(p, stream);    // 128 px x 128 ch
     if (rows % 64 == 0) return launch_f32_variant<4, 1, 4, 2>(p, stream);     // 128 px x 64 ch
     return launch_f32_variant<4, 1, 1, 4>(p, stream);                          // 256 px x 16 ch (heads)

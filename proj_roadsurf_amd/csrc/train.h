@@ -14,6 +14,7 @@ struct RpnLossParams {
   int A, cs, dcs, HW, n_anchors, level_off, total_anchors, gt_cap;   // dcs: row stride of dhead (>= 5A; 0 = cs)
   float normalizer;         // BATCH_SIZE_PER_IMAGE * N
   float loss_scale;
+  int d32;                  // 1: dhead points to fp32 (reference-precision trainer)
 };
 struct BoxLossParams {
   const float* pred;        // [n_rois][cs] fp32: [0,K] logits (K = background), then 4K deltas
@@ -28,6 +29,7 @@ struct BoxLossParams {
   int n_valid_n;
   float wx, wy, ww, wh;
   float loss_scale;
+  int d32;                  // 1: dpred points to fp32
 };
 struct MaskLossParams {
   const float* logits;      // [n_masks][S*S][cs] fp32, channel = class
@@ -38,6 +40,7 @@ struct MaskLossParams {
   const int* n_masks_ptr;   // optional device count (<= n_masks = capacity): the mean runs over it
   int n_masks, S, cs, dcs;  // dcs: row stride of dlogits (0 = cs)
   float loss_scale;
+  int d32;                  // 1: dlogits points to fp32
 };
 int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s);
 int launch_box_loss(const BoxLossParams& p, hipStream_t s);
@@ -54,6 +57,7 @@ struct FoldDesc {
   float* fwd32;
   int Cout, Cin, KH, KW, Kpad, kc, KpadT;
   unsigned block_start;     // first block of this entry in the table launch
+  int f32;                  // 1: fwd / bwd point to fp32 operands (reference-precision trainer: no rounding, same layouts)
 };
 unsigned fold_desc_blocks(const FoldDesc& d);
 int launch_fold_table(const FoldDesc* table_dev, int n_desc, unsigned total_blocks, hipStream_t s);
@@ -61,8 +65,8 @@ int launch_fold_weights(const float* w32, const float* scale, half_t* fwd, half_
                         int kc, int KpadT, hipStream_t s);
 #define RS_BIAS_GRAD_SLICES 1024  // scratch: RS_BIAS_GRAD_SLICES * cout floats
 int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s, const int* m_count,
-                     int m_mul, float* scratch);
-int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s);
+                     int m_mul, float* scratch, int f32 = 0);
+int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s, int f32 = 0);
 
 // ---- label assignment (Matcher + subsample_labels) ----
 struct MatchParams {

@@ -47,6 +47,7 @@ __device__ __forceinline__ void block_sum_to(float v, float* dst) {
 }
 
 // one thread per anchor of one level; head output rows are [pixel][cs] fp32: columns [0,A) logits, [A,5A) deltas (a*4+d)
+template <typename G>
 __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
   const int n = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;          // anchor index inside the level, order (y, x, a)
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
     const long long row = ((long long)n * p.HW + px) * p.cs;
     const int label = p.labels[(long long)n * p.total_anchors + p.level_off + i];
     const int dcs = p.dcs ? p.dcs : p.cs;
-    half_t* g = p.dhead + ((long long)n * p.HW + px) * dcs;
+    G* g = (G*)p.dhead + ((long long)n * p.HW + px) * dcs;
     float gl = 0.f, gd[4] = {0.f, 0.f, 0.f, 0.f};
     if (label >= 0) {
       const float x = p.head[row + a], t = (float)label;
@@ -76,15 +77,16 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
         }
       }
     }
-    g[a] = (half_t)(gl * p.loss_scale);
-    for (int d = 0; d < 4; ++d) g[p.A + a * 4 + d] = (half_t)(gd[d] * p.loss_scale);
-    if (a == 0) for (int c = 5 * p.A; c < dcs; ++c) g[c] = (half_t)0.f;       // padding columns of the fused head
+    g[a] = (G)(gl * p.loss_scale);
+    for (int d = 0; d < 4; ++d) g[p.A + a * 4 + d] = (G)(gd[d] * p.loss_scale);
+    if (a == 0) for (int c = 5 * p.A; c < dcs; ++c) g[c] = (G)0.f;       // padding columns of the fused head
   }
   block_sum_to(lc, p.loss_out);
   block_sum_to(ll, p.loss_out + 1);
 }
 
 // one thread per sampled RoI; pred rows [roi][cs] fp32: [0,K] class logits (background = K), then 4K deltas
+template <typename G>
 __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   float lc = 0.f, ll = 0.f;
@@ -97,10 +99,10 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
   if (r < p.n_rois) {
     const float* pr = p.pred + (long long)r * p.cs;
     const int dcs = p.dcs ? p.dcs : p.cs;
-    half_t* g = p.dpred + (long long)r * dcs;
+    G* g = (G*)p.dpred + (long long)r * dcs;
     const int K = p.K;
     const int cls = p.gt_classes[r];                       // 0..K-1 foreground, K background, -1 ignored slot
-    for (int c = 0; c < dcs; ++c) g[c] = (half_t)0.f;
+    for (int c = 0; c < dcs; ++c) g[c] = (G)0.f;
     if (cls >= 0 && cls <= K) {                            // anything else (empty slot, corrupt label) contributes nothing
       float mx = pr[0];
       for (int c = 1; c <= K; ++c) mx = fmaxf(mx, pr[c]);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
       lc = (lse - pr[cls]) / n_valid;
       for (int c = 0; c <= K; ++c) {
         const float sm = expf(pr[c] - lse);
-        g[c] = (half_t)((sm - (c == cls ? 1.f : 0.f)) / n_valid * p.loss_scale);
+        g[c] = (G)((sm - (c == cls ? 1.f : 0.f)) / n_valid * p.loss_scale);
       }
       if (cls < K) {
         const float* pb = p.proposals + (long long)r * 4;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
         for (int d = 0; d < 4; ++d) {
           const float diff = pr[K + 1 + cls * 4 + d] - tgt[d];
           ll += fabsf(diff) / n_valid;
-          g[K + 1 + cls * 4 + d] = (half_t)(sgnf(diff) / n_valid * p.loss_scale);
+          g[K + 1 + cls * 4 + d] = (G)(sgnf(diff) / n_valid * p.loss_scale);
         }
       }
     }
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
 }
 
 // one thread per (mask, pixel); logits [mask][S*S][cs] fp32 (channel = class), targets [mask][S*S] uint8
+template <typename G>
 __global__ __launch_bounds__(256) void mask_loss_kernel(const MaskLossParams p) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   float l = 0.f;
@@ -141,13 +144,13 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const MaskLossParams p) 
     const int m = (int)(i / per);
     const int cls = p.gt_classes[m];
     const int dcs = p.dcs ? p.dcs : p.cs;
-    half_t* g = p.dlogits + i * dcs;
-    for (int c = 0; c < dcs; ++c) g[c] = (half_t)0.f;
+    G* g = (G*)p.dlogits + i * dcs;
+    for (int c = 0; c < dcs; ++c) g[c] = (G)0.f;
     if (cls >= 0 && cls < p.cs) {
       const float x = p.logits[i * p.cs + cls], t = (float)p.targets[i];
       const float norm = (float)n_masks * (float)per;
       l = bce_with_logits(x, t) / norm;
-      g[cls] = (half_t)((sigmoidf(x) - t) / norm * p.loss_scale);
+      g[cls] = (G)((sigmoidf(x) - t) / norm * p.loss_scale);
     }
   }
   block_sum_to(l, p.loss_out);
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* grad, 
 // One block = one 32 (co) x 32 (ci) tile of one tap: the master rows are read along ci, the forward operand written in the
 // same layout, and the tile goes through LDS so that the transposed copy is written along co (64-byte runs instead of one
 // 2-byte element per row: the scattered form cost 0.31 ms per step for the 44 M weights, this one is bandwidth-bound).
-__device__ __forceinline__ void fold_tile(const FoldDesc& d, unsigned blk, half_t (*tile)[34]) {
+template <typename T>
+__device__ __forceinline__ void fold_tile(const FoldDesc& d, unsigned blk, T (*tile)[34]) {
   const int cit = (d.Cin + 31) >> 5, taps = d.KH * d.KW;
   const int ct = (int)(blk % cit);
   const unsigned r = blk / cit;
@@ -198,7 +202,7 @@ __device__ __forceinline__ void fold_tile(const FoldDesc& d, unsigned blk, half_
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int co = cot * 32 + ty + j * 8, ci = ct * 32 + tx;
-    half_t h = (half_t)0.f;
+    T h = (T)0.f;
     if (co < d.Cout && ci < d.Cin) {
       const long long idx = (long long)co * d.Kpad + tap * d.Cin + ci;
       float v = d.w32[idx] * (d.scale ? d.scale[co] : 1.f);
@@ -206,8 +210,8 @@ __device__ __forceinline__ void fold_tile(const FoldDesc& d, unsigned blk, half_
       // fp16), which differs from the host fold (numpy: fp32 multiply, then astype(float16)) on fp32-rounding ties -- measured
       // 5 of 73,728 weights one fp16 ulp apart
       asm volatile("" : "+v"(v));
-      h = (half_t)v;
-      d.fwd[idx] = h;
+      h = (T)v;
+      ((T*)d.fwd)[idx] = h;
     }
     tile[ty + j * 8][tx] = h;
   }
@@ -217,18 +221,19 @@ __device__ __forceinline__ void fold_tile(const FoldDesc& d, unsigned blk, half_
   for (int j = 0; j < 4; ++j) {
     const int ci = ct * 32 + ty + j * 8, co = cot * 32 + tx;
     if (co < d.Cout && ci < d.Cin)          // kc >= Cout: channel stride per tap
-      d.bwd[(long long)ci * d.KpadT + ((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.kc + co] = tile[tx][ty + j * 8];
+      ((T*)d.bwd)[(long long)ci * d.KpadT + ((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.kc + co] = tile[tx][ty + j * 8];
   }
 }
 __global__ __launch_bounds__(256) void fold_weights_kernel(const FoldDesc d) {
-  __shared__ half_t tile[32][34];
-  fold_tile(d, blockIdx.x, tile);
+  __shared__ float tile32[32][34];
+  if (d.f32) fold_tile<float>(d, blockIdx.x, tile32);
+  else fold_tile<half_t>(d, blockIdx.x, (half_t(*)[34])tile32);
 }
 // every layer of a trainer in ONE launch: the block looks its layer up in the table (block_start ascending, n_desc <= a few
 // hundred: binary search), then folds one tile of it. A descriptor with Cout == 0 is a bias copy: fwd32[g*n + j] =
 // w32[j] for g < tile (the 2x2 deconv's forward bias is the master bias repeated per GEMM), 256 elements per block.
 __global__ __launch_bounds__(256) void fold_table_kernel(const FoldDesc* __restrict__ table, int n_desc) {
-  __shared__ half_t tile[32][34];
+  __shared__ float tile32[32][34];
   int lo = 0, hi = n_desc - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -241,7 +246,8 @@ __global__ __launch_bounds__(256) void fold_table_kernel(const FoldDesc* __restr
     if (i < n) d.fwd32[i] = d.w32[i % d.Cin];
     return;
   }
-  fold_tile(d, blockIdx.x - d.block_start, tile);
+  if (d.f32) fold_tile<float>(d, blockIdx.x - d.block_start, tile32);     // block-uniform
+  else fold_tile<half_t>(d, blockIdx.x - d.block_start, (half_t(*)[34])tile32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -425,8 +431,10 @@ __global__ __launch_bounds__(1024) void subsample_kernel(const SubsampleParams p
 // + 256/(C/8), ... of its slice, so a wave reads whole contiguous rows (C = 256: two rows per load instruction); fixed
 // order inside (per thread ascending rows, then the row groups in ascending order) -> scratch[z][c].  Stage 2 adds the
 // slices in order (bitwise reproducible, no atomics).
-__global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long long rows, int C, int cout, float* scratch,
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* dy, long long rows, int C, int cout, float* scratch,
                                                        const int* m_count, int m_mul) {
+  typedef T V8 __attribute__((ext_vector_type(8)));
   __shared__ float red[256][9];
   if (m_count) { const long long mc = (long long)(*m_count) * m_mul; if (mc < rows) rows = mc; }
   const int cgs = C >> 3;
@@ -440,16 +448,16 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const half_t* dy, long l
     if (r1 > rows) r1 = rows;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ro < rpi) {
-      const half_t* src = dy + (long long)(cg0 + cg) * 8;
+      const T* src = dy + (long long)(cg0 + cg) * 8;
       long long r = r0 + ro;
       for (; r + 3 * rpi < r1; r += 4 * rpi) {
-        const half8 v0 = *(const half8*)(src + r * C), v1 = *(const half8*)(src + (r + rpi) * C);
-        const half8 v2 = *(const half8*)(src + (r + 2 * rpi) * C), v3 = *(const half8*)(src + (r + 3 * rpi) * C);
+        const V8 v0 = *(const V8*)(src + r * C), v1 = *(const V8*)(src + (r + rpi) * C);
+        const V8 v2 = *(const V8*)(src + (r + 2 * rpi) * C), v3 = *(const V8*)(src + (r + 3 * rpi) * C);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc[i] += (float)v0[i]; acc[i] += (float)v1[i]; acc[i] += (float)v2[i]; acc[i] += (float)v3[i]; }
       }
       for (; r < r1; r += rpi) {
-        const half8 v = *(const half8*)(src + r * C);
+        const V8 v = *(const V8*)(src + r * C);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
       }
@@ -493,7 +501,9 @@ __global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float* scra
 }
 
 // backward of LastLevelMaxPool (max_pool2d k=1 s=2): d_fine[2y][2x] += d_coarse[y][x]; both NHWC fp16 with halo 1
-__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const half_t* dc, half_t* df, int N, int Hf, int Wf, int Hc, int Wc, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const T* dc, T* df, int N, int Hf, int Wf, int Hc, int Wc, int C) {
+  typedef T V8 __attribute__((ext_vector_type(8)));
   const int cv = C >> 3;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)N * Hc * Wc * cv;
@@ -503,12 +513,12 @@ __global__ __launch_bounds__(256) void subsample2_bwd_kernel(const half_t* dc, h
   const int x = (int)(t % Wc); t /= Wc;
   const int y = (int)(t % Hc);
   const int n = (int)(t / Hc);
-  const half8 a = *(const half8*)(dc + (((long long)n * (Hc + 2) + y + 1) * (Wc + 2) + x + 1) * C + c8 * 8);
-  half_t* o = df + (((long long)n * (Hf + 2) + 2 * y + 1) * (Wf + 2) + 2 * x + 1) * C + c8 * 8;
-  half8 b = *(const half8*)o;
+  const V8 a = *(const V8*)(dc + (((long long)n * (Hc + 2) + y + 1) * (Wc + 2) + x + 1) * C + c8 * 8);
+  T* o = df + (((long long)n * (Hf + 2) + 2 * y + 1) * (Wf + 2) + 2 * x + 1) * C + c8 * 8;
+  V8 b = *(const V8*)o;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) b[i] = (half_t)((float)b[i] + (float)a[i]);
-  *(half8*)o = b;
+  for (int i = 0; i < 8; ++i) b[i] = (T)((float)b[i] + (float)a[i]);
+  *(V8*)o = b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -597,19 +607,22 @@ __global__ __launch_bounds__(256) void mask_entries_kernel(const MaskEntriesPara
 
 int launch_rpn_loss(const RpnLossParams& p, int N, hipStream_t s) {
   RS_CHECK(p.head && p.dhead && p.labels && p.anchors && (p.matched_gt || (p.gt && p.matched)) && p.loss_out && p.n_anchors > 0 && p.cs >= 5 * p.A, RS_ERR_ARG, "rpn_loss: bad arguments");
-  hipLaunchKernelGGL(rpn_loss_kernel, dim3(cdiv(p.n_anchors, 256), N), dim3(256), 0, s, p);
+  if (p.d32) hipLaunchKernelGGL(rpn_loss_kernel<float>, dim3(cdiv(p.n_anchors, 256), N), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(rpn_loss_kernel<half_t>, dim3(cdiv(p.n_anchors, 256), N), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
 int launch_box_loss(const BoxLossParams& p, hipStream_t s) {
   RS_CHECK(p.pred && p.dpred && p.gt_classes && p.proposals && p.gt_boxes && p.loss_out && p.n_rois > 0 && p.cs >= 5 * p.K + 1 && (p.n_valid > 0 || p.n_valid_counts), RS_ERR_ARG, "box_loss: bad arguments");
-  hipLaunchKernelGGL(box_loss_kernel, dim3(cdiv(p.n_rois, 256)), dim3(256), 0, s, p);
+  if (p.d32) hipLaunchKernelGGL(box_loss_kernel<float>, dim3(cdiv(p.n_rois, 256)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(box_loss_kernel<half_t>, dim3(cdiv(p.n_rois, 256)), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
 int launch_mask_loss(const MaskLossParams& p, hipStream_t s) {
   RS_CHECK(p.logits && p.dlogits && p.targets && p.gt_classes && p.loss_out && p.n_masks > 0 && p.S > 0, RS_ERR_ARG, "mask_loss: bad arguments");
-  hipLaunchKernelGGL(mask_loss_kernel, dim3((unsigned)cdiv((long long)p.n_masks * p.S * p.S, 256)), dim3(256), 0, s, p);
+  if (p.d32) hipLaunchKernelGGL(mask_loss_kernel<float>, dim3((unsigned)cdiv((long long)p.n_masks * p.S * p.S, 256)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(mask_loss_kernel<half_t>, dim3((unsigned)cdiv((long long)p.n_masks * p.S * p.S, 256)), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
@@ -666,20 +679,22 @@ int launch_subsample(const SubsampleParams& p, int N, hipStream_t s) {
 }
 
 int launch_bias_grad(const half_t* dy, long long rows, int C, int cout, float* grad, int accumulate, hipStream_t s, const int* m_count,
-                     int m_mul, float* scratch) {
+                     int m_mul, float* scratch, int f32) {
   RS_CHECK(dy && grad && scratch && rows > 0 && C % 8 == 0 && cout > 0 && cout <= C, RS_ERR_ARG, "bias_grad: bad arguments");
   int slices = (int)(rows * (C >> 3) / 4096);    // >= 16 rows per thread and slice
   if (slices < 1) slices = 1;
   if (slices > RS_BIAS_GRAD_SLICES) slices = RS_BIAS_GRAD_SLICES;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(slices), dim3(256), 0, s, dy, rows, C, cout, scratch, m_count, m_mul);
+  if (f32) hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(slices), dim3(256), 0, s, (const float*)dy, rows, C, cout, scratch, m_count, m_mul);
+  else hipLaunchKernelGGL(bias_grad_kernel<half_t>, dim3(slices), dim3(256), 0, s, dy, rows, C, cout, scratch, m_count, m_mul);
   hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(cdiv(cout, 16)), dim3(256), 0, s, scratch, slices, cout, grad, accumulate);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
-int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s) {
+int launch_subsample2_bwd(const half_t* d_coarse, half_t* d_fine, int N, int Hf, int Wf, int Hc, int Wc, int C, hipStream_t s, int f32) {
   RS_CHECK(d_coarse && d_fine && C % 8 == 0 && 2 * (Hc - 1) < Hf && 2 * (Wc - 1) < Wf, RS_ERR_ARG, "subsample2_bwd: bad arguments");
   const long long total = (long long)N * Hc * Wc * (C >> 3);
-  hipLaunchKernelGGL(subsample2_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, d_coarse, d_fine, N, Hf, Wf, Hc, Wc, C);
+  if (f32) hipLaunchKernelGGL(subsample2_bwd_kernel<float>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const float*)d_coarse, (float*)d_fine, N, Hf, Wf, Hc, Wc, C);
+  else hipLaunchKernelGGL(subsample2_bwd_kernel<half_t>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, d_coarse, d_fine, N, Hf, Wf, Hc, Wc, C);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

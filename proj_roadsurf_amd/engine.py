@@ -817,6 +817,9 @@ class Trainer:
         lib.rs_trainer_mask_forward.argtypes = [vp, i32]
         lib.rs_trainer_mask_backward.argtypes = [vp, i32, vp, i32]
         lib.rs_trainer_sync.argtypes = [vp]
+        lib.rs_trainer_set_profiling.argtypes = [vp, i32]
+        lib.rs_trainer_stage_count.argtypes = [vp]
+        lib.rs_trainer_stage_info.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         lib.rs_trainer_tensor.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         lib.rs_trainer_tensor_count.argtypes = [vp]
         lib.rs_trainer_tensor_name.argtypes = [vp, i32, C.c_char_p]
@@ -991,6 +994,21 @@ class Trainer:
         if getattr(self, "_infer", None) is None:
             self._infer = Engine.from_handle(self.lib, int(self._eng.value), self.spec, (self.tile_h, self.tile_w, self.tile_c), self.batch)
         return self._infer
+
+    def set_profiling(self, on: bool) -> None:
+        """HIP events around every stage of the following training steps (``stage_times`` reads them)."""
+        _check(self.lib, self.lib.rs_trainer_set_profiling(self._h, 1 if on else 0), "rs_trainer_set_profiling")
+
+    def stage_times(self) -> List[Dict[str, Any]]:
+        """Per stage of the training step since ``set_profiling(True)``: name, ms_total, calls, algorithmic flops of one execution,
+        side (True: runs on the weight-gradient side stream, next to the chain)."""
+        out = []
+        name = C.create_string_buffer(96)
+        ms, fl, calls, sd = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+        for i in range(self.lib.rs_trainer_stage_count(self._h)):
+            _check(self.lib, self.lib.rs_trainer_stage_info(self._h, i, name, C.byref(ms), C.byref(calls), C.byref(fl), C.byref(sd)), "rs_trainer_stage_info")
+            out.append({"name": name.value.decode(), "ms_total": ms.value, "calls": calls.value, "flops": fl.value, "side": bool(sd.value)})
+        return out
 
     def buckets(self) -> List[Tuple[str, int, int]]:
         """Gradient buckets (name, offset, count in floats of the flat gradient buffer) in the order a step completes them."""

@@ -112,12 +112,14 @@ def detectron2_head_init(spec, W: Dict[str, np.ndarray], seed: int = 0) -> Dict[
     return out
 
 
-def train_trained_like(spec, tile: int = 512, steps: int = 300, batch: int = 4, seed: int = 0, lr: float = 0.01,
-                       warmup: int = 50, loss_scale: float = 1024.0, log=None, W0: Optional[Dict[str, np.ndarray]] = None,
+def train_trained_like(spec, tile: int = 512, steps: int = 300, batch: int = 4, seed: int = 0, lr: Optional[float] = None,
+                       warmup: int = 100, loss_scale: float = 1024.0, log=None, W0: Optional[Dict[str, np.ndarray]] = None,
                        pool: int = 48) -> Tuple[Dict[str, np.ndarray], List[float]]:
     """``steps`` SGD iterations (reference solver: momentum 0.9, weight decay 1e-4, linear warm-up from 0.001 x lr,
     R:config/detectron2_config_3bands.yaml:268-305) of the training engine on a pool of ``pool`` ``synthetic_scenes``
     (scene seeds ``seed * 7919 + 1 ...``), starting from ``synthetic_weights`` with detectron2's head initialisation.
+    ``lr`` defaults to the reference's BASE_LR 0.01 at IMS_PER_BATCH 8 scaled linearly to ``batch`` (0.005 at batch 4): at 0.01 with
+    a 50-step warm-up one training seed in three diverged right after the warm-up (round 3, seed 2: loss_cls 8e4 at iteration 73).
     Returns (weights under detectron2 key names, total-loss curve)."""
     from .engine import Trainer
     from .spec import resize_shortest_edge_shape
@@ -132,6 +134,8 @@ def train_trained_like(spec, tile: int = 512, steps: int = 300, batch: int = 4, 
     npoly = [[[p * np.tile([sx, sy], p.size // 2) for p in inst] for inst in img] for img in polys]
     order = np.random.default_rng(seed)
     curve: List[float] = []
+    if lr is None:
+        lr = 0.01 * batch / 8.0
     try:
         scale = loss_scale
         for it in range(steps):

@@ -540,4 +540,6 @@ def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False
         for k, v in T32.items():
             if k.endswith(".w") and k != "roi_heads.mask_head.predictor.w":
                 T[k + "32"] = v
+        if train and "roi_heads.mask_head.predictor16.m32" in T:      # the reference-precision trainer's 16-row mask predictor operand
+            T["roi_heads.mask_head.predictor16.w32"] = T["roi_heads.mask_head.predictor16.m32"]
     return serialize(T)

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle runs on torch CPU: a one-GPU box's share is 16 cores whatever the host shows, and torch's default of one thread
+    # per visible core oversubscribes them (measured: the oracle ~5x slower)
+    try:
+        import torch
+
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(16, n)))
+    except Exception:
+        pass
 
 
 def has_gpu() -> bool:

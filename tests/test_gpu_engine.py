@@ -10,16 +10,17 @@ Two kinds of checks:
   matched greedily by class + IoU >= 0.95.  SURVEY.md §8d's tolerance is >= 98 % matched both ways, |dscore| <= 0.02,
   mask IoU >= 0.95.  Two workloads:
   - TRAINED-LIKE weights (proj_roadsurf_amd.synthetic.train_trained_like: the repo's own trainer, 600 SGD steps on
-    synthetic scenes): the fp16 engine MEETS the tolerance -- measured on MI355X (round 2, four training runs x 12 fresh
-    scenes, profiles/r02/parity/trained_like_stats.json): 98.9-100 % matched both ways, |dscore| <= 4.3e-3, mask IoU
-    >= 0.96.  `test_fp16_meets_the_stated_tolerance_on_a_trained_like_detector` asserts the stated numbers.
+    synthetic scenes): the fp16 engine MEETS the tolerance -- asserted on a pool of four training seeds x 48 scenes (>= 1500
+    detections) together with the Wilson lower bound of the matched fraction
+    (`test_fp16_meets_the_stated_tolerance_on_a_trained_like_detector`; measured values in profiles/r03/parity/).
   - RANDOM weights (weights.synthetic_weights): every proposal regresses to a box of its own and the top-100 scores lie
     within a few percent of each other, so the detection set is chaotic in the features: re-running the ORACLE ITSELF on its
     own fp32 FPN maps plus relative Gaussian noise loses 2-6 % of the detections at 3e-4 noise and is back at 98-100 % only
     at 1e-4 (tools/parity/noise_sensitivity.py, profiles/r02/parity/noise_random.json), and the oracle downstream of the
     engine's fp16 FPN maps (rel. error 1e-3, everything after the backbone in fp32) already differs in 3-14 %
-    (tools/parity/bisect.py, profiles/r02/parity/bisect_random.json).  No choice of precision for the small
-    score-deciding GEMMs can repair that: the loss is in the fp16 storage of the trunk.  Measured: 85-95 % matched,
+    (tools/parity/bisect.py, profiles/r02/parity/bisect_random.json).  The detections that differ already differ there: the
+    loss is in the fp16 storage of the trunk (the same finding, stage by stage, on the trained-like workload: tools/parity/
+    bisect_stages.py, profiles/r03/parity/).  Measured: 85-95 % matched,
     |dscore| <= 1e-3.  These tests assert >= 0.85 on the fp16 engine and the strict bar on the reference-precision (fp32
     MFMA) mode, which is what pins the engine's LOGIC on this workload (100 % matched, |dscore| <= 2e-6).
 """
@@ -308,44 +309,56 @@ def test_lane_pipeline_streaming_host_interface(small):
 
 
 def test_fp16_meets_the_stated_tolerance_on_a_trained_like_detector(gpu_required):
-    """SURVEY.md §8d's tolerance for the fp16 production mode, asserted at its stated values, on the workload it is meant
-    for: a detector whose scores separate and whose duplicate proposals regress to the same object.  The weights come from
-    the repo's own training engine (600 SGD steps on synthetic scenes with two object classes, ~12 s); the comparison is
-    fp16 engine vs fp32 oracle on 12 fresh 512x512 scenes (800x800 network input, 1000 proposals), aggregated over the
-    scenes because a scene holds only 3-14 detections."""
+    """SURVEY.md §8d's tolerance for the fp16 production mode, asserted at its stated values on the workload it is meant for: a
+    detector whose scores separate and whose duplicate proposals regress to the same object.  FOUR training campaigns (seeds 0..3 of
+    the repo's own training engine, 600 SGD steps each on synthetic scenes with two object classes, ~12 s per campaign; the seeds are
+    the first four, not chosen) x 48 fresh 512x512 scenes with 4-12 objects (800x800 network input, 1000 proposals): fp16 engine vs
+    fp32 oracle, >= 1500 reference detections pooled.  Asserted on the POOL, both directions: matched fraction >= 0.98 AND the 95 %
+    Wilson lower bound of it >= 0.98; on every scene |dscore| <= 0.02 and mask IoU >= 0.95 of the matched pairs.
+    Measured (round 3, profiles/r03/parity/): 99.3-99.7 % matched, lower bound 0.989+; the residual misses are near-ties of two boxes
+    of ONE object in the final NMS (scores 1e-4 apart, IoU 0.7-0.9 between them) which the fp16 trunk's 4e-4 feature noise flips --
+    tools/parity/bisect_stages.py finds them already in "oracle downstream of the engine's FPN maps" and none added by any later stage."""
+    from proj_roadsurf_amd.matching import wilson_lower
     from proj_roadsurf_amd.synthetic import synthetic_scenes, train_trained_like
     from tests.util import box_iou
     O = _oracle()
     spec = EngineSpec(num_classes=2)
-    W, curve = train_trained_like(spec, 512, steps=600, seed=1)       # profiles/r02/parity/trained_like_stats.json: 76 of 76 both ways, twice
-    assert np.mean(curve[-20:]) < 0.6 * curve[0], (curve[0], np.mean(curve[-20:]))          # it did train
-    n = 12
-    tiles, gtb, gtc, _ = synthetic_scenes(n, 512, 512, 3, seed=987654)
-    eng = Engine(spec, W, (512, 512, 3), max_batch=n)
-    try:
-        dets = eng.infer(tiles)
-    finally:
-        eng.close()
-    ref = O.OracleModel(spec, W)([tiles[i] for i in range(n)])
+    n, B = 48, 16
     tot = {"fw_n": 0, "fw_m": 0, "bw_n": 0, "bw_m": 0}
-    recalled = total_gt = 0
-    for i in range(n):
-        r = {"boxes": ref[i]["boxes"].numpy(), "scores": ref[i]["scores"].numpy(), "classes": ref[i]["classes"].numpy(), "masks": ref[i]["masks"].numpy()}
-        g = {"boxes": dets[i].pred_boxes, "scores": dets[i].scores, "classes": dets[i].pred_classes, "masks": dets[i].pred_masks}
-        fw, bw = match_detections(r, g), match_detections(g, r)
-        print("trained_like", i, fw, bw)
-        tot["fw_n"] += fw["n_ref"]; tot["fw_m"] += round(fw["frac_matched"] * fw["n_ref"])
-        tot["bw_n"] += bw["n_ref"]; tot["bw_m"] += round(bw["frac_matched"] * bw["n_ref"])
-        assert fw["max_dscore"] <= 0.02, fw
-        assert fw["min_mask_iou"] >= 0.95 and fw["agg_mask_iou"] >= 0.95, fw
-        hi = dets[i].scores >= 0.5
-        iou = box_iou(gtb[i], dets[i].pred_boxes[hi]) if hi.any() else np.zeros((len(gtb[i]), 0))
-        recalled += int((iou.max(1) >= 0.5).sum()) if iou.shape[1] else 0
-        total_gt += len(gtb[i])
-    print("trained_like total", tot, "gt recalled", recalled, "of", total_gt)
-    assert recalled >= 0.9 * total_gt, "the trained-like detector does not detect its objects"
-    assert tot["fw_n"] >= 50
+    for seed in (0, 1, 2, 3):
+        W, curve = train_trained_like(spec, 512, steps=600, seed=seed)
+        assert np.mean(curve[-20:]) < 0.6 * curve[0], (seed, curve[0], np.mean(curve[-20:]))          # it did train
+        tiles, gtb, gtc, _ = synthetic_scenes(n, 512, 512, 3, seed=987654 + seed, objects=(4, 12))
+        eng = Engine(spec, W, (512, 512, 3), max_batch=B)
+        try:
+            dets = [d for b0 in range(0, n, B) for d in eng.infer(tiles[b0:b0 + B])]
+        finally:
+            eng.close()
+        m = O.OracleModel(spec, W)
+        st = {"fw_n": 0, "fw_m": 0, "bw_n": 0, "bw_m": 0}
+        recalled = total_gt = 0
+        for i in range(n):
+            ref = m([tiles[i]])[0]
+            r = {"boxes": ref["boxes"].numpy(), "scores": ref["scores"].numpy(), "classes": ref["classes"].numpy(), "masks": ref["masks"].numpy()}
+            g = {"boxes": dets[i].pred_boxes, "scores": dets[i].scores, "classes": dets[i].pred_classes, "masks": dets[i].pred_masks}
+            fw, bw = match_detections(r, g), match_detections(g, r)
+            for t in (tot, st):
+                t["fw_n"] += fw["n_ref"]; t["fw_m"] += round(fw["frac_matched"] * fw["n_ref"])
+                t["bw_n"] += bw["n_ref"]; t["bw_m"] += round(bw["frac_matched"] * bw["n_ref"])
+            assert fw["max_dscore"] <= 0.02, (seed, i, fw)
+            assert fw["min_mask_iou"] >= 0.95 and fw["agg_mask_iou"] >= 0.95, (seed, i, fw)
+            hi = dets[i].scores >= 0.5
+            iou = box_iou(gtb[i], dets[i].pred_boxes[hi]) if hi.any() else np.zeros((len(gtb[i]), 0))
+            recalled += int((iou.max(1) >= 0.5).sum()) if iou.shape[1] else 0
+            total_gt += len(gtb[i])
+        print("trained_like seed", seed, st, "gt recalled", recalled, "of", total_gt, "loss", round(float(np.mean(curve[-20:])), 3))
+        assert recalled >= 0.9 * total_gt, "the trained-like detector does not detect its objects"
+    lo_fw, lo_bw = wilson_lower(tot["fw_m"], tot["fw_n"]), wilson_lower(tot["bw_m"], tot["bw_n"])
+    print("trained_like pooled", tot, "matched", round(tot["fw_m"] / tot["fw_n"], 4), round(tot["bw_m"] / tot["bw_n"], 4),
+          "Wilson 95 % lower bound", round(lo_fw, 4), round(lo_bw, 4))
+    assert tot["fw_n"] >= 1500
     assert tot["fw_m"] >= 0.98 * tot["fw_n"] and tot["bw_m"] >= 0.98 * tot["bw_n"], tot
+    assert lo_fw >= 0.98 and lo_bw >= 0.98, (tot, lo_fw, lo_bw)
 
 
 def test_full_size_512_tile(gpu_required):
