@@ -82,7 +82,8 @@ def _trace_rings(mask: np.ndarray) -> List[Ring]:
 
 
 def ring_area(ring: Sequence[Tuple[float, float]]) -> float:
-    """Signed shoelace area (positive = clockwise in image coordinates with y down)."""
+    """Signed shoelace area (positive = clockwise on the screen, y down: the tracer's exteriors; ``mask_to_polygons`` RETURNS its
+    rings reversed, rasterio's direction, so its exteriors read negative and its holes positive)."""
     a = 0.0
     for (x0, y0), (x1, y1) in zip(ring[:-1], ring[1:]):
         a += x0 * y1 - x1 * y0
@@ -122,7 +123,10 @@ def mask_to_polygons(mask: np.ndarray) -> List[Polygon]:
                     best, best_area = i, a
         if best is not None:
             polys[best].append(hr)
-    return polys
+    # Ring direction as rasterio.features.shapes emits it (its documentation, topics/features: the single pixel at column 71, row 6
+    # comes out as [(71,6), (71,7), (72,7), (72,6), (71,6)]): from the start vertex DOWN first, counter-clockwise on the screen for
+    # exteriors, holes the other way round.  ``_trace_rings`` walks the other way; reversing a closed ring keeps its start vertex.
+    return [[list(reversed(r)) for r in poly] for poly in polys]
 
 
 def rdp(points: Sequence[Tuple[float, float]], epsilon: float) -> List[Tuple[float, float]]:

@@ -424,13 +424,22 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
 // Tail rule.  One workgroup per CU is resident, all tiles of a launch take the same time, so T tiles run in ceil(T / CUs) rounds.
 // If the last round holds r <= CUs / 2 tiles, those r tiles are split into 2 r tiles of 128 pixels, which fit one round of about
 // half the length (625 tiles on 256 CUs: 3 rounds -> ~2.55).  Returns r (0: no split).
-static int deep_tail_tiles(long long tiles) {
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    ncu = n;
+int rs_device_cu_count() {
+  // per device ordinal: a process may drive several (different) devices; without a device (the dispatch rule queried on a CPU-only
+  // box: rs_op_conv_variant, tests/golden/conv_variants.json) the MI355X's 256
+  static int ncu[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!ncu[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu[dev] = n;
   }
+  return ncu[dev];
+}
+
+static int deep_tail_tiles(long long tiles) {
+  const int ncu = rs_device_cu_count();
   if (!rs_debug().deep_tail) return 0;
   const int r = (int)(tiles % ncu);
   return (r > 0 && 2 * r <= ncu) ? r : 0;

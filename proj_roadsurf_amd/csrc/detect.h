@@ -49,6 +49,9 @@ struct RpnMergeParams {
   float* prop_scores;       // [N][cap]
   int* prop_level;          // optional [N][cap]
   int* prop_count;          // [N]
+  int* prop_order;          // optional [N][cap]: the image's slots sorted by (FPN level of the RoI pooler, top row, left column) -- the order
+                            // box.roi_align visits them in (RoiAlignParams::order), so that neighbouring workgroups read neighbouring
+                            // feature rows; slots beyond prop_count come last
 };
 
 struct RoiAlignParams {
@@ -65,6 +68,8 @@ struct RoiAlignParams {
   half_t* out;              // [entry][P+2*out_pad][P+2*out_pad][256]
   int P, out_pad;
   int* out_level;           // optional [entry]
+  const int* order;         // optional [S]: workgroup k processes entry order[remap(k)] (remap = the XCD-aware bijection of the conv
+                            // kernels: each XCD's L2 sees one contiguous run of the order); results land in the entry's own slot
   int f32;                  // fp32 validation mode: features and output are float
   // backward (roi_align_bwd_kernel): `out` holds the incoming gradient [entry][P+2*out_pad]^2[256] fp16 and the
   // gradient of the feature maps is accumulated (float atomics) into dfeat[level], fp32, same geometry as feat[level]

@@ -32,7 +32,7 @@ void rs_debug_reload() {
   rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_DEEP_TILE_PX", &d.deep_tile_px); rd("RS_FUSE_BNECK", &d.fuse_bneck); rd("RS_FUSE_STEM", &d.fuse_stem);
   rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
   rd("RS_TRAIN_SIDE", &d.train_side); rd("RS_WGRAD_TARGET", &d.wgrad_target); rd("RS_WGRAD_CB", &d.wgrad_cb);
-  rd("RS_SELECT_DEBUG", &d.select_debug); rd("RS_NMS_DEBUG", &d.nms_debug); rd("RS_ROI_WINDOW", &d.roi_window);
+  rd("RS_SELECT_DEBUG", &d.select_debug); rd("RS_NMS_DEBUG", &d.nms_debug); rd("RS_ROI_WINDOW", &d.roi_window); rd("RS_ROI_ORDER", &d.roi_order);
   g_debug = d;
   g_debug_loaded = true;
 }
@@ -778,11 +778,20 @@ int rs_engine::build() {
   reg("proposal_logits", prop_scores, DT_F32, {NB, PC}, 0);
   reg("proposal_level", prop_level, DT_I32, {NB, PC}, 0);
   reg("proposal_count", prop_count, DT_I32, {NB}, 0);
+  // visiting order of box.roi_align (RpnMergeParams::prop_order): inference engines on the windowed fp16 kernel only -- a training
+  // engine overwrites the proposal buffer with its sampled RoIs after this stage
+  int* prop_order = nullptr;
+  const bool roi_order = !f32 && !g_trainer_unfused_shortcut && rs_debug().roi_order != 0;
+  if (roi_order) {
+    if ((rc = alloc((void**)&prop_order, (size_t)NB * PC * 4))) return rc;
+    reg("proposal_order", prop_order, DT_I32, {NB, PC}, 0);
+  }
   {
     RpnMergeParams mp = {};
     mp.cand_boxes = rp.cand_boxes; mp.cand_scores = rp.cand_scores; mp.keep = cand_keep; mp.cand_count = rp.cand_count;
     mp.L = L; mp.post_topk = S.rpn_post_nms_topk; mp.cap = PC;
     mp.prop_boxes = prop_boxes; mp.prop_scores = prop_scores; mp.prop_level = prop_level; mp.prop_count = prop_count;
+    mp.prop_order = prop_order;
     Stage st;
     st.name = "rpn.merge";
     st.fn = [mp](int n, hipStream_t s) { return launch_rpn_merge(mp, n, s); };
@@ -804,6 +813,7 @@ int rs_engine::build() {
     RoiAlignParams q = ra;
     q.rois = prop_boxes; q.per_image_count = prop_count; q.slots_per_image = PC; q.out = boxfeat.p; q.P = PR; q.out_pad = 0;
     q.out_level = box_level;
+    q.order = prop_order;
     Stage st;
     st.name = "box.roi_align";
     st.bytes_per_image = (double)PC * PR * PR * 256 * 2 * 2;

@@ -227,6 +227,12 @@ void vectorize_one(const uint8_t* m, int wb, int h, int w, double eps, InstOut& 
     }
     if (best >= 0) poly[best].push_back((int)i);
   }
+  // Ring direction as rasterio.features.shapes (GDAL polygonize) emits it: the exterior of a single pixel at column 71, row 6 is
+  // [(71,6), (71,7), (72,7), (72,6), (71,6)] in rasterio's documentation (topics/features) -- from the top-left corner DOWN first,
+  // i.e. counter-clockwise on the screen (y down), holes the other way round.  The tracer above walks the other way (foreground on
+  // its right); the rings are reversed here, keeping their start vertex, BEFORE the simplification: Douglas-Peucker on a closed ring
+  // depends on where the ring starts and which way it runs.
+  for (Ring& r : rings) std::reverse(r.begin(), r.end());
   Ring simp;
   for (size_t p = 0; p < poly.size(); ++p) {
     o.poly_ring_count.push_back((int32_t)poly[p].size());

@@ -91,3 +91,45 @@ def test_max_dets_and_empty_inputs():
     gm = np.zeros((1, 8, 8), bool); gm[0, 2:6, 2:6] = True
     r = evaluate([_img([[2, 2, 6, 6]], [0], masks=gm)], [_img(np.zeros((0, 4)), [], scores=[], masks=np.zeros((0, 8, 8), bool))], 1, "segm")
     assert r["AP"] == pytest.approx(0.0)
+
+
+def test_cocoeval_rules_crowd_area_range_maxdets_ties():
+    """The rules of pycocotools' COCOeval.evaluateImg / accumulate that decide ignore flags and ordering, each on a case whose answer
+    follows from the published rule (pycocotools itself is absent: parity unpinned):
+    * a crowd region absorbs ANY number of detections (its gtm flag never blocks) and they become "ignored", not false positives;
+    * a detection that reaches a regular ground truth keeps it even when a crowd region overlaps it more (regular gts are scanned
+      first and the scan stops at the first ignored gt once a regular match exists);
+    * per area range, ground truths outside the range are "ignore", detections matched to them are ignored, UNMATCHED detections
+      outside the range are ignored too;
+    * maxDets caps the detections per (image, category), highest scores first;
+    * equal scores keep their input order (mergesort)."""
+    # crowd absorbs two detections
+    g = [_img([[0, 0, 10, 10], [50, 50, 150, 150]], [0, 0], crowd=[False, True])]
+    d = [_img([[0, 0, 10, 10], [60, 60, 80, 80], [100, 100, 120, 120]], [0, 0, 0], scores=[0.9, 0.8, 0.7])]
+    assert evaluate(g, d, 1, "bbox")["AP"] == pytest.approx(100.0)
+    # duplicate of a detected object inside a crowd region: ignored with the crowd flag, a false positive without it
+    gb = [[0, 0, 10, 10], [0, 0, 10, 12], [40, 40, 60, 60]]
+    dd = [_img([[0, 0, 10, 10], [0, 0, 10, 10], [40, 40, 60, 60]], [0, 0, 0], scores=[0.9, 0.8, 0.7])]
+    assert evaluate([_img(gb, [0, 0, 0], crowd=[False, True, False])], dd, 1, "bbox")["AP50"] == pytest.approx(100.0)
+    stair = (51 * 1.0 + 50 * 2 / 3) / 101 * 100
+    assert evaluate([_img([gb[0], gb[2]], [0, 0])], dd, 1, "bbox")["AP50"] == pytest.approx(stair)
+    # the first detection keeps the REGULAR ground truth although the crowd's IoU (intersection over detection area) is as high
+    one = [_img([[0, 0, 10, 10]], [0], scores=[0.9])]
+    assert evaluate([_img([[0, 0, 10, 10], [0, 0, 10, 12]], [0, 0], crowd=[False, True])], one, 1, "bbox")["AP"] == pytest.approx(100.0)
+    # area ranges
+    g = [_img([[0, 0, 20, 20], [100, 100, 300, 300]], [0, 0])]                      # small (undetected), large (detected)
+    d = [_img([[100, 100, 300, 300], [400, 400, 600, 600]], [0, 0], scores=[0.9, 0.5])]   # + an unmatched large detection
+    r = evaluate(g, d, 1, "bbox")
+    assert r["APl"] == pytest.approx(100.0)                  # small gt ignored; TP, then the FP ranked last
+    assert r["APs"] == pytest.approx(0.0)                    # the small gt is never reached; both detections are ignored in this range
+    assert r["AP50"] == pytest.approx(51 / 101 * 100)        # all areas: two gts, TP then FP
+    # maxDets per (image, category)
+    g = [_img([[0, 0, 10, 10], [0, 0, 10, 10]], [0, 1])]
+    d = [_img([[50, 50, 60, 60], [70, 70, 80, 80], [0, 0, 10, 10], [0, 0, 10, 10]], [0, 0, 0, 1], scores=[0.9, 0.8, 0.7, 0.6])]
+    r = evaluate(g, d, 2, "bbox", max_dets=2)
+    assert r["AP-class0"] == pytest.approx(0.0) and r["AP-class1"] == pytest.approx(100.0) and r["AP"] == pytest.approx(50.0)
+    # ties: input order decides
+    g = [_img([[0, 0, 10, 10]], [0])]
+    fp_first = [_img([[50, 50, 60, 60], [0, 0, 10, 10]], [0, 0], scores=[0.5, 0.5])]
+    tp_first = [_img([[0, 0, 10, 10], [50, 50, 60, 60]], [0, 0], scores=[0.5, 0.5])]
+    assert evaluate(g, fp_first, 1, "bbox")["AP50"] == pytest.approx(50.0) and evaluate(g, tp_first, 1, "bbox")["AP50"] == pytest.approx(100.0)

@@ -593,6 +593,47 @@ def test_fused_stem_changes_no_bit(gpu_required, monkeypatch):
         assert all(_same_instances(a, b) for a, b in zip(d0, d1))
 
 
+def test_roi_visiting_order_is_a_permutation_and_changes_no_bit(gpu_required, monkeypatch):
+    """box.roi_align visits the proposals sorted by (pooler level, top row, left column) instead of in score order, so that
+    neighbouring workgroups read neighbouring rows of one feature map (L2 hits; csrc/detect_kernels.hip rpn_merge_kernel /
+    RoiAlignParams::order).  Pure scheduling: the order is a permutation of every image's slots, sorted as stated over the valid
+    ones, and the pooled features, levels and detections are BIT-identical to the engine without it (RS_ROI_ORDER=0)."""
+    spec = EngineSpec(num_classes=2, min_size_test=512, max_size_test=853)
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(3, 512, 512, 3, seed=99)
+    O = _oracle()
+
+    def run(want_order):
+        eng = Engine(spec, W, (512, 512, 3), max_batch=3)
+        try:
+            dets = eng.infer(tiles)
+            out = {n: eng.tensor(n, n=3).copy() for n in ("proposal_boxes", "proposal_count", "box_roi_level")}
+            out["box_pooled"] = eng.tensor("box_pooled", strip_halo=False)[:3 * 1024].copy()
+            assert ("proposal_order" in eng.tensor_names()) == want_order
+            if want_order:
+                out["order"] = eng.tensor("proposal_order", n=3).copy()
+            return dets, out
+        finally:
+            eng.close()
+    d1, t1 = run(True)
+    monkeypatch.setenv("RS_ROI_ORDER", "0")
+    d0, t0 = run(False)
+    for k in ("proposal_boxes", "proposal_count", "box_roi_level", "box_pooled"):
+        assert np.array_equal(t0[k], t1[k]), k
+    assert float(np.abs(t1["box_pooled"].astype(np.float32)).max()) > 0
+    assert all(_same_instances(a, b) for a, b in zip(d0, d1)) and all(len(d) > 0 for d in d1)
+    for i in range(3):
+        o = t1["order"][i] - i * 1024
+        assert sorted(o.tolist()) == list(range(1024)), "not a permutation of the image's slots"
+        c = int(t1["proposal_count"][i])
+        assert c > 100 and sorted(o[:c].tolist()) == list(range(c)), "valid slots first"
+        b = t1["proposal_boxes"][i][o[:c]]
+        lv = O.assign_levels(torch.from_numpy(b), 2, 5).numpy()
+        key = lv.astype(np.int64) * (1 << 26) + np.minimum(np.floor(np.maximum(b[:, 1], 0)), 8191).astype(np.int64) * (1 << 13) + \
+            np.minimum(np.floor(np.maximum(b[:, 0], 0)), 8191).astype(np.int64)
+        assert np.all(np.diff(key) >= 0), "valid slots are not sorted by (level, row, column)"
+
+
 def test_merged_level_launches_and_split_tail_change_no_bit(gpu_required, monkeypatch):
     """The FPN output convolutions of p2..p5 and the shared RPN 3x3 over p2..p6 run as one multi-map conv_deep launch each, and
     a last round that fills at most half the chip runs as 128-pixel tiles (csrc/conv_deep.hip).  Neither changes the arithmetic

@@ -72,6 +72,62 @@ def test_run_sharded_world2_gloo():
     assert calls0 == [4, 2] and calls1 == [4, 1]                              # rank 0: tiles 0-5, rank 1: tiles 6-10
 
 
+def _worker8(rank, world, port, q, n_tiles):
+    """The CLI's form of the call (make_detections.main): three stages + the streaming predictor + gather on rank 0."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    entries = [{"file_name": f"t{i}.tif", "v": i} for i in range(n_tiles)]
+    seen = []
+
+    def prepare(es):
+        return [np.full((2, 2, 3), e["v"], np.uint8) for e in es]
+
+    def stream(batches):
+        for b in batches:
+            seen.append(len(b))
+            yield [{"sum": int(t.sum())} for t in b]
+
+    def finish(es, raw):
+        return [(e["file_name"], r["sum"]) for e, r in zip(es, raw)]
+
+    out = run_sharded(entries, None, 4, rank, world, prepare=prepare, finish=finish, workers=2, predict_stream=stream)
+    dist.barrier()
+    q.put((rank, out, seen))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_tiles", [5, 0, 19])
+def test_run_sharded_world8_gloo_with_empty_shards(n_tiles):
+    """BASELINE configs[2] shape of the job (tiles sharded over the 8 GPUs of a node, rank 0 gathers and writes) with FEWER tiles
+    than ranks: ranks 5..7 of 8 get an empty block, take part in the gather all the same, and rank 0 still sees every tile exactly
+    once in tile order; also no tile at all, and a ragged 19."""
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, n_tiles)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, out, seen = q.get(timeout=180)
+        got[r] = (out, seen)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][0] == [(f"t{i}.tif", i * 12) for i in range(n_tiles)]
+    assert all(got[r][0] is None for r in range(1, world))
+    per_rank = [sum(got[r][1]) for r in range(world)]
+    assert per_rank == [shard_range(n_tiles, r, world)[1] - shard_range(n_tiles, r, world)[0] for r in range(world)]
+    if n_tiles == 5:
+        assert per_rank == [1, 1, 1, 1, 1, 0, 0, 0]
+
+
 def test_run_sharded_single_process():
     tiles = [np.full((2, 2, 3), i, np.uint8) for i in range(5)]
     out = run_sharded(tiles, _fake_predict, batch=2)

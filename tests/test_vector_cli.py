@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _area(polys):
-    return sum(sum(ring_area(r) for r in p) for p in polys)
+    return -sum(sum(ring_area(r) for r in p) for p in polys)      # rasterio's ring direction: exteriors negative, holes positive
 
 
 def test_polygonize_rect_with_hole():
@@ -26,7 +26,45 @@ def test_polygonize_rect_with_hole():
     P = mask_to_polygons(m)
     assert len(P) == 1 and len(P[0]) == 2
     assert P[0][0][0] == P[0][0][-1] and len(P[0][0]) == 5          # closed rectangle, corner vertices only
-    assert ring_area(P[0][0]) == 20 and ring_area(P[0][1]) == -2 and _area(P) == m.sum()
+    assert ring_area(P[0][0]) == -20 and ring_area(P[0][1]) == 2 and _area(P) == m.sum()
+
+
+def test_polygonize_follows_the_documented_rasterio_conventions():
+    """rasterio.features.shapes is absent (parity unpinned); what its documentation states is pinned here:
+    * ring direction and start: the example of topics/features -- one pixel at column 71, row 6 ->
+      [(71, 6), (71, 7), (72, 7), (72, 6), (71, 6)] (recalled from the documentation, like the detectron2 vectors of test_train_oracle);
+    * connectivity 4 by default: foreground pixels touching only at a corner are separate polygons (next test);
+    * an island inside a hole is its own polygon, not a ring of the enclosing one (GeoJSON polygon = exterior + its holes only);
+    * the native vectoriser (rs_vectorize_masks) returns the same vertices in the same order."""
+    m = np.zeros((10, 80), bool)
+    m[6, 71] = True
+    P = mask_to_polygons(m)
+    assert P == [[[(71.0, 6.0), (71.0, 7.0), (72.0, 7.0), (72.0, 6.0), (71.0, 6.0)]]]
+    _native_lib()
+    got = vectorize_masks_native(np.packbits(m[None], axis=2, bitorder="little"), 10, 80, 0.0, 1)
+    assert got == [[[[(71.0, 6.0), (71.0, 7.0), (72.0, 7.0), (72.0, 6.0), (71.0, 6.0)]]]]
+    # a 5x5 frame (hole 3x3) with a 1-pixel island in the middle of the hole: two polygons, the frame with ONE hole
+    f = np.zeros((7, 7), bool)
+    f[1:6, 1:6] = True
+    f[2:5, 2:5] = False
+    f[3, 3] = True
+    P = mask_to_polygons(f)
+    assert sorted(len(p) for p in P) == [1, 2]
+    frame = next(p for p in P if len(p) == 2)
+    island = next(p for p in P if len(p) == 1)
+    assert -ring_area(frame[0]) == 25 and ring_area(frame[1]) == 9 and -ring_area(island[0]) == 1
+    assert frame[0][0] == (1.0, 1.0) and frame[0][1] == (1.0, 6.0)          # exterior: top-left corner first, then down
+    # a background pixel enclosed except for a CORNER contact with the outside: with 4-connected foreground the background is
+    # 8-connected, so that pixel belongs to the outside -- no hole, ONE exterior ring that passes twice through the shared vertex
+    # (our reading of connectivity 4; GDAL's handling of such pinch points is not documented: parity unpinned)
+    g = np.ones((4, 4), bool)
+    g[1, 1] = False
+    g[0, 0] = False
+    P = mask_to_polygons(g)
+    assert len(P) == 1 and len(P[0]) == 1 and _area(P) == 14 and P[0][0].count((1.0, 1.0)) == 2
+    assert vectorize_masks_native(np.packbits(np.stack([f, np.pad(g, ((0, 3), (0, 3)))]), axis=2, bitorder="little"), 7, 7, 0.0, 1) == \
+        [[[[(float(x), float(y)) for x, y in r] for r in p] for p in mask_to_polygons(f)],
+         [[[(float(x), float(y)) for x, y in r] for r in p] for p in mask_to_polygons(np.pad(g, ((0, 3), (0, 3))))]]
 
 
 def test_polygonize_diagonal_pixels_are_separate_regions():
