@@ -264,6 +264,28 @@ def training_leg(spec, W, device, steps=12, warmup=3):
             out[f"batch{B}"] = rec
         finally:
             tr.close()
+    # the reference's arithmetic (fp32, no AMP key in its YAML): the same step on the reference-precision trainer
+    tiles, boxes, classes, polys = synthetic_scenes(8, T, T, 3, seed=4321)
+    s = 800.0 / T
+    nb = [b * np.float32(s) for b in boxes]
+    npoly = [[[p * s for p in inst] for inst in img] for img in polys]
+    tr = Trainer(spec.replace(precision="fp32"), W, (T, T, 3), batch=8, device=device, loss_scale=1.0)
+    try:
+        n32 = max(3, steps // 3)
+        for it in range(2):
+            tr.train_step(tiles, nb, classes, npoly, seed=100 + it); tr.apply_sgd(1e-5, 0.9, 1e-4)
+        tr.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(n32):
+            tr.train_step(tiles, nb, classes, npoly, seed=200 + it); tr.apply_sgd(1e-5, 0.9, 1e-4)
+        tr.sync(); torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t0) / n32
+        fl = out["batch8"]["whole_step_tflops"] * out["batch8"]["ms_per_step"] * 1e-3          # TFLOP of one batch-8 step (same layers)
+        out["reference_precision_batch8"] = {"batch": 8, "steps": n32, "ms_per_step": d32 * 1e3, "images_per_s": 8 / d32, "dtype": "f32",
+                                             "whole_step_tflops": fl / d32, "frac_of_fp32_matrix_peak": fl / d32 / F32_MFMA_PEAK_TFLOPS,
+                                             "kernels": "conv_f32_mfma_kernel (forward, input gradients), conv_wgrad_f32_kernel; v_mfma_f32_16x16x4_f32"}
+    finally:
+        tr.close()
     if own_pg:
         dist.destroy_process_group()
     return out

@@ -212,7 +212,11 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("config_file", help="YAML with a 'train_model.py' section (R:config/config_obj_detec.yaml)")
     ap.add_argument("--synthetic-weights", action="store_true", help="start from seeded synthetic weights (no checkpoint available offline)")
     ap.add_argument("--max-iter", type=int, default=0, help="override SOLVER.MAX_ITER (smoke runs)")
-    ap.add_argument("--loss-scale", type=float, default=1024.0, help="initial fp16 loss scale (halved when a step overflows)")
+    ap.add_argument("--precision", choices=["auto", "fp32", "fp16"], default="auto",
+                    help="arithmetic of the training step.  auto (default) follows the detectron2 YAML as the reference does: SOLVER.AMP.ENABLED "
+                         "false / absent (R:config/detectron2_config_3bands.yaml has no AMP key) = fp32 activations, gradients and operands on the "
+                         "fp32 matrix cores; true = fp16 operands with fp32 master weights and dynamic loss scaling (~9x faster per step)")
+    ap.add_argument("--loss-scale", type=float, default=1024.0, help="initial fp16 loss scale (halved when a step overflows); fp32 runs use 1")
     ap.add_argument("--scale-window", type=int, default=2000, help="clean steps after which the loss scale doubles (0 = never)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log-period", type=int, default=20)
@@ -296,6 +300,11 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     else:
         raise SystemExit("model_weights needs pth_file or model_zoo_checkpoint_url (or --synthetic-weights)")
 
+    precision = args.precision if args.precision != "auto" else ("fp16" if sv["amp"] else "fp32")
+    spec = spec.replace(precision=precision)
+    if precision == "fp32":
+        args.loss_scale, args.scale_window = 1.0, 0     # nothing to protect from underflow; the overflow check stays on (it also catches a diverged run)
+    log.info("precision: %s (%s)", precision, "--precision" if args.precision != "auto" else f"SOLVER.AMP.ENABLED {sv['amp']}")
     from .engine import MultiScaleTrainer      # fails loudly without librs_engine.so / a HIP device
     from .make_detections import read_tile
     first = read_tile(recs[0]["file_name"])
