@@ -193,7 +193,7 @@ def reference_precision_leg(spec, W, tiles, B, steps, warmup, device):
         e32.close()
 
 
-def training_leg(spec, W, device, steps=12, warmup=3):
+def training_leg(spec, W, device, steps=12, warmup=3, legs=("b8", "b1", "fp32")):
     """One training step (BASELINE configs[4]: 2-class fine-tune, YAML samplers: 256 anchors / 1024 RoIs per image, 2000/1000 train
     proposals) on 1 GPU: forward + five losses + backward + SGD + refold, host-side mask-target rasterisation included; batch 8
     (the YAML's IMS_PER_BATCH on one GPU) and batch 1 (its per-GPU share on 8 GPUs).  Per-stage HIP events give the share and rate of
@@ -217,7 +217,7 @@ def training_leg(spec, W, device, steps=12, warmup=3):
             own_pg = True
         except Exception as ex:                                  # the figures without a collective are still valid
             log(f"training leg: no RCCL group ({ex})")
-    for B in (8, 1):
+    for B in [b for b in (8, 1) if f"b{b}" in legs]:
         tiles, boxes, classes, polys = synthetic_scenes(B, T, T, 3, seed=4321)
         s = 800.0 / T
         nb = [b * np.float32(s) for b in boxes]
@@ -245,9 +245,16 @@ def training_leg(spec, W, device, steps=12, warmup=3):
             run(4, False)
             st = [x for x in tr.stage_times() if x["calls"]]
             tr.set_profiling(False)
+            # the mask head's GEMMs are bounded by a device-side entry count (the sampled foreground RoIs); their stage FLOP figure is
+            # the 256-entries-per-image capacity: scale it to the entries of the last step
+            entries = int(tr.tensor("mask_total")[0]) if spec.mask_on else 0
+            mask_fill = entries / float(B * 256)
+            rec["mask_head_entries_last_step"] = entries
             groups = {}
             for x in st:
                 nm = x["name"]
+                if nm.startswith("mask.") or nm.startswith("bwd.mask."):
+                    x = dict(x, flops=x["flops"] * mask_fill)
                 g = ("weight gradients (conv_wgrad_kernel, side stream)" if nm.endswith(".w") else
                      "input gradients (conv_igemm / conv_deep on the transposed weights)" if nm.endswith(".x") else
                      "forward GEMMs" if x["flops"] > 0 else "RoIAlign forward / backward" if "roi_align" in nm else "other (losses, sampling, NMS, bias gradients, pooling)")
@@ -264,6 +271,10 @@ def training_leg(spec, W, device, steps=12, warmup=3):
             out[f"batch{B}"] = rec
         finally:
             tr.close()
+    if "fp32" not in legs or "batch8" not in out:
+        if own_pg:
+            dist.destroy_process_group()
+        return out
     # the reference's arithmetic (fp32, no AMP key in its YAML): the same step on the reference-precision trainer
     tiles, boxes, classes, polys = synthetic_scenes(8, T, T, 3, seed=4321)
     s = 800.0 / T
@@ -316,6 +327,7 @@ def main():
     ap.add_argument("--no-trained-leg", action="store_true", help="skip the trained-like leg of the default run")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step leg of the default run")
     ap.add_argument("--train", action="store_true", help="ONLY the training-step leg, as its own JSON line (BASELINE configs[4])")
+    ap.add_argument("--train-legs", default="b8,b1,fp32", help="with --train: which trainers to time (b8 = fp16 batch 8, b1 = fp16 one image, fp32 = reference precision batch 8); profiler runs take b8 alone")
     ap.add_argument("--sustain-seconds", type=float, default=5.0,
                     help="after the K timed steps, keep stepping for this long and report `sustained_tiles_per_s` (clocks settle "
                          "after a few seconds of load); 0 = skip (profiler runs)")
@@ -355,7 +367,8 @@ def main():
         if world != 1:
             raise SystemExit("--train measures one GPU (the 8-GPU data-parallel run is the driver's)")
         with stdout_to_stderr():
-            tl = training_leg(spec, synthetic_weights(spec, seed=0), local_rank, steps=args.steps, warmup=args.warmup)
+            tl = training_leg(spec, synthetic_weights(spec, seed=0), local_rank, steps=args.steps, warmup=args.warmup,
+                              legs=tuple(["b8"] + [x for x in args.train_legs.split(",") if x]))
         b8 = tl["batch8"]
         print(json.dumps({"metric": "train_images_per_sec_512x512x3", "value": b8["images_per_s"], "unit": "images/s", "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": b8["ms_per_step"], "higher_is_better": True,
