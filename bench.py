@@ -126,7 +126,7 @@ def parity_object(got, ref, what):
     the tiles, both directions, with the 95 % Wilson lower bound of each matched fraction."""
     from proj_roadsurf_amd.matching import match_detections, wilson_lower
     tot = {"fw_n": 0, "fw_m": 0, "bw_n": 0, "bw_m": 0}
-    dscore, inter_u, miou = 0.0, [], 1.0
+    dscore, miou = 0.0, 1.0
     agg = []
     for g, r in zip(as_sets(got), as_sets(ref)):
         fw, bw = match_detections(r, g), match_detections(g, r)
@@ -193,6 +193,29 @@ def reference_precision_leg(spec, W, tiles, B, steps, warmup, device):
         e32.close()
 
 
+def stage_groups_of(tr, spec, B, run4):
+    """Per-stage HIP events of four training steps grouped into weight gradients / input gradients / forward GEMMs / RoIAlign / other,
+    with the mask head's GEMM FLOP scaled from its 256-entries-per-image capacity to the entries of the last step."""
+    tr.set_profiling(True)
+    run4()
+    st = [x for x in tr.stage_times() if x["calls"]]
+    tr.set_profiling(False)
+    entries = int(tr.tensor("mask_total")[0]) if spec.mask_on else 0
+    mask_fill = entries / float(B * 256)
+    groups = {}
+    for x in st:
+        nm = x["name"]
+        if nm.startswith("mask.") or nm.startswith("bwd.mask."):
+            x = dict(x, flops=x["flops"] * mask_fill)
+        g = ("weight gradients (conv_wgrad kernels, side stream)" if nm.endswith(".w") else
+             "input gradients (the forward conv kernels on the transposed weights)" if nm.endswith(".x") else
+             "forward GEMMs" if x["flops"] > 0 else "RoIAlign forward / backward" if "roi_align" in nm else "other (losses, sampling, NMS, bias gradients, pooling)")
+        a = groups.setdefault(g, {"ms_per_step": 0.0, "flops_per_step": 0.0})
+        a["ms_per_step"] += x["ms_total"] / x["calls"]
+        a["flops_per_step"] += x["flops"]
+    return groups, entries
+
+
 def training_leg(spec, W, device, steps=12, warmup=3, legs=("b8", "b1", "fp32")):
     """One training step (BASELINE configs[4]: 2-class fine-tune, YAML samplers: 256 anchors / 1024 RoIs per image, 2000/1000 train
     proposals) on 1 GPU: forward + five losses + backward + SGD + refold, host-side mask-target rasterisation included; batch 8
@@ -241,26 +264,8 @@ def training_leg(spec, W, device, steps=12, warmup=3, legs=("b8", "b1", "fp32"))
                 rec["ms_per_step_with_bucketed_allreduce_1rank"] = dta * 1e3
                 rec["exposed_allreduce_ms_1rank"] = (dta - dt) * 1e3
                 tr.allreduce_gradients = _orig
-            tr.set_profiling(True)
-            run(4, False)
-            st = [x for x in tr.stage_times() if x["calls"]]
-            tr.set_profiling(False)
-            # the mask head's GEMMs are bounded by a device-side entry count (the sampled foreground RoIs); their stage FLOP figure is
-            # the 256-entries-per-image capacity: scale it to the entries of the last step
-            entries = int(tr.tensor("mask_total")[0]) if spec.mask_on else 0
-            mask_fill = entries / float(B * 256)
+            groups, entries = stage_groups_of(tr, spec, B, lambda: run(4, False))
             rec["mask_head_entries_last_step"] = entries
-            groups = {}
-            for x in st:
-                nm = x["name"]
-                if nm.startswith("mask.") or nm.startswith("bwd.mask."):
-                    x = dict(x, flops=x["flops"] * mask_fill)
-                g = ("weight gradients (conv_wgrad_kernel, side stream)" if nm.endswith(".w") else
-                     "input gradients (conv_igemm / conv_deep on the transposed weights)" if nm.endswith(".x") else
-                     "forward GEMMs" if x["flops"] > 0 else "RoIAlign forward / backward" if "roi_align" in nm else "other (losses, sampling, NMS, bias gradients, pooling)")
-                a = groups.setdefault(g, {"ms_per_step": 0.0, "flops_per_step": 0.0})
-                a["ms_per_step"] += x["ms_total"] / x["calls"]
-                a["flops_per_step"] += x["flops"]
             for g, a in groups.items():
                 a["tflops"] = a["flops_per_step"] / (a["ms_per_step"] * 1e-3) / 1e12 if a["ms_per_step"] and a["flops_per_step"] else None
                 a["frac_of_mfma_peak"] = a["tflops"] / MFMA_PEAK_TFLOPS if a["tflops"] else None
@@ -291,10 +296,19 @@ def training_leg(spec, W, device, steps=12, warmup=3, legs=("b8", "b1", "fp32"))
             tr.train_step(tiles, nb, classes, npoly, seed=200 + it); tr.apply_sgd(1e-5, 0.9, 1e-4)
         tr.sync(); torch.cuda.synchronize()
         d32 = (time.perf_counter() - t0) / n32
+        def run4():
+            for it in range(4):
+                tr.train_step(tiles, nb, classes, npoly, seed=300 + it); tr.apply_sgd(1e-5, 0.9, 1e-4)
+            tr.sync()
+        g32, _ = stage_groups_of(tr, spec, 8, run4)
+        for g, a in g32.items():
+            a["tflops"] = a["flops_per_step"] / (a["ms_per_step"] * 1e-3) / 1e12 if a["ms_per_step"] and a["flops_per_step"] else None
+            a["frac_of_fp32_matrix_peak"] = a["tflops"] / F32_MFMA_PEAK_TFLOPS if a["tflops"] else None
         fl = out["batch8"]["whole_step_tflops"] * out["batch8"]["ms_per_step"] * 1e-3          # TFLOP of one batch-8 step (same layers)
         out["reference_precision_batch8"] = {"batch": 8, "steps": n32, "ms_per_step": d32 * 1e3, "images_per_s": 8 / d32, "dtype": "f32",
                                              "whole_step_tflops": fl / d32, "frac_of_fp32_matrix_peak": fl / d32 / F32_MFMA_PEAK_TFLOPS,
-                                             "kernels": "conv_f32_mfma_kernel (forward, input gradients), conv_wgrad_f32_kernel; v_mfma_f32_16x16x4_f32"}
+                                             "kernels": "conv_f32_mfma_kernel (forward, input gradients), conv_wgrad_f32_kernel; v_mfma_f32_16x16x4_f32",
+                                             "stage_groups": g32}
     finally:
         tr.close()
     if own_pg:

@@ -324,7 +324,11 @@ int rs_op_fold_weights(const float* w32, const float* scale, void* w_fwd, void* 
  * (torch.optim.SGD step on every trainable tensor + refold of the fp16 operands): what detectron2 reaches through autograd +
  * SimpleTrainer.run_step
  * ([EXT d2: engine/train_loop.py]).  Tensors: "d:<forward tensor>" activation gradients (fp16, times loss_scale),
- * "g:<layer>.w|.b" gradients and "m:<layer>.w|.b" master weights (fp32, forward layout). */
+ * "g:<layer>.w|.b" gradients and "m:<layer>.w|.b" master weights (fp32, forward layout).
+ * rs_spec.precision selects the arithmetic of the whole step: 1 = REFERENCE PRECISION -- activations, activation gradients and GEMM
+ * operands fp32 on v_mfma_f32_16x16x4_f32 (what detectron2's SimpleTrainer computes for the reference's YAML, which has no SOLVER.AMP
+ * key, R:config/detectron2_config_3bands.yaml:268-305; "d:" tensors are then fp32, blob packed with the `.w32` operands, loss_scale 1);
+ * 0 = fp16 operands with fp32 master weights and a loss scale (AMPTrainer's place). */
 typedef struct rs_trainer rs_trainer;
 int rs_trainer_create(const rs_spec* spec, const void* weights, size_t nbytes, int device_ordinal, int batch, int tile_h,
                       int tile_w, int tile_c, float loss_scale, rs_trainer** out);
