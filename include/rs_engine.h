@@ -252,6 +252,10 @@ int rs_op_conv2d_dgrad(const void* dy, const void* w_t, void* dx, const void* re
 int rs_op_conv2d_wgrad(const void* dy, const void* in, float* grad, const float* scale, int n, int hi, int wi, int cin,
                        int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits,
                        void* stream);
+/* the same from fp32 operands (dy, x point to float): the reference-precision trainer's conv_wgrad_f32_kernel */
+int rs_op_conv2d_wgrad_f32(const void* dy, const void* in, float* grad, const float* scale, int n, int hi, int wi, int cin,
+                       int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits,
+                       void* stream);
 
 /* Greedy NMS over `segments` independent lists of up to 1024 boxes in priority order
  * (torchvision.ops.nms semantics: IoU > thresh suppresses). keep: [segments][cap] 0/1. */

@@ -301,19 +301,68 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradParams p
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int s = s0; s < s1; ++s) {
-    const int m = s * 4 + lq;
-    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (m < M) {
-      const int xx = m % p.Wo, tt = m / p.Wo, y = tt % p.Ho, n = tt / p.Ho;
-      if (cok) a = *(const f32x4*)(dy + ((long long)(n * p.dy_Hp + y + p.dy_pad) * p.dy_Wp + xx + p.dy_pad) * p.dy_Cs + co0 + 4 * lc);
-      b = *(const f32x4*)(x + ((long long)(n * p.in_Hp + y * p.stride + kh + p.in_off) * p.in_Wp + xx * p.stride + kw + p.in_off) * p.in_Cs + ci0 + 4 * lc);
-    }
+  // Pixel m = 4 s + lq of this lane, advanced by 4 per step: (xx, row) = (x, n * Ho + y).  The loop body is STRAIGHT-LINE code: loads
+  // from clamped (always valid) addresses, the tail / channel masks applied by selects at the point of use -- with a branch around a
+  // load hipcc waits vmcnt(0) before the first MFMA of every iteration (seen in the ISA) and the prefetch below overlaps nothing.
+  int m = s0 * 4 + lq;
+  int xx = m % p.Wo, y, n;
+  { const int row = m / p.Wo; y = row % p.Ho; n = row / p.Ho; }
+  const int q4 = 4 / p.Wo, r4 = 4 - q4 * p.Wo;          // a step advances the pixel by 4 = q4 rows + r4 columns (launcher: q4 < Ho)
+  const int last_row = (M - 1) / p.Wo, last_x = (M - 1) - last_row * p.Wo, last_n = last_row / p.Ho, last_y = last_row - last_n * p.Ho;
+  const int coff = cok ? co0 + 4 * lc : 0;
+  auto load = [&](f32x4& a, f32x4& b, bool& ok) {
+    ok = m < M;
+    const int yc = ok ? y : last_y, nc = ok ? n : last_n, xc = ok ? xx : last_x;
+    a = *(const f32x4*)(dy + ((long long)(nc * p.dy_Hp + yc + p.dy_pad) * p.dy_Wp + xc + p.dy_pad) * p.dy_Cs + coff);
+    b = *(const f32x4*)(x + ((long long)(nc * p.in_Hp + yc * p.stride + kh + p.in_off) * p.in_Wp + xc * p.stride + kw + p.in_off) * p.in_Cs + ci0 + 4 * lc);
+    m += 4;
+    xx += r4;
+    const bool wx = xx >= p.Wo;
+    xx = wx ? xx - p.Wo : xx;
+    y += q4 + (wx ? 1 : 0);
+    const bool wy = y >= p.Ho;
+    y = wy ? y - p.Ho : y;
+    n += wy ? 1 : 0;
+  };
+  auto mfma16 = [&](f32x4 a, f32x4 b, bool ok) {
+    const bool oka = ok && cok;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { a[t] = oka ? a[t] : 0.f; b[t] = ok ? b[t] : 0.f; }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[j], acc[t][j], 0, 0, 0);
+  };
+  // Two steps per half iteration: the four loads of the NEXT pair are in flight under the 32 MFMAs of this one.  The two pairs
+  // ping-pong between two register sets WITHOUT copies (a copy of a just-loaded register is a use: it would wait for the load at once),
+  // and a sched_barrier pins the issue order (hipcc otherwise sinks the loads below the MFMAs).
+  f32x4 a0, b0, a1, b1, a2, b2, a3, b3;
+  bool k0 = false, k1 = false, k2 = false, k3 = false;
+  int s = s0;
+  if (s + 1 < s1) {
+    load(a0, b0, k0);
+    load(a1, b1, k1);
+    for (; s + 5 < s1; s += 4) {             // steps s, s+1 are loaded; s+2 .. s+5 exist
+      load(a2, b2, k2);
+      load(a3, b3, k3);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(a0, b0, k0);
+      mfma16(a1, b1, k1);
+      __builtin_amdgcn_sched_barrier(0);
+      load(a0, b0, k0);
+      load(a1, b1, k1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(a2, b2, k2);
+      mfma16(a3, b3, k3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma16(a0, b0, k0);
+    mfma16(a1, b1, k1);
+    s += 2;
+  }
+  for (; s < s1; ++s) {                      // at most four steps left
+    load(a0, b0, k0);
+    mfma16(a0, b0, k0);
   }
   float* out = p.partial + (long long)blockIdx.z * p.Cout * p.Kpad;
 #pragma unroll
@@ -344,6 +393,17 @@ static inline int wgrad_cb(const WgradParams& p) {
 }
 
 int wgrad_splits(const WgradParams& p) {
+  if (p.f32) {
+    // conv_wgrad_f32_kernel: a workgroup is 64 channels x 4 K-column tiles of 64, its waves are independent and hide their own load
+    // latency only through the waves beside them -- aim at ~5 waves per SIMD (1280 workgroups), at least 8 four-pixel steps per split
+    const long long out_tiles = (long long)cdiv(p.Cout, 64) * cdiv(p.KH * p.KW * (p.Cin >> 6), 4);
+    const int steps = cdiv(p.M, 4);
+    long long s = cdiv(1280, out_tiles);
+    if (s > steps / 8) s = steps / 8;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+  }
   const int cb = wgrad_cb(p);
   const long long out_tiles = (long long)cdiv(p.Cout, cb * 64) * cdiv(p.KH * p.KW * (p.Cin >> 6), 2);
   const int steps = cdiv(p.M, BK);
@@ -364,6 +424,7 @@ int launch_conv_wgrad(const WgradParams& p, hipStream_t stream) {
     const int units = p.KH * p.KW * (p.Cin >> 6);
     RS_CHECK(p.M > 0 && p.Cin % 64 == 0 && p.dy_Cs % 4 == 0 && p.in_Cs % 4 == 0 && p.Cout >= 1 && units * 64 == p.Kpad && p.splits >= 1, RS_ERR_ARG,
              "wgrad (fp32): Cin %d must be a multiple of 64 and K = %d unpadded", p.Cin, p.Kpad);
+    RS_CHECK(4 / p.Wo + 1 <= p.Ho, RS_ERR_UNSUPPORTED, "wgrad (fp32): map %d x %d too small for the 4-pixel step", p.Ho, p.Wo);
     dim3 grid(cdiv(p.Cout, 64), cdiv(units, 4), p.splits);
     hipLaunchKernelGGL(conv_wgrad_f32_kernel, grid, dim3(256), 0, stream, p);
     RS_HIP(hipGetLastError());

@@ -1628,8 +1628,19 @@ int rs_op_conv2d_dgrad(const void* dy, const void* w_t, void* dx, const void* re
   return rc;
 }
 
+static int op_conv2d_wgrad(const void* dy, const void* x, float* grad, const float* scale, int n, int hi, int wi, int cin, int in_halo,
+                           int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits, void* stream, int f32);
 int rs_op_conv2d_wgrad(const void* dy, const void* x, float* grad, const float* scale, int n, int hi, int wi, int cin, int in_halo,
                        int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits, void* stream) {
+  return op_conv2d_wgrad(dy, x, grad, scale, n, hi, wi, cin, in_halo, kh, kw, stride, pad, cout, kpad, dy_halo, splits, stream, 0);
+}
+// the same weight gradient from fp32 operands (reference-precision trainer: conv_wgrad_f32_kernel)
+int rs_op_conv2d_wgrad_f32(const void* dy, const void* x, float* grad, const float* scale, int n, int hi, int wi, int cin, int in_halo,
+                           int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits, void* stream) {
+  return op_conv2d_wgrad(dy, x, grad, scale, n, hi, wi, cin, in_halo, kh, kw, stride, pad, cout, kpad, dy_halo, splits, stream, 1);
+}
+static int op_conv2d_wgrad(const void* dy, const void* x, float* grad, const float* scale, int n, int hi, int wi, int cin, int in_halo,
+                           int kh, int kw, int stride, int pad, int cout, int kpad, int dy_halo, int splits, void* stream, int f32) {
   RS_CHECK(dy && x && grad, RS_ERR_ARG, "null argument");
   RS_CHECK(in_halo >= pad, RS_ERR_ARG, "input halo %d < pad %d", in_halo, pad);
   const int ho = (hi + 2 * pad - kh) / stride + 1, wo = (wi + 2 * pad - kw) / stride + 1;
@@ -1640,6 +1651,7 @@ int rs_op_conv2d_wgrad(const void* dy, const void* x, float* grad, const float* 
   p.dy_Hp = ho + 2 * dy_halo; p.dy_Wp = wo + 2 * dy_halo; p.dy_Cs = cout; p.dy_pad = dy_halo;
   p.in_Hp = hi + 2 * in_halo; p.in_Wp = wi + 2 * in_halo; p.in_Cs = cin; p.in_off = in_halo - pad;
   p.stride = stride; p.KH = kh; p.KW = kw; p.Cin = cin; p.Cout = cout; p.Kpad = kpad;
+  p.f32 = f32;
   p.splits = splits > 0 ? splits : wgrad_splits(p);
   hipStream_t s = (hipStream_t)stream;
   void *partial = nullptr, *zeros = nullptr;

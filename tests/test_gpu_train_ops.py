@@ -25,15 +25,29 @@ def _r16(t):
     return t.half().float()
 
 
-def run_wgrad(x, dy, k, stride, pad, scale=None, splits=0, in_halo=None, dy_halo=1):
-    """x (N,Cin,H,W), dy (N,Cout,Ho,Wo) fp32 fp16-representable -> dW (Cout,Cin,k,k) fp32 from the GPU."""
+def run_wgrad(x, dy, k, stride, pad, scale=None, splits=0, in_halo=None, dy_halo=1, f32=False):
+    """x (N,Cin,H,W), dy (N,Cout,Ho,Wo) fp32 (fp16-representable unless f32) -> dW (Cout,Cin,k,k) fp32 from the GPU.
+    f32: operands stay fp32 and the reference-precision kernel runs (rs_op_conv2d_wgrad_f32)."""
     lib = load_library()
     dev = torch.device("cuda:0")
     n, cin, hi, wi = x.shape
     cout = dy.shape[1]
     in_halo = pad if in_halo is None else in_halo
-    xd = _halo(x.permute(0, 2, 3, 1).half().contiguous(), in_halo).to(dev)
-    dyd = _halo(dy.permute(0, 2, 3, 1).half().contiguous(), dy_halo).to(dev)
+    dt = torch.float32 if f32 else torch.float16
+    xd = _halo(x.permute(0, 2, 3, 1).to(dt).contiguous(), in_halo).to(dev)
+    dyd = _halo(dy.permute(0, 2, 3, 1).to(dt).contiguous(), dy_halo).to(dev)
+    if f32:
+        kpad = k * k * cin
+        gd = torch.full((cout, kpad), float("nan"), dtype=torch.float32, device=dev)
+        sd = scale.to(dev) if scale is not None else None
+        lib.rs_op_conv2d_wgrad_f32.argtypes = lib.rs_op_conv2d_wgrad.argtypes
+        torch.cuda.synchronize()
+        rc = lib.rs_op_conv2d_wgrad_f32(C.c_void_p(dyd.data_ptr()), C.c_void_p(xd.data_ptr()), C.c_void_p(gd.data_ptr()),
+                                        C.c_void_p(sd.data_ptr()) if sd is not None else None,
+                                        n, hi, wi, cin, in_halo, k, k, stride, pad, cout, kpad, dy_halo, splits, None)
+        _check(lib, rc, "rs_op_conv2d_wgrad_f32")
+        torch.cuda.synchronize()
+        return gd.cpu().reshape(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
     kpad = (k * k * cin + 63) // 64 * 64
     gd = torch.full((cout, kpad), float("nan"), dtype=torch.float32, device=dev)
     sd = scale.to(dev) if scale is not None else None
@@ -74,6 +88,31 @@ def test_conv_wgrad_matches_autograd(gpu_required, cin, cout, k, stride, hw, n, 
     got = run_wgrad(x, dy, k, stride, pad, splits=splits, in_halo=max(pad, 1))
     err = float((got - ref).abs().max())
     assert err <= 2e-3 * max(1.0, float(ref.abs().max())), f"max err {err}, ref max {float(ref.abs().max())}"
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw,n,splits", [
+    (256, 256, 3, 1, (25, 27), 2, 0),      # FPN output / RPN / mask-head 3x3
+    (64, 128, 1, 1, (19, 23), 3, 1),       # one K unit: three of the workgroup's four waves idle; single split
+    (256, 128, 1, 2, (26, 30), 2, 0),      # strided 1x1 (res3.0.conv1 shape)
+    (128, 128, 3, 1, (14, 14), 5, 3),      # pixel count not a multiple of the 4-pixel step
+    (512, 16, 1, 1, (13, 13), 2, 0),       # 16 output rows (the fused heads): three quarters of the channel tile masked
+])
+def test_conv_wgrad_f32_matches_autograd(gpu_required, cin, cout, k, stride, hw, n, splits):
+    """Reference-precision weight gradient (conv_wgrad_f32_kernel: fp32 operands on v_mfma_f32_16x16x4_f32) against fp32 autograd:
+    1e-5 of the largest entry (summation order only)."""
+    g = torch.Generator().manual_seed(cin + cout + k + 1)
+    h, w = hw
+    pad = k // 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = torch.randn(n, cout, ho, wo, generator=g) * 0.1
+    scale = torch.rand(cout, generator=g) + 0.5 if k == 3 else None
+    ref = ref_wgrad(x, dy, k, stride, pad)
+    if scale is not None:
+        ref = ref * scale[:, None, None, None]
+    got = run_wgrad(x, dy, k, stride, pad, scale=scale, splits=splits, in_halo=max(pad, 1), f32=True)
+    err = float((got - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), f"max err {err}, ref max {float(ref.abs().max())}"
 
 
 def test_conv_wgrad_scale_and_fc_shape(gpu_required):
