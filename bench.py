@@ -495,32 +495,40 @@ def main():
         log(f"reference precision: {ref['tiles_per_s']:.0f} tiles/s; parity {par['matched_fw']:.3f} / {par['matched_bw']:.3f} of {par['n_fw']}")
     trained = None
     if rank == 0 and world == 1 and args.weights == "random" and W_tr is not None:
-        Ht = measure(W_tr, tiles_tr, False)
-        trained = {"workload": f"detector trained here ({args.train_steps} SGD steps on synthetic scenes, two classes), batch {B} of fresh {T}x{T}x{C_in} scenes with 4-12 objects",
-                   "tiles_per_s": B * args.steps / Ht["dt"], "ms_per_step": Ht["dt"] / args.steps * 1e3, "steps": args.steps,
-                   "proposals_per_tile": Ht["nprop"], "detections_per_tile": Ht["ndet"], "pcie_inclusive_tiles_per_s": Ht["pcie"]}
-        if not args.no_ref:
-            rt, d32t = reference_precision_leg(spec, W_tr, tiles_tr, B, max(3, args.steps // 4), 1, local_rank)
-            trained["reference_precision_tiles_per_s"] = rt["tiles_per_s"]
-            # parity over a pool that makes the >= 0.98 bar decidable: 12 batches of fresh scenes (~1500 detections), both engines on the GPU
-            from proj_roadsurf_amd.engine import Engine
-            got, want = list(Ht["dets"]), list(d32t)
-            e16 = Engine(spec, W_tr, (T, T, C_in), max_batch=B, device=local_rank)
-            e32 = Engine(spec.replace(precision="fp32"), W_tr, (T, T, C_in), max_batch=B, device=local_rank)
-            try:
-                for k in range(1, 12):
-                    more = synthetic_scenes(B, T, T, C_in, seed=555000 + 7919 * k, objects=(4, 12))[0]
-                    got += e16.infer(more)
-                    want += e32.infer(more)
-            finally:
-                e16.close(); e32.close()
-            trained["parity"] = parity_object(got, want, f"fp16-operand engine vs reference-precision engine on {len(got)} trained-like scenes, GPU vs GPU")
-            log(f"trained-like: {trained['tiles_per_s']:.0f} tiles/s; parity {trained['parity']['matched_fw']:.4f} / {trained['parity']['matched_bw']:.4f} of {trained['parity']['n_fw']}, "
-                f"Wilson lower {trained['parity']['wilson95_lower_fw']:.4f}")
+        try:
+            Ht = measure(W_tr, tiles_tr, False)
+            trained = {"workload": f"detector trained here ({args.train_steps} SGD steps on synthetic scenes, two classes), batch {B} of fresh {T}x{T}x{C_in} scenes with 4-12 objects",
+                       "tiles_per_s": B * args.steps / Ht["dt"], "ms_per_step": Ht["dt"] / args.steps * 1e3, "steps": args.steps,
+                       "proposals_per_tile": Ht["nprop"], "detections_per_tile": Ht["ndet"], "pcie_inclusive_tiles_per_s": Ht["pcie"]}
+            if not args.no_ref:
+                rt, d32t = reference_precision_leg(spec, W_tr, tiles_tr, B, max(3, args.steps // 4), 1, local_rank)
+                trained["reference_precision_tiles_per_s"] = rt["tiles_per_s"]
+                # parity over a pool that makes the >= 0.98 bar decidable: 12 batches of fresh scenes (~1500 detections), both engines on the GPU
+                from proj_roadsurf_amd.engine import Engine
+                got, want = list(Ht["dets"]), list(d32t)
+                e16 = Engine(spec, W_tr, (T, T, C_in), max_batch=B, device=local_rank)
+                e32 = Engine(spec.replace(precision="fp32"), W_tr, (T, T, C_in), max_batch=B, device=local_rank)
+                try:
+                    for k in range(1, 12):
+                        more = synthetic_scenes(B, T, T, C_in, seed=555000 + 7919 * k, objects=(4, 12))[0]
+                        got += e16.infer(more)
+                        want += e32.infer(more)
+                finally:
+                    e16.close(); e32.close()
+                trained["parity"] = parity_object(got, want, f"fp16-operand engine vs reference-precision engine on {len(got)} trained-like scenes, GPU vs GPU")
+                log(f"trained-like: {trained['tiles_per_s']:.0f} tiles/s; parity {trained['parity']['matched_fw']:.4f} / {trained['parity']['matched_bw']:.4f} of {trained['parity']['n_fw']}, "
+                    f"Wilson lower {trained['parity']['wilson95_lower_fw']:.4f}")
+        except Exception as ex:
+            trained = {"error": f"{type(ex).__name__}: {ex}"}
+            log(f"trained-like leg failed: {ex}")
     training = None
     if rank == 0 and world == 1 and not args.no_train_leg and C_in == 3 and T == 512:
-        with stdout_to_stderr():
-            training = training_leg(spec, W_rand, local_rank)
+        try:                                     # an optional leg never costs the headline: its failure is reported inside the line
+            with stdout_to_stderr():
+                training = training_leg(spec, W_rand, local_rank)
+        except Exception as ex:
+            training = {"error": f"{type(ex).__name__}: {ex}"}
+            log(f"training leg failed: {ex}")
 
     if rank == 0:
         value = world * B * args.steps / dt
