@@ -586,6 +586,34 @@ def test_twenty_sgd_steps_side_by_side_with_the_oracle(gpu_required):
     assert abs(np.mean(curve16) - np.mean(curve32)) <= 0.05 * np.mean(curve32), (np.mean(curve16), np.mean(curve32))
 
 
+def test_trainer_stage_profiling(gpu_required):
+    """rs_trainer_set_profiling / rs_trainer_stage_info (what bench.py --train groups): every stage of a step is timed once per step,
+    GEMM stages carry their algorithmic FLOP, weight gradients are flagged as side-stream work, and nothing accumulates when off."""
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    Wn = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(2, 256, 256, 3, seed=777)
+    gt_boxes, gt_classes, polys = _two_image_problem()
+    tr = Trainer(spec, Wn, (256, 256, 3), batch=2, loss_scale=128.0)
+    try:
+        tr.set_sampling(256, 0.5, 64, 0.25)
+        _engine_step(tr, tiles, gt_boxes, gt_classes, polys, seed=1)          # not profiled
+        tr.set_profiling(True)
+        for it in range(3):
+            _engine_step(tr, tiles, gt_boxes, gt_classes, polys, seed=2 + it)
+        st = {x["name"]: x for x in tr.stage_times()}
+        tr.set_profiling(False)
+        assert st["preprocess"]["calls"] == 3 and st["bwd.res4.2.conv2.w"]["calls"] == 3 and st["box.loss"]["calls"] == 3
+        assert all(x["ms_total"] > 0 for x in st.values() if x["calls"])
+        assert st["bwd.res4.2.conv2.w"]["side"] and not st["bwd.res4.2.conv2.x"]["side"]
+        want = 2.0 * 2 * 20 * 20 * 9 * 256 * 256                              # res4 conv2 at 320x320: 20x20 pixels, batch 2
+        assert st["bwd.res4.2.conv2.w"]["flops"] == want and st["bwd.res4.2.conv2.x"]["flops"] == want and st["res4.2.conv2"]["flops"] == want
+        assert st["rpn.loss2"]["flops"] == 0
+        _engine_step(tr, tiles, gt_boxes, gt_classes, polys, seed=9)          # off again: nothing accumulates
+        assert {x["name"]: x["calls"] for x in tr.stage_times()}["preprocess"] == 3
+    finally:
+        tr.close()
+
+
 def _tiny_training_workdir(tmp_path):
     """Four 128x128 synthetic tiles with two boxes each, COCO JSON, a small detectron2 YAML and the reference's two YAML sections
     (R:config/config_obj_detec.yaml:62-90) -- train_model.py section UNCHANGED in its model_weights key (zoo name only)."""
