@@ -317,7 +317,8 @@ def test_fp16_meets_the_stated_tolerance_on_a_trained_like_detector(gpu_required
     Wilson lower bound of it >= 0.98; on every scene |dscore| <= 0.02 and mask IoU >= 0.95 of the matched pairs.
     Measured (round 3, profiles/r03/parity/): 99.3-99.7 % matched, lower bound 0.989+; the residual misses are near-ties of two boxes
     of ONE object in the final NMS (scores 1e-4 apart, IoU 0.7-0.9 between them) which the fp16 trunk's 4e-4 feature noise flips --
-    tools/parity/bisect_stages.py finds them already in "oracle downstream of the engine's FPN maps" and none added by any later stage."""
+    tools/parity/bisect_stages.py finds 11 of 15 such scenes (8 seeds) already in "oracle downstream of the engine's FPN maps", 4 created
+    by the RPN's 3x3 convolution, none by any later stage."""
     from proj_roadsurf_amd.matching import wilson_lower
     from proj_roadsurf_amd.synthetic import synthetic_scenes, train_trained_like
     from tests.util import box_iou
