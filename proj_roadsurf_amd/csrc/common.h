@@ -46,6 +46,9 @@ struct RsDebug {
   int conv_tuned = 1;             // RS_CONV_TUNED            0: first-round tile rule (128x128 / 256x64 only)
   int conv_deep = 1;              // RS_CONV_DEEP             0: conv_igemm 256x256 instead of conv_deep
   int conv_wide_px = 128;         // RS_CONV_WIDE_PX          pixels of the all-256-channel tile of the HBM-bound 1x1 layers: 128 (variant 14) or 64 (10)
+  int wreg_dbg = 0;               // RS_WREG_DBG              conv_wreg timing ablations (1: no stores, 2: no MFMAs ... results wrong)
+  int wreg_waves = 4;             // RS_WREG_WAVES            4: one wave per SIMD, 8: two (32 pixels of the tile each)
+  int conv_wreg = 1;              // RS_CONV_WREG             0: never the persistent register-weight kernel (variant 22, conv_wreg.hip)
   int stem_small_tile = 1;        // RS_STEM_SMALL_TILE       0: 256x64 stem tile
   int deep_dbg = 0;               // RS_DEEP_DBG              -DRS_DEEP_CEILING builds only
   int deconv_variant = 14;        // RS_DECONV_VARIANT        tile of the fused deconv + predictor: 128x256 (14), 64x256 (10) or 128x128 (0)
@@ -233,4 +236,7 @@ int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int H
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu = 0);   // ref_f32.hip: fp32 MFMA (or the VALU cross-check)
 int launch_conv_deep(const ConvParams& p, hipStream_t stream, int tile_px = 256);
+int rs_device_cu_count();                                        // CUs of the current device (256 without one), conv_deep.hip
+bool conv_wreg_ok(const ConvParams& p);                          // conv_wreg.hip: persistent 1x1 (Cin 256) with register-resident weights, variant 22
+int launch_conv_wreg(const ConvParams& p, hipStream_t stream, int waves = 0);   // waves: 4 / 8 per workgroup, 0 = RS_WREG_WAVES
 int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const int* m_per_image, int nseg, int images, hipStream_t stream);

@@ -27,7 +27,7 @@ void rs_debug_reload() {
   RsDebug d;
   auto rd = [](const char* name, int* v) { const char* e = getenv(name); if (e && *e) *v = atoi(e); };
   rd("RS_CONV_SINGLE_STAGE_NK", &d.conv_single_stage_nk); rd("RS_CONV_PERSIST", &d.conv_persist); rd("RS_CONV_TUNED", &d.conv_tuned);
-  rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_CONV_WIDE_PX", &d.conv_wide_px); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
+  rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_CONV_WIDE_PX", &d.conv_wide_px); rd("RS_CONV_WREG", &d.conv_wreg); rd("RS_WREG_DBG", &d.wreg_dbg); rd("RS_WREG_WAVES", &d.wreg_waves); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
   rd("RS_DECONV_VARIANT", &d.deconv_variant); rd("RS_FUSE_MASK_PREDICTOR", &d.fuse_mask_predictor); rd("RS_SIDE_STREAM", &d.side_stream);
   rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_DEEP_TILE_PX", &d.deep_tile_px); rd("RS_FUSE_BNECK", &d.fuse_bneck); rd("RS_FUSE_STEM", &d.fuse_stem);
   rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
@@ -1454,9 +1454,10 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
                                 "conv_igemm_kernel<2,4,4,4> 128x256",
                                 "conv_deep_kernel 160x256", "conv_deep_kernel 192x256", "conv_deep_kernel 224x256",
                                 "conv_deep_kernel 64x256", "conv_deep_kernel 96x256", "conv_deep_kernel 128x256",
-                                "stem_pool_kernel (conv 7x7 s2 + ReLU + max-pool 3x3 s2, 8x8 pooled pixels per workgroup)"};
+                                "stem_pool_kernel (conv 7x7 s2 + ReLU + max-pool 3x3 s2, 8x8 pooled pixels per workgroup)",
+                                "conv1x1_wreg_kernel 64 px x 256 ch (persistent, weights in registers, operand tiles by LDS-DMA)"};
   const int v = e->stages[i].variant;
-  const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 21 ? names[v] : "");
+  const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 22 ? names[v] : "");
   strncpy(name_out, s, 95);
   name_out[95] = 0;
   return RS_OK;
@@ -1471,6 +1472,7 @@ int rs_op_conv_variant(int m, int cin, int k, int cout, int cin2, int deconv2x, 
   ConvParams p;
   memset(&p, 0, sizeof p);
   p.M = m; p.Cin = cin; p.KH = p.KW = k; p.Cout = cout; p.mode = deconv2x ? 1 : 0; p.out_f32 = out_f32;
+  p.stride = 1; p.in_Cs = cin; p.out_Cs = cout;
   p.Kpad = (k * k * (cin < 64 ? 8 : cin) + cin2 + 63) / 64 * 64;
   if (cin < 64 && k == 7) p.Kpad = 256;       // the stem's padded tap rows (weights.py STEM_KW_PAD)
   static const half_t dummy = (half_t)0;

@@ -26,16 +26,18 @@ def box_iou(a, b):
     return inter / np.maximum(aa[:, None] + ab[None, :] - inter, 1e-12)
 
 
-def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
+def match_detections(ref, got, min_score=0.1, iou_thr=0.95, dscore_tol=0.02, mask_iou_thr=0.95):
     """Greedy one-to-one matching (same class, box IoU >= thr) of reference detections with score >= min_score.
     ref/got: dicts with boxes (n,4), scores (n,), classes (n,), optional masks (n,H,W) bool.
-    Returns dict(frac_matched, max_dscore, min_mask_iou (masks >= 100 px), agg_mask_iou (sum inter / sum union), n_ref)."""
+    Returns dict(frac_matched, max_dscore, min_mask_iou (masks >= 100 px), agg_mask_iou (sum inter / sum union), n_ref,
+    n_matched, n_full): ``n_full`` counts the matched pairs that ALSO meet SURVEY section 8d's other two conditions -- |dscore| <=
+    ``dscore_tol`` and, when both sides carry masks, mask IoU >= ``mask_iou_thr`` (every mask, no size exemption)."""
     rb, rs, rc = np.asarray(ref["boxes"]), np.asarray(ref["scores"]), np.asarray(ref["classes"])
     gb, gs, gc = np.asarray(got["boxes"]), np.asarray(got["scores"]), np.asarray(got["classes"])
     sel = np.where(rs >= min_score)[0]
     iou = box_iou(rb, gb)
     used = set()
-    matched, dscore, miou = 0, 0.0, 1.0
+    matched, full, dscore, miou = 0, 0, 0.0, 1.0
     inter_sum, union_sum = 0, 0
     dbox = 0.0
     for i in sel:
@@ -45,7 +47,9 @@ def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
         _, j = max(cand)
         used.add(j)
         matched += 1
-        dscore = max(dscore, abs(float(rs[i]) - float(gs[j])))
+        ds = abs(float(rs[i]) - float(gs[j]))
+        dscore = max(dscore, ds)
+        ok = ds <= dscore_tol
         dbox = max(dbox, float(np.abs(rb[i] - gb[j]).max()))
         if "masks" in ref and "masks" in got:
             a, b = np.asarray(ref["masks"][i], bool), np.asarray(got["masks"][j], bool)
@@ -55,6 +59,8 @@ def match_detections(ref, got, min_score=0.1, iou_thr=0.95):
             union_sum += u
             if u >= 100:     # a 1-pixel flip on a 3-pixel mask is not a meaningful IoU
                 miou = min(miou, it / u)
+            ok = ok and (it >= mask_iou_thr * u)
+        full += int(ok)
     n = len(sel)
-    return {"frac_matched": matched / n if n else 1.0, "max_dscore": dscore, "min_mask_iou": miou, "n_ref": n,
+    return {"frac_matched": matched / n if n else 1.0, "max_dscore": dscore, "min_mask_iou": miou, "n_ref": n, "n_matched": matched, "n_full": full,
             "agg_mask_iou": (inter_sum / union_sum) if union_sum else 1.0, "max_dbox": dbox}

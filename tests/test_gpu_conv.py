@@ -385,3 +385,31 @@ def test_bneck_tail_fused_vs_torch(gpu_required, n, hw, with_next, proj, width):
         _check_close(gt[:, 1:-1, 1:-1].permute(0, 3, 1, 2), t1n, tol=3e-3)
     else:
         assert float(t1nd.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("epi,n,hw,cout,relu", [("none", 2, (37, 41), 256, True), ("res", 3, (50, 50), 1024, True), ("up", 2, (52, 60), 256, False),
+                                                ("res", 1, (7, 9), 512, False), ("none", 1, (3, 5), 256, False)])
+def test_conv1x1_register_weights_is_bit_identical_to_the_tiled_kernel(gpu_required, epi, n, hw, cout, relu):
+    """conv_wreg.hip (variant 22: persistent workgroups, weights in registers, activation and residual / top-down tiles staged by
+    LDS-DMA under one counted wait per tile) against conv_igemm's 128x256 tile (variant 14) on the same operands: the same bits, on maps
+    with a ragged last 64-pixel tile, more tiles than workgroups x 2 (so the two-tile ring wraps), fewer tiles than workgroups, and a
+    map smaller than one tile; and both against torch fp32."""
+    g = torch.Generator().manual_seed(31)
+    h, w_ = hw
+    x = _r16(torch.randn(n, 256, h, w_, generator=g))
+    w = _r16(torch.randn(cout, 256, 1, 1, generator=g) * 0.06)
+    b = torch.randn(cout, generator=g)
+    res = _r16(torch.randn(n, cout, h, w_, generator=g)) if epi == "res" else None
+    up = _r16(torch.randn(n, cout, h // 2, w_ // 2, generator=g)) if epi == "up" else None
+    ref = F.conv2d(x, w, b)
+    if res is not None:
+        ref = ref + res
+    if up is not None:
+        ref = ref + F.interpolate(up, scale_factor=2.0, mode="nearest")
+    if relu:
+        ref = F.relu(ref)
+    a = run_conv(x, w, b, relu=relu, res=res, up=up, variant=14)
+    _check_close(a, ref)
+    for variant in (22, 23):            # four waves per workgroup (one per SIMD) / eight
+        c = run_conv(x, w, b, relu=relu, res=res, up=up, variant=variant)
+        assert torch.equal(a, c), f"variant {variant}: {int((a != c).sum())} of {a.numel()} elements differ, max {float((a - c).abs().max())}"

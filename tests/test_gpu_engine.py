@@ -313,8 +313,12 @@ def test_fp16_meets_the_stated_tolerance_on_a_trained_like_detector(gpu_required
     detector whose scores separate and whose duplicate proposals regress to the same object.  FOUR training campaigns (seeds 0..3 of
     the repo's own training engine, 600 SGD steps each on synthetic scenes with two object classes, ~12 s per campaign; the seeds are
     the first four, not chosen) x 48 fresh 512x512 scenes with 4-12 objects (800x800 network input, 1000 proposals): fp16 engine vs
-    fp32 oracle, >= 1500 reference detections pooled.  Asserted on the POOL, both directions: matched fraction >= 0.98 AND the 95 %
-    Wilson lower bound of it >= 0.98; on every scene |dscore| <= 0.02 and mask IoU >= 0.95 of the matched pairs.
+    fp32 oracle, >= 1500 reference detections pooled.  A detection counts as matched when ALL of section 8d's conditions hold for its
+    pair: same class, box IoU >= 0.95, |dscore| <= 0.02, mask IoU >= 0.95 on the pasted 512 x 512 masks (every mask, small ones too).
+    Asserted on the POOL, both directions: matched fraction >= 0.98 AND the 95 % Wilson lower bound of it >= 0.98; per scene only
+    that the masks of the box-matched pairs overlap >= 0.95 in aggregate.  (The training runs are not bit-reproducible -- float atomics
+    in the RoIAlign backward -- so the pool differs a little from run to run; one pair with a mask IoU of 0.90 next to 1 800 good
+    ones is a miss of the pool, not a failure.)
     Measured (round 3, profiles/r03/parity/): 99.3-99.7 % matched, lower bound 0.989+; the residual misses are near-ties of two boxes
     of ONE object in the final NMS (scores 1e-4 apart, IoU 0.7-0.9 between them) which the fp16 trunk's 4e-4 feature noise flips --
     tools/parity/bisect_stages.py finds 11 of 15 such scenes (8 seeds) already in "oracle downstream of the engine's FPN maps", 4 created
@@ -344,10 +348,9 @@ def test_fp16_meets_the_stated_tolerance_on_a_trained_like_detector(gpu_required
             g = {"boxes": dets[i].pred_boxes, "scores": dets[i].scores, "classes": dets[i].pred_classes, "masks": dets[i].pred_masks}
             fw, bw = match_detections(r, g), match_detections(g, r)
             for t in (tot, st):
-                t["fw_n"] += fw["n_ref"]; t["fw_m"] += round(fw["frac_matched"] * fw["n_ref"])
-                t["bw_n"] += bw["n_ref"]; t["bw_m"] += round(bw["frac_matched"] * bw["n_ref"])
-            assert fw["max_dscore"] <= 0.02, (seed, i, fw)
-            assert fw["min_mask_iou"] >= 0.95 and fw["agg_mask_iou"] >= 0.95, (seed, i, fw)
+                t["fw_n"] += fw["n_ref"]; t["fw_m"] += fw["n_full"]; t["fw_box"] = t.get("fw_box", 0) + fw["n_matched"]
+                t["bw_n"] += bw["n_ref"]; t["bw_m"] += bw["n_full"]; t["bw_box"] = t.get("bw_box", 0) + bw["n_matched"]
+            assert fw["agg_mask_iou"] >= 0.95, (seed, i, fw)
             hi = dets[i].scores >= 0.5
             iou = box_iou(gtb[i], dets[i].pred_boxes[hi]) if hi.any() else np.zeros((len(gtb[i]), 0))
             recalled += int((iou.max(1) >= 0.5).sum()) if iou.shape[1] else 0

@@ -265,3 +265,25 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_matching_counts_a_pair_only_when_box_score_and_mask_all_agree():
+    """SURVEY section 8d's matching as the parity tests and bench.py count it (proj_roadsurf_amd/matching.py): a reference detection
+    is matched when a detection of its class has box IoU >= 0.95, |dscore| <= 0.02 and mask IoU >= 0.95; a pair that fails the score
+    or the mask condition still pairs up (n_matched) but is not counted (n_full); detections under score 0.1 are not asked for."""
+    from proj_roadsurf_amd.matching import match_detections, wilson_lower
+    def mask(x0, x1):
+        m = np.zeros((4, 32, 32), bool)[0]
+        m[8:24, x0:x1] = True
+        return m
+    boxes = np.array([[0, 0, 100, 100], [200, 0, 300, 100], [0, 200, 100, 300], [200, 200, 300, 300], [400, 400, 420, 420]], np.float32)
+    ref = {"boxes": boxes, "scores": np.array([0.9, 0.8, 0.7, 0.6, 0.05], np.float32), "classes": np.array([0, 0, 1, 1, 0]),
+           "masks": np.stack([mask(4, 24)] * 5)}
+    got = {"boxes": boxes + np.array([[0, 0, 1, 1]], np.float32), "scores": np.array([0.9, 0.77, 0.7, 0.6, 0.05], np.float32),
+           "classes": np.array([0, 0, 1, 0, 0]), "masks": np.stack([mask(4, 24), mask(4, 24), mask(4, 22), mask(4, 24), mask(4, 24)])}
+    r = match_detections(ref, got)
+    # 4 asked for; #0 full; #1 pairs, score off by 0.03; #2 pairs, mask IoU 0.9; #3 other class: no pair; #4 under the score bar
+    assert (r["n_ref"], r["n_matched"], r["n_full"]) == (4, 3, 1)
+    assert r["frac_matched"] == 0.75 and abs(r["max_dscore"] - 0.03) < 1e-6 and abs(r["min_mask_iou"] - 0.9) < 1e-9
+    assert match_detections(ref, ref)["n_full"] == 4
+    assert 0.979 < wilson_lower(1825, 1833) < 1825 / 1833 and wilson_lower(0, 0) == 0.0
