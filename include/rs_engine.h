@@ -270,8 +270,10 @@ int rs_op_roi_align(const void* const feats[4], const int32_t heights[4], const 
                     int P, int out_halo, void* out, int32_t* levels_out, void* stream);
 
 /* Training path: adjoint of rs_op_roi_align.  dout: gradient of the pooled output, same layout as `out` above;
- * dfeats[l]: fp32 gradient maps with the geometry of feats[l] ([N][H_l+2][W_l+2][256]), accumulated into with float atomics
- * (torchvision's roi_align_backward_kernel does the same: [EXT tv: csrc/ops/cuda/roi_align_kernel.cu]). */
+ * dfeats[l]: fp32 gradient maps with the geometry of feats[l] ([N][H_l+2][W_l+2][256]), ACCUMULATED into.  Owner-computes: one workgroup
+ * per 8 x 8-cell region adds the RoIs that reach it in entry order (fixed summation order, reproducible bits); RoIs whose window exceeds
+ * the weight tables go through float atomics, as every RoI does in torchvision's roi_align_backward_kernel
+ * ([EXT tv: csrc/ops/cuda/roi_align_kernel.cu]).  Synchronises `stream` (its table workspace lives for the call). */
 int rs_op_roi_align_bwd(float* const dfeats[4], const int32_t heights[4], const int32_t widths[4], const float scales[4],
                         int nlevels, const float* rois, int n_rois, int rois_per_image, int P, int out_halo, const void* dout,
                         void* stream);

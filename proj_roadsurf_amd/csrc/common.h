@@ -71,6 +71,7 @@ struct RsDebug {
   int select_debug = 0;           // RS_SELECT_DEBUG
   int nms_debug = 0;              // RS_NMS_DEBUG
   int roi_window = 1;             // RS_ROI_WINDOW
+  int roi_bwd_atomic = 0;         // RS_ROI_BWD_ATOMIC        1: RoIAlign backward by float atomics for every RoI (rounds 1-2) instead of owner-computes regions
   int roi_order = 1;              // RS_ROI_ORDER             box.roi_align visits the proposals sorted by (level, row, column) instead of by score
 };
 const RsDebug& rs_debug();

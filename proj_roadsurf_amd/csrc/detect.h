@@ -74,7 +74,14 @@ struct RoiAlignParams {
   // backward (roi_align_bwd_kernel): `out` holds the incoming gradient [entry][P+2*out_pad]^2[256] fp16 and the
   // gradient of the feature maps is accumulated (float atomics) into dfeat[level], fp32, same geometry as feat[level]
   float* dfeat[4];
+  // owner-computes form of the backward (roi_bwd_prep_kernel + roi_bwd_gather_kernel): per-entry tables workspace (RS_ROI_BWD_TABLE_BYTES
+  // each, S entries), a device counter of the entries left to the atomic kernel, and the number of images behind the entries.  Null
+  // bwd_tables = the atomic kernel for every entry (round 1-2 behaviour).
+  void* bwd_tables;
+  int* bwd_overflow;
+  int n_images;
 };
+#define RS_ROI_BWD_TABLE_BYTES 2944
 
 struct BoxCandParams {
   const float* pred;        // [N][cap][cs]: [0,K] class logits, then 4K deltas

@@ -784,6 +784,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
   __shared__ int s_org[2], s_ext[2];
   const int entry = blockIdx.x;
   const int tid = threadIdx.x;
+  if (p.bwd_overflow && *p.bwd_overflow == 0) return;      // every entry was handled by roi_bwd_gather_kernel (the usual case)
   int n_entries = p.S;
   if (p.n_entries) { const int c = *p.n_entries; n_entries = c < n_entries ? c : n_entries; }
   if (entry >= n_entries) return;
@@ -870,6 +871,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
   __syncthreads();
   const int eh = s_ext[0], ew = s_ext[1];
   if (eh >= 0 && ew >= 0) {
+    if (p.bwd_overflow) return;                              // ... as was this one
     for (int t = tid; t < eh + ew; t += 256) {
       const int ax = t >= eh ? 1 : 0;
       const int rel = ax ? t - eh : t;
@@ -963,6 +965,260 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ROIAlign backward, owner-computes form (round 3).  The atomic kernel above adds every RoI's window into the fp32 maps with one float
+// atomic per cell and channel: 4 096 RoIs of ~20 x 20 cells x 256 channels are 0.4 G atomics -- 1.4 ms at batch 8, at the chip's atomic
+// rate, in an order that differs from run to run (so did the weights a training run produced).  Here every 8 x 8-cell REGION of a map is
+// owned by one workgroup, which walks the RoIs that reach it in ENTRY ORDER and adds their contributions into registers (64 floats per
+// thread: 8 cells x 8 channels), then adds the total into the map with plain loads and stores -- no atomics, a fixed summation order,
+// bit-reproducible gradients.  The per-RoI tables (the same separable weights as the forward kernel) are built once per entry by a
+// pre-pass; a RoI's contribution to a cell is computed exactly as the atomic kernel computes it.  RoIs whose window exceeds the
+// tables (very elongated ones) are counted and left to the atomic kernel, which otherwise returns at once.
+// ---------------------------------------------------------------------------------------------
+struct RoiBwdTable {
+  int img, lvl;               // lvl < 0: contributes nothing (invalid slot, empty window); lvl >= 4: left to the atomic kernel
+  int y0, y1, x0, x1;         // cell window [y0, y1) x [x0, x1) of the whole RoI at its level
+  float count;
+  int pad_;
+  int base[2][RS_ROI_PMAX], len[2][RS_ROI_PMAX];
+  float w[2][RS_ROI_PMAX][RS_ROI_WMAX];
+};
+static_assert(sizeof(RoiBwdTable) == RS_ROI_BWD_TABLE_BYTES, "RS_ROI_BWD_TABLE_BYTES");
+
+__global__ __launch_bounds__(64) void roi_bwd_prep_kernel(const RoiAlignParams p, RoiBwdTable* tabs, int* n_overflow) {
+  __shared__ float s_w[2][RS_ROI_PMAX][RS_ROI_WMAX];
+  __shared__ int s_base[2][RS_ROI_PMAX], s_len[2][RS_ROI_PMAX];
+  const int entry = blockIdx.x, tid = threadIdx.x;
+  RoiBwdTable* T = tabs + entry;
+  int n_entries = p.S;
+  if (p.n_entries) { const int c = *p.n_entries; n_entries = c < n_entries ? c : n_entries; }
+  bool valid = entry < n_entries;
+  int slot = 0, n = 0;
+  if (valid) {
+    slot = p.slot_list ? p.slot_list[entry] : entry;
+    n = slot / p.slots_per_image;
+    if (p.per_image_count && (slot - n * p.slots_per_image) >= p.per_image_count[n]) valid = false;
+  }
+  if (!valid) { if (tid == 0) { T->img = -1; T->lvl = -1; } return; }
+  const int P = p.P;
+  const float* r = p.rois + (long long)slot * 4;
+  const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+  const float area = (x2 - x1) * (y2 - y1);
+  const float v = sqrtf(area) / 224.0f + 1e-8f;
+  int lvl = v >= 2.0f ? 3 : (v >= 1.0f ? 2 : (v >= 0.5f ? 1 : 0));
+  if (lvl > p.nlevels - 1) lvl = p.nlevels - 1;
+  const int H = p.H[lvl], W = p.W[lvl];
+  const float sc = p.scale[lvl];
+  const float roi_start_w = x1 * sc - 0.5f;
+  const float roi_start_h = y1 * sc - 0.5f;
+  const float roi_w = (x2 * sc - 0.5f) - roi_start_w;
+  const float roi_h = (y2 * sc - 0.5f) - roi_start_h;
+  const float bin_h = roi_h / (float)P;
+  const float bin_w = roi_w / (float)P;
+  int gh = (int)ceilf(roi_h / (float)P);
+  int gw = (int)ceilf(roi_w / (float)P);
+  if (gh < 0) gh = 0;
+  if (gw < 0) gw = 0;
+  const float count = (float)((gh * gw) > 1 ? (gh * gw) : 1);
+  if ((tid < P) || (tid >= 32 && tid < 32 + P)) {               // the forward kernel's tables, built the same way
+    const int ax = tid >= 32 ? 1 : 0;
+    const int b = ax ? tid - 32 : tid;
+    const int g = ax ? gw : gh;
+    const int size = ax ? W : H;
+    const float start = ax ? roi_start_w : roi_start_h;
+    const float bin = ax ? bin_w : bin_h;
+    float* w = s_w[ax][b];
+    for (int j = 0; j < RS_ROI_WMAX; ++j) w[j] = 0.f;
+    int base = 0, len = 0;
+    bool have = false, overflow = false;
+    for (int i = 0; i < g; ++i) {
+      float c = start + (float)b * bin + ((float)i + 0.5f) * bin / (float)g;
+      if (c < -1.0f || c > (float)size) continue;
+      if (c <= 0.f) c = 0.f;
+      int lo = (int)c, hi;
+      if (lo >= size - 1) { hi = lo = size - 1; c = (float)lo; } else { hi = lo + 1; }
+      const float l = c - (float)lo, h = 1.f - l;
+      if (!have) { base = lo; have = true; }
+      if (hi - base >= RS_ROI_WMAX) { overflow = true; break; }
+      w[lo - base] += h;
+      w[hi - base] += l;
+      len = hi - base + 1;
+    }
+    s_base[ax][b] = base;
+    s_len[ax][b] = overflow ? -1 : len;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int org[2], end[2], bad = 0;
+    for (int ax = 0; ax < 2; ++ax) {
+      org[ax] = 0x7fffffff; end[ax] = -1;
+      for (int b = 0; b < P; ++b) {
+        const int len = s_len[ax][b];
+        if (len < 0) { bad = 1; break; }
+        if (len == 0) continue;
+        org[ax] = min(org[ax], s_base[ax][b]);
+        end[ax] = max(end[ax], s_base[ax][b] + len);
+      }
+      if (end[ax] < 0) { org[ax] = 0; end[ax] = 0; }
+      if (end[ax] - org[ax] > RS_ROI_CELLS) bad = 1;             // the atomic kernel's own criterion for its gather form
+    }
+    T->img = n;
+    T->lvl = bad ? 4 + lvl : ((end[0] > org[0] && end[1] > org[1]) ? lvl : -1);
+    T->y0 = org[0]; T->y1 = end[0]; T->x0 = org[1]; T->x1 = end[1];
+    T->count = count;
+    if (bad) atomicAdd(n_overflow, 1);
+  }
+  for (int i = tid; i < 2 * RS_ROI_PMAX; i += 64) { (&T->base[0][0])[i] = (&s_base[0][0])[i]; (&T->len[0][0])[i] = (&s_len[0][0])[i]; }
+  for (int i = tid; i < 2 * RS_ROI_PMAX * RS_ROI_WMAX; i += 64) (&T->w[0][0][0])[i] = (&s_w[0][0][0])[i];
+}
+
+struct RoiBwdGeom { int rh[4], rw[4], off[5]; };   // regions per level (rows, columns) and their running sum per image
+
+template <typename G>
+__device__ __forceinline__ void roi_grad8(const G* gp, float g[8]);
+template <>
+__device__ __forceinline__ void roi_grad8<half_t>(const half_t* gp, float g[8]) {
+  const half8 v = *(const half8*)gp;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) g[c] = (float)v[c];
+}
+template <>
+__device__ __forceinline__ void roi_grad8<float>(const float* gp, float g[8]) {
+  const f32x4 a = *(const f32x4*)gp, b = *(const f32x4*)(gp + 4);
+  g[0] = a[0]; g[1] = a[1]; g[2] = a[2]; g[3] = a[3]; g[4] = b[0]; g[5] = b[1]; g[6] = b[2]; g[7] = b[3];
+}
+
+#define RS_ROI_BWD_LIST 2048     // RoIs of one image a region can meet (box head: 512 per image, mask head: 256)
+#define RS_ROI_BWD_TABW (2 * RS_ROI_PMAX * 2 + 2 * RS_ROI_PMAX * RS_ROI_WMAX)   // words of base + len + w in a RoiBwdTable
+template <typename G>
+__global__ __launch_bounds__(256) void roi_bwd_gather_kernel(const RoiAlignParams p, const RoiBwdTable* tabs, const RoiBwdGeom geo) {
+  __shared__ unsigned short s_list[RS_ROI_BWD_LIST];
+  __shared__ int s_cnt, s_wave[4];
+  __shared__ int s_tab[2][RS_ROI_BWD_TABW];    // two RoIs' base / len / w (the RoiBwdTable layout from `base` on): one in use, one being filled
+  __shared__ float s_inv[2];
+  const int tid = threadIdx.x, hw = tid >> 5, l32 = tid & 31, wv = tid >> 6, ln = tid & 63;
+  const int per_image = geo.off[4];
+  const int n = blockIdx.x / per_image;
+  int rr = blockIdx.x - n * per_image;
+  int lvl = 0;
+  while (lvl < 3 && rr >= geo.off[lvl + 1]) ++lvl;
+  rr -= geo.off[lvl];
+  const int ry = rr / geo.rw[lvl], rx = rr - ry * geo.rw[lvl];
+  const int cy0 = ry * 8, cx0 = rx * 8;
+  const int H = p.H[lvl], W = p.W[lvl];
+  // ---- the entries of this image that reach the region, in entry order
+  int e0, e1;
+  if (p.slot_list) { e0 = 0; e1 = p.S; if (p.n_entries) { const int c = *p.n_entries; e1 = c < e1 ? c : e1; } }
+  else { e0 = n * p.slots_per_image; e1 = e0 + p.slots_per_image; if (e1 > p.S) e1 = p.S; }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int c0 = e0; c0 < e1; c0 += 256) {
+    const int e = c0 + tid;
+    bool hit = false;
+    if (e < e1) {
+      const RoiBwdTable* T = tabs + e;
+      hit = T->lvl == lvl && T->img == n && T->y0 < cy0 + 8 && T->y1 > cy0 && T->x0 < cx0 + 8 && T->x1 > cx0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (ln == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    int pos = s_cnt + __popcll(m & ((1ull << ln) - 1ull));
+    for (int w = 0; w < wv; ++w) pos += s_wave[w];
+    if (hit && pos < RS_ROI_BWD_LIST) s_list[pos] = (unsigned short)(e - e0);
+    __syncthreads();
+    if (tid == 0) { int c = s_cnt + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]; s_cnt = c < RS_ROI_BWD_LIST ? c : RS_ROI_BWD_LIST; }
+    __syncthreads();
+  }
+  const int cnt = s_cnt;
+  if (cnt == 0) return;                         // nothing reaches the region: the map keeps what it holds
+  const int P = p.P, PP = P + 2 * p.out_pad;
+  const int y = cy0 + hw;                       // this half-wave's row of the region; the thread owns 8 channels of its 8 cells
+  float acc[8][8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[x][c] = 0.f;
+  // table of list entry k -> registers (3 words per thread), then -> s_tab[k & 1]; the loads of k + 1 are in flight under the work on k
+  constexpr int TW = (RS_ROI_BWD_TABW + 255) / 256;
+  int treg[TW];
+  float tinv = 0.f;
+  auto fetch = [&](int k) {
+    const RoiBwdTable* T = tabs + e0 + s_list[k];
+    const int* src = &T->base[0][0];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) { const int o = tid + i * 256; treg[i] = o < RS_ROI_BWD_TABW ? src[o] : 0; }
+    tinv = 1.0f / T->count;
+  };
+  auto commit = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < TW; ++i) { const int o = tid + i * 256; if (o < RS_ROI_BWD_TABW) s_tab[k & 1][o] = treg[i]; }
+    if (tid == 0) s_inv[k & 1] = tinv;
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int k = 0; k < cnt; ++k) {
+    if (k + 1 < cnt) fetch(k + 1);
+    const int* tb = s_tab[k & 1];
+    const int* base0 = tb;                                   // [2][PMAX] base, [2][PMAX] len, [2][PMAX][WMAX] w
+    const int* base1 = tb + RS_ROI_PMAX;
+    const int* len0 = tb + 2 * RS_ROI_PMAX;
+    const int* len1 = tb + 3 * RS_ROI_PMAX;
+    const float* w0 = (const float*)(tb + 4 * RS_ROI_PMAX);
+    const float* w1 = w0 + RS_ROI_PMAX * RS_ROI_WMAX;
+    const float inv = s_inv[k & 1];
+    // bins whose column window meets the region's 8 columns (uniform over the workgroup)
+    int qlo = P, qhi = 0;
+    for (int pw = 0; pw < P; ++pw)
+      if (len1[pw] > 0 && base1[pw] < cx0 + 8 && base1[pw] + len1[pw] > cx0) { qlo = min(qlo, pw); qhi = max(qhi, pw + 1); }
+    const G* gout = (const G*)p.out + (long long)(e0 + s_list[k]) * PP * PP * 256 + l32 * 8;
+    for (int ph = 0; ph < P; ++ph) {
+      const int jy = y - base0[ph];
+      if (jy < 0 || jy >= len0[ph]) continue;
+      const float wy = w0[ph * RS_ROI_WMAX + jy];
+      if (wy == 0.f) continue;
+      const float wyc = wy * inv;                            // weight of the row and 1 / (samples per bin), once per bin row
+      const G* grow = gout + (long long)(ph + p.out_pad) * PP * 256;
+      for (int q0 = qlo; q0 < qhi; q0 += 6) {
+        float g[6][8];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {                        // six independent loads in flight (slots past the range re-load its first bin)
+          const int pw = q0 + u < qhi ? q0 + u : qlo;
+          roi_grad8<G>(grow + (long long)(pw + p.out_pad) * 256, g[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int pw = q0 + u;
+          if (pw >= qhi) break;
+          const int bx = base1[pw], lx = len1[pw];
+          const float* wx = w1 + pw * RS_ROI_WMAX;
+#pragma unroll
+          for (int x = 0; x < 8; ++x) {
+            const int jx = cx0 + x - bx;
+            if (jx < 0 || jx >= lx) continue;
+            const float wgt = wyc * wx[jx];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[x][c] += wgt * g[u][c];
+          }
+        }
+      }
+    }
+    if (k + 1 < cnt) commit(k + 1);             // the other buffer was last read before the barrier that ended iteration k - 1
+    __syncthreads();
+  }
+  if (y >= H) return;
+  float* drow = p.dfeat[lvl] + (((long long)n * (H + 2) + y + 1) * (W + 2) + cx0 + 1) * 256 + l32 * 8;
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {
+    if (cx0 + x >= W) break;
+    f32x4* d = (f32x4*)(drow + (long long)x * 256);
+    f32x4 a = d[0], b = d[1];
+    a[0] += acc[x][0]; a[1] += acc[x][1]; a[2] += acc[x][2]; a[3] += acc[x][3];
+    b[0] += acc[x][4]; b[1] += acc[x][5]; b[2] += acc[x][6]; b[3] += acc[x][7];
+    d[0] = a; d[1] = b;
   }
 }
 
@@ -1352,10 +1608,24 @@ int launch_roi_align(const RoiAlignParams& p, hipStream_t s) {
   return RS_OK;
 }
 
-int launch_roi_align_bwd(const RoiAlignParams& p, hipStream_t s) {
+int launch_roi_align_bwd(const RoiAlignParams& p_in, hipStream_t s) {
+  RoiAlignParams p = p_in;
   RS_CHECK(p.C == 256 && p.P <= RS_ROI_PMAX, RS_ERR_UNSUPPORTED, "roi_align backward: C must be 256, P <= %d", RS_ROI_PMAX);
   RS_CHECK(p.S > 0, RS_ERR_ARG, "roi_align backward: S");
   for (int l = 0; l < p.nlevels; ++l) RS_CHECK(p.dfeat[l] != nullptr, RS_ERR_ARG, "roi_align backward: null gradient map");
+  const bool gather = p.bwd_tables && p.bwd_overflow && p.n_images > 0 && p.nlevels == 4 && p.slots_per_image <= RS_ROI_BWD_LIST &&
+                      (!p.slot_list || p.S <= RS_ROI_BWD_LIST * 8) && rs_debug().roi_bwd_atomic == 0;
+  if (!gather) p.bwd_overflow = nullptr;                       // the atomic kernel serves every entry
+  else {
+    RoiBwdGeom geo;
+    geo.off[0] = 0;
+    for (int l = 0; l < 4; ++l) { geo.rh[l] = cdiv(p.H[l], 8); geo.rw[l] = cdiv(p.W[l], 8); geo.off[l + 1] = geo.off[l] + geo.rh[l] * geo.rw[l]; }
+    RS_HIP(hipMemsetAsync(p.bwd_overflow, 0, sizeof(int), s));
+    hipLaunchKernelGGL(roi_bwd_prep_kernel, dim3(p.S), dim3(64), 0, s, p, (RoiBwdTable*)p.bwd_tables, p.bwd_overflow);
+    const dim3 grid((unsigned)(p.n_images * geo.off[4]));
+    if (p.f32) hipLaunchKernelGGL(roi_bwd_gather_kernel<float>, grid, dim3(256), 0, s, p, (const RoiBwdTable*)p.bwd_tables, geo);
+    else hipLaunchKernelGGL(roi_bwd_gather_kernel<half_t>, grid, dim3(256), 0, s, p, (const RoiBwdTable*)p.bwd_tables, geo);
+  }
   if (p.f32) hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(p.S), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(roi_align_bwd_kernel<half_t>, dim3(p.S), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());

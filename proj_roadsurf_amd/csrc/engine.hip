@@ -27,7 +27,7 @@ void rs_debug_reload() {
   RsDebug d;
   auto rd = [](const char* name, int* v) { const char* e = getenv(name); if (e && *e) *v = atoi(e); };
   rd("RS_CONV_SINGLE_STAGE_NK", &d.conv_single_stage_nk); rd("RS_CONV_PERSIST", &d.conv_persist); rd("RS_CONV_TUNED", &d.conv_tuned);
-  rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_CONV_WIDE_PX", &d.conv_wide_px); rd("RS_CONV_WREG", &d.conv_wreg); rd("RS_WREG_DBG", &d.wreg_dbg); rd("RS_WREG_WAVES", &d.wreg_waves); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
+  rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_CONV_WIDE_PX", &d.conv_wide_px); rd("RS_CONV_WREG", &d.conv_wreg); rd("RS_WREG_DBG", &d.wreg_dbg); rd("RS_ROI_BWD_ATOMIC", &d.roi_bwd_atomic); rd("RS_WREG_WAVES", &d.wreg_waves); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
   rd("RS_DECONV_VARIANT", &d.deconv_variant); rd("RS_FUSE_MASK_PREDICTOR", &d.fuse_mask_predictor); rd("RS_SIDE_STREAM", &d.side_stream);
   rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_DEEP_TILE_PX", &d.deep_tile_px); rd("RS_FUSE_BNECK", &d.fuse_bneck); rd("RS_FUSE_STEM", &d.fuse_stem);
   rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
@@ -1706,7 +1706,18 @@ int rs_op_roi_align_bwd(float* const dfeats[4], const int32_t heights[4], const 
   for (int l = 0; l < nlevels; ++l) { p.dfeat[l] = dfeats[l]; p.H[l] = heights[l]; p.W[l] = widths[l]; p.scale[l] = scales[l]; }
   p.nlevels = nlevels; p.C = 256; p.rois = rois; p.S = n_rois; p.slots_per_image = rois_per_image;
   p.out = (half_t*)dout; p.P = P; p.out_pad = out_halo;
-  return launch_roi_align_bwd(p, (hipStream_t)stream);
+  rs_debug_reload();                                         // RS_ROI_BWD_ATOMIC: the operator tests switch between the two forms
+  // workspace of the owner-computes form (the trainer owns its own): per-entry tables + the overflow counter, for the time of this call
+  p.n_images = (n_rois + rois_per_image - 1) / rois_per_image;
+  void* ws = nullptr;
+  RS_HIP(hipMalloc(&ws, (size_t)n_rois * RS_ROI_BWD_TABLE_BYTES + 64));
+  p.bwd_overflow = (int*)ws;
+  p.bwd_tables = (char*)ws + 64;
+  const int rc = launch_roi_align_bwd(p, (hipStream_t)stream);
+  hipError_t he = hipStreamSynchronize((hipStream_t)stream);
+  hipFree(ws);
+  RS_HIP(he);
+  return rc;
 }
 
 int rs_op_rpn_loss(const float* head, void* dhead, const int32_t* labels, const float* anchors, const float* matched_gt,

@@ -316,9 +316,9 @@ def test_fp16_meets_the_stated_tolerance_on_a_trained_like_detector(gpu_required
     fp32 oracle, >= 1500 reference detections pooled.  A detection counts as matched when ALL of section 8d's conditions hold for its
     pair: same class, box IoU >= 0.95, |dscore| <= 0.02, mask IoU >= 0.95 on the pasted 512 x 512 masks (every mask, small ones too).
     Asserted on the POOL, both directions: matched fraction >= 0.98 AND the 95 % Wilson lower bound of it >= 0.98; per scene only
-    that the masks of the box-matched pairs overlap >= 0.95 in aggregate.  (The training runs are not bit-reproducible -- float atomics
-    in the RoIAlign backward -- so the pool differs a little from run to run; one pair with a mask IoU of 0.90 next to 1 800 good
-    ones is a miss of the pool, not a failure.)
+    that the masks of the box-matched pairs overlap >= 0.95 in aggregate (one pair with a mask IoU of 0.90 next to 1 800 good ones is a
+    miss of the pool, not a failure).  Since round 3 the training runs are bit-reproducible (owner-computes RoIAlign backward,
+    tests/test_gpu_trainer.py::test_two_training_runs_give_the_same_bits), so this pool is the same from run to run.
     Measured (round 3, profiles/r03/parity/): 99.3-99.7 % matched, lower bound 0.989+; the residual misses are near-ties of two boxes
     of ONE object in the final NMS (scores 1e-4 apart, IoU 0.7-0.9 between them) which the fp16 trunk's 4e-4 feature noise flips --
     tools/parity/bisect_stages.py finds 11 of 15 such scenes (8 seeds) already in "oracle downstream of the engine's FPN maps", 4 created

@@ -268,6 +268,63 @@ def test_roi_align_backward_is_the_adjoint_of_forward(gpu_required, P):
     assert sum(float(d.abs().sum()) for d in dfd) > 0
 
 
+def test_roi_align_backward_owner_computes_equals_atomics_and_is_reproducible(gpu_required, monkeypatch):
+    """The owner-computes backward (one workgroup per 8 x 8-cell region of a map walks the RoIs that reach it in entry order; plain
+    stores) against the float-atomic kernel of rounds 1-2 (RS_ROI_BWD_ATOMIC=1) on 2 x 512 clustered, overlapping RoIs over all four
+    levels, image borders and one elongated box (left to the atomic kernel in both): the same gradient maps up to the fp32 summation
+    order (a RoI's contribution to a cell is computed the same way in both), nothing in the halo, the maps ACCUMULATE (a second call
+    doubles them), and two runs of the new form agree BIT for bit -- the atomics did not."""
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    n_img, rpi, P = 2, 512, 7
+    sizes = [(64, 72), (32, 36), (16, 18), (8, 9)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    W_img, H_img = 288.0, 256.0
+    centres = torch.rand(12, 2, generator=g) * torch.tensor([W_img, H_img])
+    c = centres[torch.randint(0, 12, (n_img * rpi,), generator=g)] + torch.randn(n_img * rpi, 2, generator=g) * 6.0
+    side = torch.tensor([16.0, 40.0, 90.0, 170.0, 300.0, 24.0, 60.0, 560.0])[torch.randint(0, 8, (n_img * rpi,), generator=g)]
+    bw = side * (0.6 + 0.8 * torch.rand(n_img * rpi, generator=g))
+    bh = side * (0.6 + 0.8 * torch.rand(n_img * rpi, generator=g))
+    bw[5], bh[5] = 900.0, 5.0                   # elongated: window larger than the tables
+    rois = torch.stack([c[:, 0] - bw / 2, c[:, 1] - bh / 2, c[:, 0] + bw / 2, c[:, 1] + bh / 2], 1).clamp(-30, 630).float().contiguous()
+    rd = rois.to(dev)
+    Gd = (torch.randn(n_img * rpi, P, P, 256, generator=g) * 0.5).half().to(dev)
+    vp4 = C.c_void_p * 4
+    hs = (C.c_int32 * 4)(*[h for h, _ in sizes])
+    ws = (C.c_int32 * 4)(*[w for _, w in sizes])
+    sc = (C.c_float * 4)(*scales)
+
+    def run(calls=1, boxes=rd):
+        dfd = [torch.zeros(n_img, h + 2, w + 2, 256, dtype=torch.float32, device=dev) for h, w in sizes]
+        torch.cuda.synchronize()
+        for _ in range(calls):
+            _check(lib, lib.rs_op_roi_align_bwd(vp4(*[f.data_ptr() for f in dfd]), hs, ws, sc, 4, C.c_void_p(boxes.data_ptr()), n_img * rpi, rpi, P, 0,
+                                                C.c_void_p(Gd.data_ptr()), None), "rs_op_roi_align_bwd")
+        torch.cuda.synchronize()
+        return [d.cpu() for d in dfd]
+
+    monkeypatch.setenv("RS_ROI_BWD_ATOMIC", "1")
+    ref = run()
+    monkeypatch.setenv("RS_ROI_BWD_ATOMIC", "0")
+    got = run()
+    for l, (r, x) in enumerate(zip(ref, got)):
+        assert float(r.abs().max()) > 0
+        xd = x.double()
+        assert float(xd.abs().sum()) == pytest.approx(float(xd[:, 1:-1, 1:-1].abs().sum()), rel=1e-12), "gradient written into the halo"
+        err = float((x - r).abs().max())
+        assert err <= 2e-5 * max(1.0, float(r.abs().max())), (l, err, float(r.abs().max()))
+    # reproducibility and accumulation without the elongated box (its bins' windows overlap, and the atomic kernel it is left to adds them
+    # in whatever order they arrive)
+    plain = rois.clone()
+    plain[5] = plain[6]
+    pd_ = plain.to(dev)
+    a, b, twice = run(boxes=pd_), run(boxes=pd_), run(2, boxes=pd_)
+    for l, (x, y, t) in enumerate(zip(a, b, twice)):
+        assert torch.equal(x, y), f"level {l}: two runs of the owner-computes form differ"
+        assert float((t - 2 * x).abs().max()) <= 4e-5 * max(1.0, float(x.abs().max())), l
+
+
 def test_deconv2x2_backward_through_conv_ops(gpu_required):
     """ConvTranspose2d(k=2, s=2) of the mask head: its input gradient is a 2x2 stride-2 convolution of dY (forward
     kernel, rs_op_conv2d) and its weight gradient is rs_op_conv2d_wgrad with the operands swapped (X as the 'output
