@@ -241,6 +241,7 @@ struct rs_engine {
   int fuse_shortcut = 1;
   int fuse_bneck = 1;
   int fuse_stem = 1;      // stem conv + ReLU + max-pool as one launch (inference engines, fp16 path)
+  bool frozen_fusions_only = false;   // a trainer's forward engine: layer fusions only where nothing is differentiated (stem + res2 at FREEZE_AT 2)
   int merge_levels = 1;   // FPN output convs / RPN 3x3 of all levels as one multi-map launch each (inference engines, fp16 path)
   long long forward_index = 0;
   std::set<int> warmed;
@@ -565,6 +566,8 @@ int rs_engine::build() {
       // in one launch -- t2 is never materialised and the next conv1 reads `out` from registers.  fp16 inference engine only.
       // Block 0 of the stage has a projection shortcut from the 64-channel stem output at the same resolution: the tail then adds
       // Wsc . x0 as two more K steps instead of the identity residual (needs the folded conv3sc bias = conv3's + the shortcut's).
+      const bool may_fuse = !frozen_fusions_only || si == 0;          // a trainer fuses only inside the frozen res2
+      const bool fuse_bneck = this->fuse_bneck && may_fuse, fuse_shortcut = this->fuse_shortcut && may_fuse;
       const bool tail0 = !f32 && fuse_bneck && fuse_shortcut && bi == 0 && bott == 64 && cout == 256 && stride == 1 && cur.C == 64 &&
                          findw(wn + ".conv3p") != nullptr && findw(wn + ".shortcut") != nullptr && find(wn + ".conv3sc.b") != nullptr;
       const bool tail = tail0 || (!f32 && fuse_bneck && bi > 0 && (bott == 64 || bott == 128) && cout == 4 * bott && stride == 1 && findw(wn + ".conv3p") != nullptr);
@@ -1216,7 +1219,9 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   e->fuse_bneck = rs_debug().fuse_bneck;
   e->fuse_stem = rs_debug().fuse_stem;
   e->merge_levels = rs_debug().merge_levels;
-  if (g_trainer_unfused_shortcut) { e->fuse_shortcut = 0; e->fuse_bneck = 0; e->merge_levels = 0; e->fuse_stem = 0; }   // the training engine differentiates every convolution separately and needs every layer output
+  // the training engine differentiates every convolution of res3..res5 / FPN / heads separately and needs every layer output there; the frozen
+  // stem and res2 (FREEZE_AT 2, what rs_trainer implements) keep the inference engine's fused stem and fused bottleneck tails
+  if (g_trainer_unfused_shortcut) { e->frozen_fusions_only = true; e->merge_levels = 0; }
   e->use_graph = rs_debug().use_graph;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
   else {
