@@ -287,3 +287,14 @@ def test_matching_counts_a_pair_only_when_box_score_and_mask_all_agree():
     assert r["frac_matched"] == 0.75 and abs(r["max_dscore"] - 0.03) < 1e-6 and abs(r["min_mask_iou"] - 0.9) < 1e-9
     assert match_detections(ref, ref)["n_full"] == 4
     assert 0.979 < wilson_lower(1825, 1833) < 1825 / 1833 and wilson_lower(0, 0) == 0.0
+
+
+def test_host_pools_shrink_with_the_ranks_share_of_the_cores():
+    """make_detections sizes its decode processes / host threads / vectoriser threads per RANK: 4 each where the rank has >= 16 cores
+    (what one MI355X was measured to need), a quarter of the share below that, never under 1; explicit values are kept."""
+    from proj_roadsurf_amd.make_detections import host_pool_sizes
+    assert host_pool_sizes(None, None, None, cores=128, local_world=8) == (4, 4, 4, 16)
+    assert host_pool_sizes(None, None, None, cores=64, local_world=8) == (2, 2, 2, 8)
+    assert host_pool_sizes(None, None, None, cores=16, local_world=8) == (1, 1, 1, 2)
+    assert host_pool_sizes(None, None, None, cores=8, local_world=1) == (2, 2, 2, 8)
+    assert host_pool_sizes(6, 0, None, cores=8, local_world=2) == (6, 0, 1, 4)
