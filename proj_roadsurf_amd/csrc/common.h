@@ -235,7 +235,7 @@ int launch_maxpool(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho,
 int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
-int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu = 0);   // ref_f32.hip: fp32 MFMA (or the VALU cross-check)
+int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu = 0, int tile = 0);   // ref_f32.hip: fp32 MFMA (or the VALU cross-check)
 int launch_conv_deep(const ConvParams& p, hipStream_t stream, int tile_px = 256);
 int rs_device_cu_count();                                        // CUs of the current device (256 without one), conv_deep.hip
 bool conv_wreg_ok(const ConvParams& p);                          // conv_wreg.hip: persistent 1x1 (Cin 256) with register-resident weights, variant 22

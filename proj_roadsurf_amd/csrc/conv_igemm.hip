@@ -574,7 +574,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
   if (use_glds < 0) {                   // fp32 reference-precision mode (ref_f32.hip)
     RS_CHECK(!p_in.in2, RS_ERR_UNSUPPORTED, "conv: the fp32 kernel has no second K source");
     g_last_conv_variant = -1;
-    return launch_conv_f32(p_in, stream, use_glds == -2);      // -2: the VALU cross-check kernel
+    return launch_conv_f32(p_in, stream, use_glds == -2, force_variant);      // -2: the VALU cross-check kernel
   }
   ConvParams p = p_in;
   const int nk2 = p.in2 ? (p.Cin2 >> 6) : 0;

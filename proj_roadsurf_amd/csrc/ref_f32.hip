@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_f32_valu_kernel(const ConvParams p) 
 }  // namespace
 
 // ConvParams with every tensor pointer (in, w, out, res, up) referring to fp32 data.  force_valu: the VALU cross-check kernel.
-int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu) {
+int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu, int tile) {
   RS_CHECK(p.M > 0 && p.mode != 2, RS_ERR_ARG, "conv_f32: bad arguments");
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   // shape rules of the MFMA kernel: 128-byte K steps (Cin % 32 == 0, or the stem's 32-float kernel rows), 16-byte aligned
@@ -335,12 +335,21 @@ int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu) {
   const bool train = p.down || p.res32 || p.mask || p.out_stride > 1;
   RS_CHECK(!train || (mfma_ok && p.mode == 0), RS_ERR_UNSUPPORTED, "conv_f32: the backward epilogue needs the MFMA kernel's shape rules and mode 0");
   if (mfma_ok) {
+    // Few 128 x 128 tiles (res4 / res5 and the p4 / p5 levels: 300-1 260 of them on 256 CUs x 2) fill the chip for one full round and a
+    // ragged second one: the 128 x 64 tile (3 workgroups per CU) runs res4.x.conv2 in 403 instead of 578 us, res5.x.conv2 in 482 instead of
+    // 575 (tools/ubench/f32_tiles.py); from ~1 300 tiles on the wide tile wins (fpn_output3: 1 466 vs 1 590 us).  The K order inside an
+    // output element does not depend on the tile, so the choice changes no bit.
+    const bool wide = rows % 128 == 0 && (long long)cdiv(p.M, 128) * (rows / 128) >= 5ll * rs_device_cu_count();
     if (train) {
-      if (rows % 128 == 0) return launch_f32_variant<2, 2, 4, 4, true>(p, stream);
+      if (wide) return launch_f32_variant<2, 2, 4, 4, true>(p, stream);
       if (rows % 64 == 0) return launch_f32_variant<4, 1, 4, 2, true>(p, stream);
       return launch_f32_variant<4, 1, 1, 4, true>(p, stream);
     }
-    if (rows % 128 == 0) return launch_f32_variant<2, 2, 4, 4>(p, stream);    // 128 px x 128 ch
+    // tile forced by the operator interface (rs_op_conv2d variant 30 / 31, tools/ubench/f32_tiles.py)
+    if (tile == 30 && rows % 128 == 0) return launch_f32_variant<2, 2, 4, 4>(p, stream);
+    if (tile == 31 && rows % 64 == 0) return launch_f32_variant<4, 1, 4, 2>(p, stream);
+    RS_CHECK(tile != 30 && tile != 31, RS_ERR_ARG, "conv_f32: tile %d does not divide %d rows", tile, rows);
+    if (wide) return launch_f32_variant<2, 2, 4, 4>(p, stream);               // 128 px x 128 ch
     if (rows % 64 == 0) return launch_f32_variant<4, 1, 4, 2>(p, stream);     // 128 px x 64 ch
     return launch_f32_variant<4, 1, 1, 4>(p, stream);                          // 256 px x 16 ch (heads)
   }

@@ -254,7 +254,7 @@ def test_rejects_bad_shapes(gpu_required):
 # the VALU cross-check (use_glds = -2), against torch fp32 on the CPU.  fp32 sums of K <= 2304 products in different
 # orders: 2e-5 relative to the output scale.
 # ---------------------------------------------------------------------------------------------
-def run_conv_f32(x, w, b, *, stride=1, pad=0, relu=False, res=None, up=None, out_halo=1, deconv=False, valu=False):
+def run_conv_f32(x, w, b, *, stride=1, pad=0, relu=False, res=None, up=None, out_halo=1, deconv=False, valu=False, tile=-1):
     lib = load_library()
     dev = torch.device("cuda:0")
     n, cin, hi, wi = x.shape
@@ -284,7 +284,7 @@ def run_conv_f32(x, w, b, *, stride=1, pad=0, relu=False, res=None, up=None, out
     rc = lib.rs_op_conv2d(C.c_void_p(xd.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(od.data_ptr()),
                           C.c_void_p(rd.data_ptr()) if rd is not None else None, C.c_void_p(ud.data_ptr()) if ud is not None else None,
                           n, hi, wi, cin, pad, kh, kw, stride, pad, cout_store, wp.shape[1], out_halo, int(relu), 1,
-                          int(deconv), -1, -2 if valu else -1, None)
+                          int(deconv), tile, -2 if valu else -1, None)
     _check(lib, rc, "rs_op_conv2d(fp32)")
     torch.cuda.synchronize()
     o = od.cpu()
@@ -317,6 +317,11 @@ def test_conv_f32_mfma_vs_torch(gpu_required, cin, cout, k, stride, hw, n):
     valu = run_conv_f32(x, w, b, stride=stride, pad=pad, relu=res is not None, res=res, valu=True)
     _check_close(got, want, tol=2e-5)
     _check_close(valu, want, tol=2e-5)
+    # the dispatch picks the tile by the number of tiles (csrc/ref_f32.hip launch_conv_f32: 128 x 64 when few, 128 x 128 when many); forced
+    # here (30 = 128 x 128, 31 = 128 x 64), both give the SAME bits as the dispatched one: the K order of an output element is the tile's
+    for tile in ([30, 31] if cout % 128 == 0 else [31] if cout % 64 == 0 else []):
+        forced = run_conv_f32(x, w, b, stride=stride, pad=pad, relu=res is not None, res=res, tile=tile)
+        assert torch.equal(forced, got), f"tile {tile}: {int((forced != got).sum())} elements differ"
 
 
 def test_conv_f32_mfma_upsample_add_and_deconv(gpu_required):
