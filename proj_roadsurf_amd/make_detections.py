@@ -230,6 +230,10 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 if not register_host_buffer(pools[shape].slab):      # pinned: batches go from the slab to the device without a staging copy
                     log.info("the decode slab could not be pinned; batches are staged through the engine's own pinned buffer")
             pool = pools.get(shape) if uniform else None
+            if uniform:
+                t_p = time.time()
+                predictor.prepare(shape)                # engines built + kernels loaded while the decoder processes start
+                log.info("%s: lane pipeline for %s tiles ready in %.2f s", dataset, shape, time.time() - t_p)
 
             def pool_source(chunks, pool=pool):
                 it = pool.batches(chunks, key=lambda e: os.path.abspath(e["file_name"]))
