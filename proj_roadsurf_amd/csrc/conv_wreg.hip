@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256 * NWPX) void conv1x1_wreg_kernel(const ConvPara
 bool conv_wreg_ok(const ConvParams& p) {
   return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cin == 256 && p.in_Cs == 256 && p.Kpad >= 256 && p.Cout % 256 == 0 && p.mode == 0 && !p.out_f32 &&
          !p.in2 && !p.m_count && !p.koff && !(p.res && p.up) && !p.down && !p.res32 && !p.mask && p.out_stride <= 1 && !p.head_w && p.nseg == 0 &&
-         (!p.up || p.up_Cs % 8 == 0) && p.out_Cs % 8 == 0;
+         (!p.up || (p.up_Cs % 8 == 0 && p.up_Cs >= p.Cout)) && p.out_Cs % 8 == 0 && p.out_Cs >= p.Cout;
 }
 
 template <int EPI, int NWPX>
