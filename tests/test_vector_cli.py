@@ -264,6 +264,12 @@ def test_make_detections_cli_end_to_end(gpu_required, tmp_path):
     yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
     cwd = os.getcwd()
     try:
+        # the same job in the reference's arithmetic first (--precision fp32: fp32 activations / weights on the fp32 matrix cores) ...
+        assert make_detections.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--batch", "2", "--precision", "fp32"]) == 0
+        os.chdir(cwd)
+        ref_feats = read_gpkg(str(wd / "val_detections_at_0dot05_threshold.gpkg"), "val_detections_at_0dot05_threshold")
+        assert len(ref_feats) > 0
+        # ... then the production mode, which overwrites the outputs
         assert make_detections.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--batch", "2", "--geojson"]) == 0
     finally:
         os.chdir(cwd)
@@ -271,6 +277,7 @@ def test_make_detections_cli_end_to_end(gpu_required, tmp_path):
     assert out.exists() and (wd / "logs").is_dir()
     feats = read_gpkg(str(out), "val_detections_at_0dot05_threshold")
     assert len(feats) > 0
+    assert 0.5 * len(ref_feats) <= len(feats) <= 2.0 * len(ref_feats)        # random weights: the two precisions agree statistically only
     for f in feats:
         assert 0.05 < f["properties"]["score"] <= 1.0 and f["properties"]["det_class"] in (0, 1)
         i = int(f["properties"]["image"].split("_")[1]) - 100
