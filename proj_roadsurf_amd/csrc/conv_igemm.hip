@@ -561,10 +561,12 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
   // HBM-bound 1x1 layers on big maps: all 256 channels per workgroup, so every activation row is read once; 128 pixels per
   // workgroup restage the 128 KB weight matrix half as often as 64 (fpn_lateral2 0.241 -> 0.210 ms, fused deconv 0.338 -> 0.267 ms)
   // (res4.x.conv3 at batch 16, 40 000 pixels: 38.9 us against 44.0 on the 64x128 tile, tools/ubench/conv_shapes.py)
-  // ... and where a workgroup would walk >= 16 tiles of 64 pixels, the persistent form with the weights in registers (conv_wreg.hip):
-  // fpn_lateral2 at batch 16 / 8: 216 -> 167 us / 111 -> 88 us; at batch 3 (7 tiles per workgroup) 35 -> 39 us, res4.x.conv3 at
-  // batch 16 (10 tiles) 46 -> 45 us: its prologue (128 KB of weights per workgroup) wants a long walk (tools/ubench/wreg_shapes.py)
-  if (D.conv_wreg && use_glds > 0 && conv_wreg_ok(p) && (long long)cdiv(p.M, 64) * (p.Cout >> 8) >= 16ll * rs_device_cu_count()) return 22;
+  // ... and where a workgroup walks about five tiles or more, the persistent form with the weights in registers (conv_wreg.hip: 32-pixel
+  // tiles, two independent workgroups per CU).  tools/ubench/wreg_shapes.py, layers with their epilogue operands, us against the best
+  // conv_igemm tile: fpn_lateral2 at batch 16 / 8 / 3 / 2 / 1: 152 / 82 / 34.1 / 26.2 / 19.6 against 210 / 108 / 34.5 / 26.3 / 16.4;
+  // res4.x.conv3 at batch 16 / 8 / 4: 40.0 / 26.1 / 20.0 against 45.4 / 27.0 / 16.8 -- the break-even is a walk of ~4.8 tiles per workgroup
+  // (its prologue loads 128 KB of weights into registers)
+  if (D.conv_wreg && use_glds > 0 && conv_wreg_ok(p) && (long long)cdiv(p.M, 32) * (p.Cout >> 8) * 5 >= 48ll * rs_device_cu_count()) return 22;
   if (rows % 256 == 0 && nkd <= 4 && p.M >= 40000) return D.conv_wide_px == 64 ? 10 : 14;
   if (nkd <= 4 || tiles0 < 1250) return 7;                                // few tiles or shallow K: 64x128 keeps more workgroups in flight
   return 0;
@@ -592,10 +594,11 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
   const int v = conv_choose_variant(p, force_variant, use_glds);
   RS_CHECK(!(train_opts && (p.mode != 0 || (v == 12 && p.out_stride > 1) || (v >= 15 && v <= 20))), RS_ERR_UNSUPPORTED, "conv: training epilogue options need mode 0 (and no scatter on conv_deep)");
-  if (v == 22 || v == 23) {                   // persistent 1x1 with the weights in registers (conv_wreg.hip); 23 = its eight-wave form
+  if (v == 22 || v == 23 || v == 25 || v == 26) {   // persistent 1x1 with the weights in registers (conv_wreg.hip): 22 = the form that ships (RS_WREG_WAVES,
+    // default 32-pixel tiles with two workgroups per CU), 25 = that form by name, 26 / 23 = 64-pixel tiles with four / eight waves
     RS_CHECK(conv_wreg_ok(p) && !train_opts, RS_ERR_UNSUPPORTED, "conv: variant %d takes 1x1 / Cin 256 / Cout %% 256 == 0 inference layers only", v);
     g_last_conv_variant = v;
-    return launch_conv_wreg(p, stream, v == 23 ? 8 : 0);
+    return launch_conv_wreg(p, stream, v == 23 ? 8 : (v == 25 ? 2 : (v == 26 ? 4 : 0)));
   }
   if (v == 12 || (v >= 15 && v <= 20)) {     // 256x256 with 3 activation stages / 2 weight stages (conv_deep.hip); 15 / 16 / 17: 160 / 192 / 224 pixels, 18 / 19 / 20: 64 / 96 / 128
     RS_CHECK(!p.in2, RS_ERR_UNSUPPORTED, "conv: variant %d has no second K source", v);

@@ -7,11 +7,11 @@
 // a tile's epilogue reads (residual / top-down addend: ordinary loads, waited for with nothing else in flight) overlap nothing of
 // their own workgroup.  Little's law at the ~3.4 us these loads take under load gives the 3.2-3.6 TB/s the stage table shows.
 //
-// Here a workgroup (4 waves, one per SIMD) owns ONE 256-channel group for its whole life:
+// Here a workgroup (4 waves, one per SIMD; two such workgroups per CU in the form that ships) owns ONE 256-channel group for its whole life:
 //   * its wave's weight fragments -- 64 channels x 256 K as 32 MFMA A operands, 128 VGPRs -- are loaded once (after the first two
 //     tiles' pieces are on their way);
-//   * LDS holds two operand tiles of 64 pixels: the 256-channel activation rows (32 KB) AND the epilogue operand of the same pixels
-//     (residual, or the coarser map's rows of the FPN top-down add: 32 KB), both staged by LDS-DMA in the 128-byte XOR-swizzled rows
+//   * LDS holds two operand tiles of BM pixels: the 256-channel activation rows (BM x 512 B) AND the epilogue operand of the same pixels
+//     (residual, or the coarser map's rows of the FPN top-down add: as much again), both staged by LDS-DMA in the 128-byte XOR-swizzled rows
 //     of conv_igemm -- no register is ever the target of a load in flight, so nothing here depends on where hipcc puts a copy;
 //   * tile k is computed while k+1 is in flight and k+2 is issued as soon as every wave has read tile k: 64-128 KB of HBM reads in
 //     flight per CU;
@@ -24,7 +24,13 @@
 // (tests/test_gpu_conv.py::test_conv1x1_register_weights_is_bit_identical_to_the_tiled_kernel); a NaN accumulator, which variant 14
 // stores as NaN, is stored as -65504 here (v_med3_f32).
 //
-// Measured (tools/ubench/wreg_shapes.py, one box, batch 16): fpn_lateral2 with its top-down add 216 -> 167 us (3.42 -> 4.42 TB/s of
+// The form that ships has 32-PIXEL tiles and TWO such workgroups per CU (template BM = 32: 64 KB of LDS and <= 256 registers each): the
+// phases of a workgroup -- wait for the tile, MFMAs, epilogue -- run one after the other (see the ablations below), but two independent
+// workgroups on a CU are out of phase with each other, so one's epilogue and waits run under the other's MFMAs.  fpn_lateral2 with its
+// top-down add at batch 16: 210 us (variant 14) -> 165.5 (64-pixel tiles, one workgroup per CU) -> 152 us (4.86 TB/s of algorithmic
+// bytes); res4.x.conv3 (1024 channels, residual) 45.4 -> 40.0 us.
+//
+// Measured first with 64-pixel tiles (tools/ubench/wreg_shapes.py, one box, batch 16): fpn_lateral2 with its top-down add 216 -> 167 us (3.42 -> 4.42 TB/s of
 // algorithmic bytes), without the add 182 -> 148 us.  RS_WREG_DBG ablations of the 167 us: without its stores 103, without its loads
 // 122, without both 63 -- the three add up, i.e. the wave's phases (wait for the tile, MFMAs, epilogue) still run one after the other;
 // an eight-wave form (variant 23: two waves per SIMD, 32 pixels of the tile each) measures the same 163-166 us because one barrier
@@ -35,9 +41,7 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int BM = 64, MI = 4;
-constexpr int SLICE = BM * 128;          // one 64-channel slice of a 64-pixel tile: 8 KB
-constexpr int HALF = 4 * SLICE;          // 256 channels: 32 KB
+constexpr int MI = 4;
 
 __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -59,10 +63,14 @@ __device__ __forceinline__ Pix pix_add(int x0, int y0, int n0, int rx, int ry, i
 
 // EPI: 0 = bias (+ ReLU) only, 1 = residual (same geometry as the output), 2 = coarser map added at (y/2, x/2) (FPN top-down)
 // NWPX: 1 = four waves (one per SIMD, all 64 pixels of the tile each), 2 = eight waves (two per SIMD, 32 pixels each)
-template <int EPI, int NWPX>
-__global__ __launch_bounds__(256 * NWPX) void conv1x1_wreg_kernel(const ConvParams p, const int dbg) {
-  constexpr int NWAVE = 4 * NWPX, NJ = 4 / NWPX;
-  constexpr int PASSES = 8 / NWAVE;               // LDS-DMA passes of NWAVE * 8 rows per tile
+// BM: pixels per tile: 64 (one workgroup per CU), or 32 with NWPX = 1 (half the LDS and a quarter fewer registers: TWO independent workgroups
+// per CU, whose phases -- wait for the tile, MFMAs, epilogue -- then overlap each other's)
+template <int EPI, int NWPX, int BM>
+__global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_kernel(const ConvParams p, const int dbg) {
+  constexpr int SLICE = BM * 128;                 // one 64-channel slice of a tile
+  constexpr int HALF = 4 * SLICE;                 // 256 channels
+  constexpr int NWAVE = 4 * NWPX, NJ = BM / 16 / NWPX;
+  constexpr int PASSES = BM / (NWAVE * 8);        // LDS-DMA passes of NWAVE * 8 rows per tile
   constexpr int TILE = EPI ? 2 * HALF : HALF;     // activations [+ epilogue operand]
   constexpr int OPS = (EPI ? 8 : 4) * PASSES;     // LDS-DMA pieces a wave issues per tile
   constexpr int STS = 2 * NJ;                     // stores a wave issues per (full) tile
@@ -262,27 +270,34 @@ bool conv_wreg_ok(const ConvParams& p) {
          (!p.up || (p.up_Cs % 8 == 0 && p.up_Cs >= p.Cout)) && p.out_Cs % 8 == 0 && p.out_Cs >= p.Cout;
 }
 
-template <int EPI, int NWPX>
+template <int EPI, int NWPX, int BM>
 static int launch_wreg(const ConvParams& p, hipStream_t stream) {
-  constexpr int lds = EPI ? 4 * HALF : 2 * HALF;
+  constexpr int lds = (EPI ? 4 : 2) * 4 * BM * 128;
   static bool done = false;
   if (!done) {
-    RS_HIP(hipFuncSetAttribute((const void*)conv1x1_wreg_kernel<EPI, NWPX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    RS_HIP(hipFuncSetAttribute((const void*)conv1x1_wreg_kernel<EPI, NWPX, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     done = true;
   }
   const int groups = p.Cout >> 8, tiles_m = cdiv(p.M, BM);
-  int per_group = rs_device_cu_count() / groups;                 // one workgroup per CU
+  int per_group = rs_device_cu_count() * (64 / BM) / groups;     // one workgroup per CU (two of the 32-pixel form)
   if (per_group < 1) per_group = 1;
   if (per_group > tiles_m) per_group = tiles_m;
-  hipLaunchKernelGGL((conv1x1_wreg_kernel<EPI, NWPX>), dim3((unsigned)(per_group * groups)), dim3(256 * NWPX), lds, stream, p, rs_debug().wreg_dbg);
+  hipLaunchKernelGGL((conv1x1_wreg_kernel<EPI, NWPX, BM>), dim3((unsigned)(per_group * groups)), dim3(256 * NWPX), lds, stream, p, rs_debug().wreg_dbg);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }
 
+// waves: 4 / 8 per workgroup of the 64-pixel form, 2 = the 32-pixel form with two workgroups per CU, 0 = RS_WREG_WAVES
 int launch_conv_wreg(const ConvParams& p, hipStream_t stream, int waves) {
   RS_CHECK(conv_wreg_ok(p) && p.M > 0, RS_ERR_ARG, "conv_wreg: shape outside the kernel's rules");
-  const bool w8 = (waves ? waves : rs_debug().wreg_waves) == 8;
-  if (p.res) return w8 ? launch_wreg<1, 2>(p, stream) : launch_wreg<1, 1>(p, stream);
-  if (p.up) return w8 ? launch_wreg<2, 2>(p, stream) : launch_wreg<2, 1>(p, stream);
-  return w8 ? launch_wreg<0, 2>(p, stream) : launch_wreg<0, 1>(p, stream);
+  const int w = waves ? waves : rs_debug().wreg_waves;
+  if (w == 2) {
+    if (p.res) return launch_wreg<1, 1, 32>(p, stream);
+    if (p.up) return launch_wreg<2, 1, 32>(p, stream);
+    return launch_wreg<0, 1, 32>(p, stream);
+  }
+  const bool w8 = w == 8;
+  if (p.res) return w8 ? launch_wreg<1, 2, 64>(p, stream) : launch_wreg<1, 1, 64>(p, stream);
+  if (p.up) return w8 ? launch_wreg<2, 2, 64>(p, stream) : launch_wreg<2, 1, 64>(p, stream);
+  return w8 ? launch_wreg<0, 2, 64>(p, stream) : launch_wreg<0, 1, 64>(p, stream);
 }

@@ -1460,7 +1460,7 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
                                 "conv_deep_kernel 160x256", "conv_deep_kernel 192x256", "conv_deep_kernel 224x256",
                                 "conv_deep_kernel 64x256", "conv_deep_kernel 96x256", "conv_deep_kernel 128x256",
                                 "stem_pool_kernel (conv 7x7 s2 + ReLU + max-pool 3x3 s2, 8x8 pooled pixels per workgroup)",
-                                "conv1x1_wreg_kernel 64 px x 256 ch (persistent, weights in registers, operand tiles by LDS-DMA)"};
+                                "conv1x1_wreg_kernel 32 px x 256 ch (persistent, weights in registers, operand tiles by LDS-DMA, two workgroups per CU)"};
   const int v = e->stages[i].variant;
   const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 22 ? names[v] : "");
   strncpy(name_out, s, 95);

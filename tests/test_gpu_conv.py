@@ -415,6 +415,6 @@ def test_conv1x1_register_weights_is_bit_identical_to_the_tiled_kernel(gpu_requi
         ref = F.relu(ref)
     a = run_conv(x, w, b, relu=relu, res=res, up=up, variant=14)
     _check_close(a, ref)
-    for variant in (22, 23):            # four waves per workgroup (one per SIMD) / eight
+    for variant in (22, 23, 25, 26):    # the shipped form / 64-pixel tiles with eight waves / 32-pixel tiles, two workgroups per CU / 64-pixel tiles, four waves
         c = run_conv(x, w, b, relu=relu, res=res, up=up, variant=variant)
         assert torch.equal(a, c), f"variant {variant}: {int((a != c).sum())} of {a.numel()} elements differ, max {float((a - c).abs().max())}"

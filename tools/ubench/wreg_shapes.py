@@ -15,10 +15,12 @@ from proj_roadsurf_amd import engine as E
 
 lib = E.load_library(os.environ.get("RS_LIB") or None)
 dev = torch.device("cuda:0")
-variants = [int(v) for v in sys.argv[1:]] or [14, 22, 23]
+variants = [int(v) for v in sys.argv[1:]] or [14, 22, 23, 25]
 B = int(os.environ.get("BATCH", "16"))
 shapes = [("res4.x.conv3 +res", B, 50, 50, 1024, "res"), ("fpn_lateral2 +up", B, 200, 200, 256, "up"), ("fpn_lateral2 plain", B, 200, 200, 256, ""),
-          ("res4.x.conv3 b8", 8, 50, 50, 1024, "res"), ("lateral2 b8 +up", 8, 200, 200, 256, "up"), ("lateral2 b3 +up", 3, 200, 200, 256, "up")]
+          ("res4.x.conv3 b8", 8, 50, 50, 1024, "res"), ("lateral2 b8 +up", 8, 200, 200, 256, "up"), ("lateral2 b3 +up", 3, 200, 200, 256, "up"),
+          ("lateral2 b2 +up", 2, 200, 200, 256, "up"), ("lateral2 b1 +up", 1, 200, 200, 256, "up"), ("res4.x.conv3 b4", 4, 50, 50, 1024, "res"),
+          ("res4.x.conv3 b3", 3, 50, 50, 1024, "res"), ("res4.x.conv3 b2", 2, 50, 50, 1024, "res"), ("res4.x.conv3 b1", 1, 50, 50, 1024, "res")]
 for name, N, H, W, Cout, epi in shapes:
     x = torch.randn(N, H, W, 256, device=dev).half()
     w = (torch.randn(Cout, 256, device=dev) * 0.02).half()
