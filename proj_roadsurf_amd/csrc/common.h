@@ -51,7 +51,7 @@ struct RsDebug {
   int conv_wreg = 1;              // RS_CONV_WREG             0: never the persistent register-weight kernel (variant 22, conv_wreg.hip)
   int stem_small_tile = 1;        // RS_STEM_SMALL_TILE       0: 256x64 stem tile
   int deep_dbg = 0;               // RS_DEEP_DBG              -DRS_DEEP_CEILING builds only
-  int deconv_variant = 14;        // RS_DECONV_VARIANT        tile of the fused deconv + predictor: 128x256 (14), 64x256 (10) or 128x128 (0)
+  int deconv_variant = 22;        // RS_DECONV_VARIANT        kernel of the fused deconv + predictor: conv_wreg (22), or conv_igemm's 128x256 (14), 64x256 (10), 128x128 (0) tile
   int fuse_mask_predictor = 1;    // RS_FUSE_MASK_PREDICTOR
   int side_stream = 1;            // RS_SIDE_STREAM           detection glue on a side stream
   int narrow_roialign = 0;        // RS_NARROW_ROIALIGN
@@ -123,6 +123,7 @@ struct ConvParams {
   const int* dot_cls;   // mode 2: [slots] predicted class
   const int* dot_slot;  // mode 2: [entries] entry -> slot
   float* dot_out;       // mode 2: [slots][2*Ho][2*Wo] logits (without bias), zeroed by the caller
+  int dot_k;            // mode 2: rows of dot_w (classes); 0 = not given (conv_wreg.hip then leaves the layer to conv_igemm)
   // Second activation source appended along K (bottleneck conv3 + projection shortcut in ONE GEMM:
   //   out = relu([W3 | Wsc] * [conv2 out ; block input(stride s)] + b3 + bsc)): after the KH*KW*Cin/64 steps of
   // `in`, Cin2/64 more K steps read pixel (y*stride2, x*stride2) of `in2` (1x1 taps).  Weight row = [K of in | Cin2].

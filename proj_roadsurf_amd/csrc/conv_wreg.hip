@@ -61,7 +61,9 @@ __device__ __forceinline__ Pix pix_add(int x0, int y0, int n0, int rx, int ry, i
   return Pix{x, y, n0 + rn + cy};
 }
 
-// EPI: 0 = bias (+ ReLU) only, 1 = residual (same geometry as the output), 2 = coarser map added at (y/2, x/2) (FPN top-down)
+// EPI: 0 = bias (+ ReLU) only, 1 = residual (same geometry as the output), 2 = coarser map added at (y/2, x/2) (FPN top-down),
+//      3 = the mask head's 2x2 stride-2 transposed convolution + ReLU + predictor 1x1 of the predicted class (ConvParams::mode 2: the four
+//          (dy, dx) groups of 256 rows are the channel groups; nothing but one float per output pixel is written)
 // NWPX: 1 = four waves (one per SIMD, all 64 pixels of the tile each), 2 = eight waves (two per SIMD, 32 pixels each)
 // BM: pixels per tile: 64 (one workgroup per CU), or 32 with NWPX = 1 (half the LDS and a quarter fewer registers: TWO independent workgroups
 // per CU, whose phases -- wait for the tile, MFMAs, epilogue -- then overlap each other's)
@@ -71,16 +73,19 @@ __global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_ker
   constexpr int HALF = 4 * SLICE;                 // 256 channels
   constexpr int NWAVE = 4 * NWPX, NJ = BM / 16 / NWPX;
   constexpr int PASSES = BM / (NWAVE * 8);        // LDS-DMA passes of NWAVE * 8 rows per tile
-  constexpr int TILE = EPI ? 2 * HALF : HALF;     // activations [+ epilogue operand]
-  constexpr int OPS = (EPI ? 8 : 4) * PASSES;     // LDS-DMA pieces a wave issues per tile
+  constexpr bool OPND = EPI == 1 || EPI == 2;     // an epilogue operand is staged next to the activations
+  constexpr int TILE = OPND ? 2 * HALF : HALF;    // activations [+ epilogue operand]
+  constexpr int OPS = (OPND ? 8 : 4) * PASSES;    // LDS-DMA pieces a wave issues per tile
   constexpr int STS = 2 * NJ;                     // stores a wave issues per (full) tile
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * TILE
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wch = wave & 3, wpx = wave >> 2;      // wave = 64 channels x (64 / NWPX) pixels
-  const int M = p.M, Wo = p.Wo, Ho = p.Ho;
+  int Mv = p.M;
+  if (p.m_count) { const long long mc = (long long)(*p.m_count) * p.m_mul; if (mc < Mv) Mv = (int)mc; }    // rows bounded by a device counter (mask head)
+  const int M = Mv, Wo = p.Wo, Ho = p.Ho;
   const int tiles_m = (M + BM - 1) / BM;
-  const int groups = p.Cout >> 8;
+  const int groups = EPI == 3 ? 4 : p.Cout >> 8;
   // XCD-aware order (conv_igemm.hip): workgroups b, b + 8, ... share an XCD; the `groups` workgroups that read one activation tile get
   // consecutive logical ids, i.e. the same XCD's L2
   int L;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_ker
       char* dst = base + (ps * NWAVE * 8 + wave * 8) * 128;
 #pragma unroll
       for (int s = 0; s < 4; ++s) glds16(src + s * 64, dst + s * SLICE);
-      if (EPI) {
+      if (OPND) {
         const half_t* es;
         if (EPI == 1) es = p.res + ((long long)(q.n * p.out_Hp + q.y + p.out_pad) * p.out_Wp + q.x + p.out_pad) * p.out_Cs + n0;
         else es = p.up + ((long long)(q.n * p.up_Hp + (q.y >> 1) + p.up_pad) * p.up_Wp + (q.x >> 1) + p.up_pad) * p.up_Cs + n0;
@@ -166,6 +171,23 @@ __global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_ker
     const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
     bias[i * 2] = f32x2{b4[0], b4[1]}; bias[i * 2 + 1] = f32x2{b4[2], b4[3]};
   }
+  // EPI 3: everything the epilogue looks up -- the predictor's K x 256 weights, and per mask-head entry its slot and predicted class -- goes
+  // into LDS once, so that no ordinary global load (whose compiler-made wait would drain the operand tiles in flight) is left in the loop
+  float* const red = (float*)(smem + 2 * TILE);                   // [3 channel waves][NJ][16] partial sums
+  float* const wcls = red + 256;                                  // [K][256]
+  int* const ent_slot = (int*)(wcls + (EPI == 3 ? p.dot_k : 0) * 256);
+  const int n_ent = EPI == 3 ? p.M / (Ho * Wo) : 0;               // entry capacity
+  int* const ent_cls = ent_slot + n_ent;
+  if constexpr (EPI == 3) {
+    for (int i = tid; i < p.dot_k * 256; i += 256 * NWPX) wcls[i] = p.dot_w[i];
+    const int n_valid = (M + Ho * Wo - 1) / (Ho * Wo);
+    for (int e = tid; e < n_ent; e += 256 * NWPX) {
+      int sl = 0, cl = 0;
+      if (e < n_valid) { sl = p.dot_slot[e]; cl = p.dot_cls[sl]; }
+      ent_slot[e] = sl; ent_cls[e] = cl;
+    }
+    __syncthreads();
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // weights, biases and the first two tiles have landed
   const float lo = -65504.f;
   int x_off[NJ], e_off[NJ];
@@ -181,9 +203,14 @@ __global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_ker
     // k's pieces [iteration k-2], the stores of tile k-2, tile k+1's pieces, the stores of tile k-1 (every tile but a workgroup's last
     // is a full one: the ragged tile is the last of the whole map, hence the last of its workgroup).  Tiles 0 and 1 landed in the prologue.
     if (k >= 2) {
-      const int newer = (k + 1 < ntl ? OPS : 0) + 2 * STS;
-      if (newer == OPS + 2 * STS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS + 2 * STS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STS) : "memory");
+      if (EPI == 3 && wch != 0) {               // the predictor sums leave through channel wave 0 alone (NJ atomics per tile): the others store nothing
+        if (k + 1 < ntl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        constexpr int ST = EPI == 3 ? NJ : STS;
+        if (k + 1 < ntl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS + 2 * ST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST) : "memory");
+      }
     }
     __builtin_amdgcn_s_barrier();           // every wave's pieces of tile k are in LDS
     __builtin_amdgcn_sched_barrier(0);
@@ -208,7 +235,7 @@ __global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_ker
       }
     }
     half8 e0[NJ], e1[NJ];
-    if (EPI) {
+    if (OPND) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         e0[j] = *(const half8*)(sb + e_off[j] + ec0);
@@ -220,8 +247,63 @@ __global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_ker
     __builtin_amdgcn_sched_barrier(0);
     if (k + 2 < ntl) issue_tile((first + (k + 2) * step) * BM, k & 1);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- epilogue (conv_igemm.hip's order: bias, residual, top-down add, ReLU, clamp, fp16)
     const int m0 = (first + k * step) * BM;
+    if constexpr (EPI == 3) {
+      // ---- conv_igemm.hip's mode-2 epilogue, operation for operation (same per-lane dot order, the same shuffles, the same order over the
+      // channel waves, one atomicAdd per output pixel onto the zeroed map): bias, ReLU, dot with the predicted class' 256 weights
+      float dotp[NJ];
+      long long dot_idx[NJ];
+      const int g = grp, cb = wch * 64 + fq * 16;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        dotp[j] = 0.f; dot_idx[j] = -1;
+        const int m = m0 + (wpx * NJ + j) * 16 + fi;
+        if (m >= M) continue;
+        const Pix q = pix_add(ex, ey, en, orx[j], ory[j], orn[j], Wo, Ho);
+        const int oy = 2 * q.y + (g >> 1), ox = 2 * q.x + (g & 1);
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 2 + (r >> 1)][r & 1];
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        const int slot = ent_slot[q.n];
+        const float* wv = wcls + ent_cls[q.n] * 256 + cb;
+        float sdot = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const f32x4 w4 = *(const f32x4*)(wv + i * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sdot += v[i * 4 + r] * w4[r];
+        }
+        dotp[j] = sdot;
+        dot_idx[j] = (long long)slot * (4 * Ho * Wo) + (long long)oy * (2 * Wo) + ox;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float v0 = dotp[j];
+        v0 += __shfl_xor(v0, 16);
+        v0 += __shfl_xor(v0, 32);
+        dotp[j] = v0;
+        if (wch > 0 && fq == 0) red[((wch - 1) * NJ + j) * 16 + fi] = v0;
+      }
+      __syncthreads();                               // (the next tile's sums are written two barriers later)
+      if (wch == 0 && fq == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          float v0 = dotp[j];
+#pragma unroll
+          for (int c = 1; c < 4; ++c) v0 += red[((c - 1) * NJ + j) * 16 + fi];
+          if (dot_idx[j] >= 0) atomicAdd(p.dot_out + dot_idx[j], v0);
+        }
+      }
+      { const Pix nx = pix_add(ex, ey, en, dx, dy, dn, Wo, Ho); ex = nx.x; ey = nx.y; en = nx.n; }
+      continue;
+    }
+    // ---- epilogue (conv_igemm.hip's order: bias, residual, top-down add, ReLU, clamp, fp16)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int m = m0 + (wpx * NJ + j) * 16 + fi;
@@ -234,7 +316,7 @@ __global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_ker
         v[i * 2] = f32x2{acc[i][j][0], acc[i][j][1]} + bias[i * 2];
         v[i * 2 + 1] = f32x2{acc[i][j][2], acc[i][j][3]} + bias[i * 2 + 1];
       }
-      if (EPI) {
+      if (OPND) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] += f32x2{(float)e0[j][2 * r], (float)e0[j][2 * r + 1]};
@@ -265,20 +347,26 @@ __global__ __launch_bounds__(256 * NWPX, BM == 32 ? 2 : 1) void conv1x1_wreg_ker
 // Shapes this kernel takes (conv_choose_variant returns 22 for them): 1x1, stride 1, Cin = 256 = the row pitch, Cout a multiple of 256,
 // fp16 output, at most one of residual / top-down addend, nothing else of ConvParams' options.
 bool conv_wreg_ok(const ConvParams& p) {
-  return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cin == 256 && p.in_Cs == 256 && p.Kpad >= 256 && p.Cout % 256 == 0 && p.mode == 0 && !p.out_f32 &&
-         !p.in2 && !p.m_count && !p.koff && !(p.res && p.up) && !p.down && !p.res32 && !p.mask && p.out_stride <= 1 && !p.head_w && p.nseg == 0 &&
+  const bool common = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cin == 256 && p.in_Cs == 256 && p.Kpad >= 256 && !p.out_f32 && !p.in2 && !p.koff &&
+                      !p.down && !p.res32 && !p.mask && p.out_stride <= 1 && !p.head_w && p.nseg == 0;
+  if (p.mode == 2)      // the mask head's fused deconv + predictor: four (dy, dx) groups of 256 rows
+    return common && p.Cout == 256 && !p.res && !p.up && p.dot_w && p.dot_cls && p.dot_slot && p.dot_out && p.dot_k > 0 && p.Ho * p.Wo > 0 &&
+           (long long)p.dot_k * 1024 + (long long)(p.M / (p.Ho * p.Wo)) * 8 <= 48 * 1024;
+  return common && p.mode == 0 && p.Cout % 256 == 0 && !p.m_count && !(p.res && p.up) &&
          (!p.up || (p.up_Cs % 8 == 0 && p.up_Cs >= p.Cout)) && p.out_Cs % 8 == 0 && p.out_Cs >= p.Cout;
 }
 
 template <int EPI, int NWPX, int BM>
 static int launch_wreg(const ConvParams& p, hipStream_t stream) {
-  constexpr int lds = (EPI ? 4 : 2) * 4 * BM * 128;
+  constexpr int lds_max = ((EPI == 1 || EPI == 2) ? 4 : 2) * 4 * BM * 128 + (EPI == 3 ? 1024 + 48 * 1024 : 0);
   static bool done = false;
   if (!done) {
-    RS_HIP(hipFuncSetAttribute((const void*)conv1x1_wreg_kernel<EPI, NWPX, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    RS_HIP(hipFuncSetAttribute((const void*)conv1x1_wreg_kernel<EPI, NWPX, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     done = true;
   }
-  const int groups = p.Cout >> 8, tiles_m = cdiv(p.M, BM);
+  int lds = ((EPI == 1 || EPI == 2) ? 4 : 2) * 4 * BM * 128;
+  if (EPI == 3) lds += 1024 + p.dot_k * 1024 + (p.M / (p.Ho * p.Wo)) * 8;      // partial sums, class weights, slot + class per entry
+  const int groups = EPI == 3 ? 4 : p.Cout >> 8, tiles_m = cdiv(p.M, BM);
   int per_group = rs_device_cu_count() * (64 / BM) / groups;     // one workgroup per CU (two of the 32-pixel form)
   if (per_group < 1) per_group = 1;
   if (per_group > tiles_m) per_group = tiles_m;
@@ -291,6 +379,7 @@ static int launch_wreg(const ConvParams& p, hipStream_t stream) {
 int launch_conv_wreg(const ConvParams& p, hipStream_t stream, int waves) {
   RS_CHECK(conv_wreg_ok(p) && p.M > 0, RS_ERR_ARG, "conv_wreg: shape outside the kernel's rules");
   const int w = waves ? waves : rs_debug().wreg_waves;
+  if (p.mode == 2) return w == 4 ? launch_wreg<3, 1, 64>(p, stream) : launch_wreg<3, 1, 32>(p, stream);      // the mask head's deconv + predictor
   if (w == 2) {
     if (p.res) return launch_wreg<1, 1, 32>(p, stream);
     if (p.up) return launch_wreg<2, 1, 32>(p, stream);

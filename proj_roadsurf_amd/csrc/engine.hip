@@ -981,6 +981,7 @@ int rs_engine::build() {
       // tile) is never written; a small kernel then adds the class bias and applies the sigmoid in place.
       dp.mode = 2; dp.out = nullptr;
       dp.dot_w = (const float*)pw->dev; dp.dot_cls = det_classes; dp.dot_slot = slot_list; dp.dot_out = mask_probs;
+      dp.dot_k = (int)pw->dims[0];
       const int glds = use_glds, Dc = D;
       float* probs = mask_probs;
       const size_t zero_per_tile = (size_t)D * RS_MASK_SIDE * RS_MASK_SIDE * 4;
@@ -991,7 +992,10 @@ int rs_engine::build() {
       st.fn = [dp, per_roi, Dc, glds, probs, zero_per_tile](int n, hipStream_t s) mutable {
         RS_HIP(hipMemsetAsync(probs, 0, zero_per_tile * n, s));
         dp.M = n * Dc * per_roi;
-        return launch_conv(dp, s, rs_debug().deconv_variant, glds);      // 64x256 tile: one workgroup holds all 256 channels of a (dy,dx) group
+        // conv_wreg.hip (22: persistent, a (dy, dx) group's weights in registers) or conv_igemm's tile where one workgroup holds all 256
+        // channels of a group (14 / 10); the two give the same bits
+        const int dv = rs_debug().deconv_variant;
+        return launch_conv(dp, s, (dv == 22 && !(rs_debug().conv_wreg && glds > 0)) ? 14 : dv, glds);
       };
       stages.push_back(st);
       MaskPredictParams mp;

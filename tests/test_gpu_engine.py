@@ -682,6 +682,33 @@ def test_merged_level_launches_and_split_tail_change_no_bit(gpu_required, monkey
         assert r["frac_matched"] >= 0.9, r
 
 
+def test_mask_predictor_in_the_register_weight_kernel_changes_no_bit(gpu_required, monkeypatch):
+    """The mask head's deconv + ReLU + predictor runs in conv_wreg.hip (EPI 3: persistent workgroups, one (dy, dx) group's 256 x 256
+    weights in registers, the rows bounded by the device-side detection count) instead of conv_igemm's 128 x 256 tile
+    (RS_DECONV_VARIANT=14).  Same per-lane dot order, same shuffles, same order over the channel waves: the mask logits and the
+    pasted masks are BIT-identical, on a full batch and on a batch whose detections do not fill a tile."""
+    spec = EngineSpec(num_classes=2, min_size_test=512, max_size_test=853)
+    W = synthetic_weights(spec, seed=0)
+    tiles = synthetic_tiles(5, 512, 512, 3, seed=777)
+
+    def run(n):
+        eng = Engine(spec, W, (512, 512, 3), max_batch=5)
+        try:
+            dets = eng.infer(tiles[:n])
+            return dets, eng.tensor("mask_probs").copy(), dict(eng.stage_variants())
+        finally:
+            eng.close()
+    for n in (5, 1):
+        d1, p1, v1 = run(n)
+        assert v1["mask.deconv_predict"] == 22
+        monkeypatch.setenv("RS_DECONV_VARIANT", "14")
+        d0, p0, v0 = run(n)
+        monkeypatch.delenv("RS_DECONV_VARIANT")
+        assert v0["mask.deconv_predict"] == 14
+        assert float(np.abs(p0).max()) > 0 and np.array_equal(p0, p1), f"batch {n}: {int((p0 != p1).sum())} mask probabilities differ"
+        assert all(_same_instances(a, b) for a, b in zip(d0, d1)) and all(len(d) > 0 for d in d1)
+
+
 def test_every_batch_size_gives_the_same_detections(gpu_required):
     """The tile dispatch, the split last round of conv_deep, the multi-map launches and the tile heights all depend on the batch
     size.  Every batch size from 1 to 16 must give each tile the detections it gets alone, bit for bit."""

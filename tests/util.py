@@ -55,5 +55,5 @@ def conv_stage_shapes(spec, net_h=800, net_w=800):
         mr, d = spec.mask_pooler_resolution, spec.detections_per_image
         for i in range(spec.mask_num_conv):
             out.append((f"mask.fcn{i + 1}", d * mr * mr, 256, 3, 256, 0, None))
-        out.append(("mask.deconv_predict", d * mr * mr, 256, 1, 256, 0, 14))
+        out.append(("mask.deconv_predict", d * mr * mr, 256, 1, 256, 0, 22))     # csrc/conv_wreg.hip, EPI 3
     return out
