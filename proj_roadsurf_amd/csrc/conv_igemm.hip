@@ -592,7 +592,8 @@ int launch_conv(const ConvParams& p_in, hipStream_t stream, int force_variant, i
   }
   if (p.in2) RS_CHECK(!smallc && p.mode == 0 && p.Cin2 % 64 == 0 && p.Cin2 > 0 && p.stride2 >= 1, RS_ERR_ARG, "conv: bad second K source (Cin2 %d)", p.Cin2);
   const int rows = p.Cout * (p.mode != 0 ? 4 : 1);
-  const int v = conv_choose_variant(p, force_variant, use_glds);
+  int v = conv_choose_variant(p, force_variant, use_glds);
+  if (v == 22 && p.mode == 2 && !conv_wreg_ok(p)) v = 14;     // the fused mask predictor beyond conv_wreg's LDS budget (thousands of entries): conv_igemm's tile
   RS_CHECK(!(train_opts && (p.mode != 0 || (v == 12 && p.out_stride > 1) || (v >= 15 && v <= 20))), RS_ERR_UNSUPPORTED, "conv: training epilogue options need mode 0 (and no scatter on conv_deep)");
   if (v == 22 || v == 23 || v == 25 || v == 26) {   // persistent 1x1 with the weights in registers (conv_wreg.hip): 22 = the form that ships (RS_WREG_WAVES,
     // default 32-pixel tiles with two workgroups per CU), 25 = that form by name, 26 / 23 = 64-pixel tiles with four / eight waves
