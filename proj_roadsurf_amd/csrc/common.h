@@ -46,7 +46,7 @@ struct RsDebug {
   int conv_tuned = 1;             // RS_CONV_TUNED            0: first-round tile rule (128x128 / 256x64 only)
   int conv_deep = 1;              // RS_CONV_DEEP             0: conv_igemm 256x256 instead of conv_deep
   int conv_wide_px = 128;         // RS_CONV_WIDE_PX          pixels of the all-256-channel tile of the HBM-bound 1x1 layers: 128 (variant 14) or 64 (10)
-  int wreg_dbg = 0;               // RS_WREG_DBG              conv_wreg timing ablations (1: no stores, 2: no MFMAs ... results wrong)
+  int wreg_dbg = 0;               // RS_WREG_DBG              conv_wreg timing ablations (bit 0: no epilogue / stores, bit 2: no operand loads; results wrong)
   int wreg_waves = 2;             // RS_WREG_WAVES            conv_wreg form: 2 = 32-pixel tiles, two workgroups of four waves per CU (ships); 4 / 8 = 64-pixel tiles, one workgroup of four / eight waves
   int conv_wreg = 1;              // RS_CONV_WREG             0: never the persistent register-weight kernel (variant 22, conv_wreg.hip)
   int stem_small_tile = 1;        // RS_STEM_SMALL_TILE       0: 256x64 stem tile

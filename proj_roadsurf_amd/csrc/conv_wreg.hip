@@ -1,5 +1,6 @@
-// 1x1 convolution 256 -> 256 g (g = Cout / 256) for the HBM-bound shallow-K layers on big maps (fpn_lateral2; res4.x.conv3 qualifies by
-// shape): PERSISTENT workgroups with the weights in REGISTERS and the whole LDS given to operand tiles in flight.  Variant 22.
+// 1x1 convolution 256 -> 256 g (g = Cout / 256) for the shallow-K layers on big maps -- fpn_lateral2, res4.x.conv3 (HBM-bound) and the mask
+// head's 2x2 transposed convolution + predictor (four groups of 256 rows, EPI 3): PERSISTENT workgroups with the weights in REGISTERS and the
+// whole LDS given to operand tiles in flight.  Variant 22.
 //
 // What bounds these layers in conv_igemm's 128 x 256 tile (variant 14): K = 256 is four K steps; a workgroup stages 16 KB of
 // activations (HBM) and 32 KB of weights (L2) per step into its single 48 KB buffer, three workgroups per CU -- so at most 48 KB of
