@@ -69,7 +69,13 @@ typedef struct rs_spec {
   float mask_threshold;           /* detector_postprocess default 0.5 */
   float scale_clamp;              /* Box2BoxTransform: log(1000/16) */
   int32_t precision;              /* 0 = production (fp16 operands, fp32 accumulate on MFMA); 1 = fp32 validation mode:
-                                     every conv/linear layer in plain fp32 (slow), needs "<layer>.w32" blob entries */
+                                     every conv/linear layer in fp32 on the fp32 matrix cores, needs "<layer>.w32" blob entries;
+                                     2 = SPLIT OPERANDS (inference engines): reference-equivalent arithmetic on the fp16 matrix
+                                     cores -- every GEMM operand as hi + lo fp16 planes (22 significand bits), three products
+                                     (hi.hi, hi.lo, lo.hi) into one fp32 accumulator, activations stored as two planes; needs
+                                     "<layer>.ws" (fp16 [2][rows][Kpad]: hi rows then lo rows of the weight scaled by a power
+                                     of two per row) and "<layer>.wsi" (fp32 [rows]: the inverse scales) blob entries.  The
+                                     reference computes in fp32 (no SOLVER.AMP key, R:config/detectron2_config_3bands.yaml:268-305) */
 } rs_spec;
 
 /* Caller-allocated result block for n tiles, D = detections_per_image slots per tile.
@@ -167,7 +173,8 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out);
 /* Tile-variant number of the stage's last call (-2 = not a GEMM stage, -1 = fp32 kernel; numbering: rs_op_conv_variant). */
 int rs_engine_stage_variant(rs_engine* e, int i);
 
-/* Intermediate tensors by name (parity tests): device pointer, dtype (1 f16, 2 f32, 3 i32, 4 u8),
+/* Intermediate tensors by name (parity tests): device pointer, dtype (1 f16, 2 f32, 3 i32, 4 u8, 5 = two fp16 planes of the
+ * given shape back to back, value = plane 0 + plane 1: activations of precision 2),
  * up to 5 dims (dims[ndim..] = 1) and the spatial halo of NHWC activations. */
 int rs_engine_tensor(rs_engine* e, const char* name, void** dev_ptr, int* dtype, int* ndim, int64_t dims[5], int* halo);
 int rs_engine_tensor_count(rs_engine* e);
@@ -221,6 +228,14 @@ int rs_op_conv_variant(int m, int cin, int k, int cout, int cin2, int deconv2x, 
  * workgroup that rs_op_conv2d's 256x256 deep-prefetch kernel fills with {shader clocks, 100 MHz ticks} spent in its K loop.
  * No effect in the production build. */
 int rs_debug_set_conv_probe(void* buffer);
+
+/* rs_op_conv2d in the split-operand precision mode (rs_spec.precision == 2): `in`, `w`, `out`, `residual`, `upsample_add` point to
+ * the hi plane of an fp16 tensor whose lo plane lies `*_lo` ELEMENTS behind it (value = hi + lo); w holds the weight rows scaled
+ * by a power of two per row, wscale[rows] the inverse scales.  out_f32 = 1: one fp32 output as in rs_op_conv2d. */
+int rs_op_conv2d_split(const void* in, int64_t in_lo, const void* w, int64_t w_lo, const float* wscale, const float* bias, void* out, int64_t out_lo,
+                       const void* residual, int64_t res_lo, const void* upsample_add, int64_t up_lo,
+                       int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
+                       int out_halo, int relu, int out_f32, int deconv2x, int variant, void* stream);
 
 /* Bottleneck output with a projection shortcut as ONE GEMM over two activation sources:
  *   out = act( conv_khxkw(in; W[:, :kh*kw*cin]) + conv_1x1_stride2(in2; W[:, kh*kw*cin:]) + bias )

@@ -92,6 +92,8 @@ struct ConvSeg {
   int Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp;
   int M;         // rows of this map (set per launch: images * Ho * Wo)
   int tile0;     // first logical tile of this map (set per launch)
+  long long in_lo, out_lo;   // split-operand mode (ConvParams::split): element offsets of the lo planes of this map's input / output
+  const float* wscale;       // ... and the per-row weight descale of this map's filter
 };
 #define RS_MAX_SEGS 5
 
@@ -149,6 +151,15 @@ struct ConvParams {
   int nseg;             // > 0: multi-map launch (launch_conv_deep_multi); in / w / bias / out / geometry / M come from seg[]
   int seg_tiles;        // total logical tiles of all maps
   int tail_tiles;       // conv_deep: this many of the LAST logical tiles run as two 128-pixel tiles each (set by the launcher's tail rule)
+  // ---- split-operand mode (rs_spec.precision == 2): every fp16 tensor is TWO planes, x = hi + lo with
+  // hi = fp16(x), lo = fp16(x - hi) (22 significand bits), the lo plane `*_lo` ELEMENTS behind the hi plane.  The GEMM runs three
+  // passes per 64-channel slice -- W_hi.X_hi, W_hi.X_lo, W_lo.X_hi (the lo.lo term, <= 2^-22 of the product, is dropped) -- into the
+  // same fp32 accumulators; weight rows are pre-scaled by a power of two per row (so that their lo parts stay fp16-normal) and the
+  // epilogue multiplies the accumulator by wscale[row] (the inverse, exact) before the bias.  Outputs are written as hi / lo planes;
+  // res / up are read as hi + lo.  fp32 outputs (out_f32, mode 2) as in the fp16 mode.
+  int split;
+  long long in_lo, w_lo, out_lo, res_lo, up_lo, in2_lo;
+  const float* wscale;  // [rows] fp32, power of two
   ConvSeg seg[RS_MAX_SEGS];
 };
 
@@ -228,13 +239,17 @@ struct PreprocParams {
   int ksh, ksv;
   int need_h, need_v;
   int flip;               // 1: model channel c reads source channel C-1-c
-  int out_f32;            // fp32 validation mode: out is float
+  int out_f32;            // fp32 validation mode: out is float; 2 = split-operand mode: out is the hi plane, the lo plane out_lo elements behind it
+  long long out_lo;
   float mean[4], stdv[4];
 };
 int launch_preprocess(const PreprocParams& p, hipStream_t s);
 int launch_maxpool(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_subsample2(const half_t* in, half_t* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
+// split-operand mode: in / out are hi planes, the lo planes in_lo / out_lo elements behind them
+int launch_maxpool_split(const half_t* in, long long in_lo, half_t* out, long long out_lo, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
+int launch_subsample2_split(const half_t* in, long long in_lo, half_t* out, long long out_lo, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s);
 int launch_conv_f32(const ConvParams& p, hipStream_t stream, int force_valu = 0, int tile = 0);   // ref_f32.hip: fp32 MFMA (or the VALU cross-check)
 int launch_conv_deep(const ConvParams& p, hipStream_t stream, int tile_px = 256);

@@ -30,10 +30,14 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
 
 // One tile: NJ * 32 pixels x 256 channels.  TRAIN: instantiation with the backward-epilogue options down / res32 / mask (conv_igemm.hip),
 // compiled out of the inference kernel
-template <int DBG, bool TRAIN, int NJ>
+// SPLIT: the split-operand precision mode (ConvParams::split, common.h): the K walk makes three passes per 64-channel slice (W_hi.X_hi, W_hi.X_lo,
+// W_lo.X_hi -- plane offsets added to the staged addresses, nothing else in the loop changes), the epilogue descales by the row's power of two and
+// writes hi / lo planes.
+template <int DBG, bool TRAIN, int NJ, bool SPLIT>
 __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, const half_t* g_in, const half_t* g_w, const float* g_bias, void* g_out,
                                                float* g_head_out, const int Ho, const int Wo, const int in_Hp, const int in_Wp, const int out_Hp, const int out_Wp,
-                                               const int M, const int m0, const int n0, const int q) {
+                                               const int M, const int m0, const int n0, const int q, const long long in_lo, const long long out_lo,
+                                               const float* g_wscale) {
   constexpr int APS = (NJ + 1) / 2;    // activation staging passes of 64 rows = LDS-DMA pieces per wave and stage (odd NJ: the upper half of the
                                        // last pass lands in LDS rows nothing reads -- every wave issues the same number of pieces, so one counted wait serves all)
   constexpr int WPX = NJ * 16;         // pixels per wave
@@ -65,14 +69,20 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
     const int key = (row & 3) | (((row >> 4) & 1) << 2);
     wptr[ps] = g_w + (long long)(n0 + row) * p.Kpad + (lchk ^ key) * 8;
   }
-  const int nk = p.KH * p.KW * (p.Cin >> 6);
+  const int nk = (SPLIT ? 3 : 1) * p.KH * p.KW * (p.Cin >> 6);
 
   // two independent walkers over the K steps (64-channel slice outer, taps inner -- conv_igemm.hip): the
   // activation walker runs one step ahead of the weight walker
   int akh = 0, akw = 0, ac0 = 0, an = 0;      // an = index of the next activation step to issue
+  int apass = 0, wpass = 0;                   // SPLIT: order (slice outer, pass, taps inner), as conv_igemm.hip
   auto stage_a = [&]() {
-    const int off = (akh * in_Wp + akw) * p.in_Cs + ac0;
-    if (++akw == p.KW) { akw = 0; if (++akh == p.KH) { akh = 0; ac0 += 64; } }
+    long long off = (akh * in_Wp + akw) * p.in_Cs + ac0;
+    if constexpr (SPLIT) {
+      if (apass == 1) off += in_lo;
+      if (++akw == p.KW) { akw = 0; if (++akh == p.KH) { akh = 0; if (++apass == 3) { apass = 0; ac0 += 64; } } }
+    } else {
+      if (++akw == p.KW) { akw = 0; if (++akh == p.KH) { akh = 0; ac0 += 64; } }
+    }
     char* abase = smem + (an % 3) * ASTAGE;
     ++an;
     if (DBG & 1) return;   // ceiling experiment: no global traffic
@@ -82,8 +92,13 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
   };
   int wkh = 0, wkw = 0, wc0 = 0, wn = 0;
   auto stage_w = [&]() {
-    const int koff = (wkh * p.KW + wkw) * p.Cin + wc0;
-    if (++wkw == p.KW) { wkw = 0; if (++wkh == p.KH) { wkh = 0; wc0 += 64; } }
+    long long koff = (wkh * p.KW + wkw) * p.Cin + wc0;
+    if constexpr (SPLIT) {
+      if (wpass == 2) koff += p.w_lo;
+      if (++wkw == p.KW) { wkw = 0; if (++wkh == p.KH) { wkh = 0; if (++wpass == 3) { wpass = 0; wc0 += 64; } } }
+    } else {
+      if (++wkw == p.KW) { wkw = 0; if (++wkh == p.KH) { wkh = 0; wc0 += 64; } }
+    }
     char* wbase = smem + W_BASE + (wn & 1) * WSTAGE;
     ++wn;
     if (DBG & 1) return;
@@ -226,7 +241,15 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
     const f32x4 b4 = *(const f32x4*)(g_bias + crow + i * 4);
     bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
   }
-  if (!TRAIN && p.head_w) {
+  float wsc[SPLIT ? 16 : 1];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const f32x4 s4 = *(const f32x4*)(g_wscale + crow + i * 4);
+      wsc[i * 4 + 0] = s4[0]; wsc[i * 4 + 1] = s4[1]; wsc[i * 4 + 2] = s4[2]; wsc[i * 4 + 3] = s4[3];
+    }
+  }
+  if (!TRAIN && !SPLIT && p.head_w) {
     // Fused 16-row 1x1 head on top of this convolution (RPN: objectness + anchor deltas): the 256-channel output tile never leaves
     // the CU.  relu(acc + bias), rounded to fp16 exactly as the store would round it, is per lane 16 consecutive channels of a
     // pixel = the B operand of two 32-deep MFMA steps when the head's K columns are stored in the chaining order (weights.py
@@ -286,14 +309,23 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (SPLIT) v[i * 4 + r] = acc[i][j][r] * wsc[i * 4 + r] + bias[i * 4 + r];
+        else v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+      }
     if (p.res) {
       const half_t* rp = p.res + opix * p.out_Cs + crow;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const half4 h = *(const half4*)(rp + i * 4);
+        if constexpr (SPLIT) {
+          const half4 l = *(const half4*)(rp + p.res_lo + i * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r] + (float)l[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+        }
       }
     }
     if (p.up) {
@@ -302,8 +334,14 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const half4 h = *(const half4*)(up + i * 4);
+        if constexpr (SPLIT) {
+          const half4 l = *(const half4*)(up + p.up_lo + i * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r] + (float)l[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+        }
       }
     }
     if (TRAIN && p.down) {        // backward of the nearest 2x upsample: add the 2x2 block of the finer gradient map
@@ -349,14 +387,16 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
       half_t* op = (half_t*)g_out + opix * p.out_Cs + crow;
 #pragma unroll
       for (int i = 0; i < MI; i += 2) {
-        half8 h;
+        half8 h, l;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           float f = v[i * 4 + r];
           f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
           h[r] = (half_t)f;
+          if constexpr (SPLIT) l[r] = (half_t)(f - (float)h[r]);
         }
         *(half8*)(op + i * 4) = h;
+        if constexpr (SPLIT) *(half8*)(op + out_lo + i * 4) = l;
       }
     }
   }
@@ -369,7 +409,7 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
 // NJF: 16-pixel blocks per wave of a whole tile = tile height / 32 pixels.  8 (256 pixels) is the production tile; 5 / 6 / 7 (160 / 192 /
 // 224 pixels) exist for maps whose pixel count fills the 256 CUs badly in 256-pixel tiles (50 x 50 x 16 images = 40 000 pixels: 157 tiles
 // = 0.61 of a round; 250 tiles of 160 pixels = 0.98 of one) -- launch_conv variants 15 / 16 / 17.
-template <int DBG, bool TRAIN = false, int NJF = 8>
+template <int DBG, bool TRAIN = false, int NJF = 8, bool SPLIT = false>
 __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   constexpr int BM = 32 * NJF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -389,6 +429,8 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
   const float* g_bias = p.bias;
   void* g_out = p.out;
   float* g_head_out = p.head_out;
+  long long in_lo = p.in_lo, out_lo = p.out_lo;
+  const float* g_wscale = p.wscale;
   int Ho = p.Ho, Wo = p.Wo, in_Hp = p.in_Hp, in_Wp = p.in_Wp, out_Hp = p.out_Hp, out_Wp = p.out_Wp;
   int L, half = -1;
   if (q < nfull) {
@@ -406,16 +448,17 @@ __global__ __launch_bounds__(NT) void conv_deep_kernel(const ConvParams p) {
         g_in = p.seg[i].in; g_w = p.seg[i].w; g_bias = p.seg[i].bias; g_out = p.seg[i].out; g_head_out = p.seg[i].head_out;
         Ho = p.seg[i].Ho; Wo = p.seg[i].Wo; in_Hp = p.seg[i].in_Hp; in_Wp = p.seg[i].in_Wp;
         out_Hp = p.seg[i].out_Hp; out_Wp = p.seg[i].out_Wp; M = p.seg[i].M; t0 = p.seg[i].tile0;
+        if constexpr (SPLIT) { in_lo = p.seg[i].in_lo; out_lo = p.seg[i].out_lo; g_wscale = p.seg[i].wscale; }
       }
     L -= t0;
   }
   const int n0 = (L % tiles_n) * BN;
   const int m0 = (L / tiles_n) * BM;
   if (half < 0 || NJF != 8) {
-    conv_deep_tile<DBG, TRAIN, NJF>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0, n0, q);
+    conv_deep_tile<DBG, TRAIN, NJF, SPLIT>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0, n0, q, in_lo, out_lo, g_wscale);
   } else {
     if (m0 + half * (BM / 2) >= M) return;                     // second half of a partial last tile: nothing to do (workgroup-uniform)
-    conv_deep_tile<DBG, TRAIN, NJF == 8 ? 4 : NJF>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0 + half * (BM / 2), n0, q);
+    conv_deep_tile<DBG, TRAIN, NJF == 8 ? 4 : NJF, SPLIT>(p, smem, g_in, g_w, g_bias, g_out, g_head_out, Ho, Wo, in_Hp, in_Wp, out_Hp, out_Wp, M, m0 + half * (BM / 2), n0, q, in_lo, out_lo, g_wscale);
   }
 }
 
@@ -451,11 +494,18 @@ static int launch_deep_nj(ConvParams& p, hipStream_t stream) {
   static bool done = false;
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, NJF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    if constexpr (NJF >= 5) RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, NJF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     done = true;
   }
   const long long nblk = (long long)(p.Cout / BN) * cdiv(p.M, 32 * NJF);
   RS_CHECK(nblk < (1ll << 30), RS_ERR_ARG, "conv_deep: grid too large");
   p.tail_tiles = 0;
+  if (p.split) {
+    if constexpr (NJF >= 5) hipLaunchKernelGGL((conv_deep_kernel<0, false, NJF, true>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
+    else RS_CHECK(false, RS_ERR_UNSUPPORTED, "conv_deep: the split-operand mode has the 160 .. 256-pixel tiles only");
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+  }
   hipLaunchKernelGGL((conv_deep_kernel<0, false, NJF>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
@@ -471,6 +521,7 @@ int launch_conv_deep(const ConvParams& p0, hipStream_t stream, int tile_px) {
   RS_CHECK(!p.head_w || (p.Cout == BN && p.head_b && p.head_out && !p.res && !p.up && !p.down && !p.res32 && !p.mask), RS_ERR_ARG,
            "conv_deep: the fused head needs Cout == 256, its bias and output, and no other epilogue option");
   RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
+  RS_CHECK(!p.split || (p.wscale && !p.head_w && !p.down && !p.res32 && !p.mask), RS_ERR_UNSUPPORTED, "conv_deep: the split-operand mode needs the row scales and has no fused head / training epilogue");
   if (tile_px != 256) {
     RS_CHECK(tile_px >= 64 && tile_px <= 224 && tile_px % 32 == 0 && !p.down && !p.res32 && !p.mask, RS_ERR_ARG,
              "conv_deep: tile height %d (256, or 64 .. 224 in steps of 32 without training epilogue options)", tile_px);
@@ -488,6 +539,7 @@ int launch_conv_deep(const ConvParams& p0, hipStream_t stream, int tile_px) {
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 #ifdef RS_DEEP_CEILING
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -524,7 +576,8 @@ int launch_conv_deep(const ConvParams& p0, hipStream_t stream, int tile_px) {
   if (dbg == 17) { hipLaunchKernelGGL(conv_deep_kernel<17>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p); return RS_OK; }
 #endif
   (void)dbg;
-  if (p.down || p.res32 || p.mask) hipLaunchKernelGGL((conv_deep_kernel<0, true>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
+  if (p.split) hipLaunchKernelGGL((conv_deep_kernel<0, false, 8, true>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
+  else if (p.down || p.res32 || p.mask) hipLaunchKernelGGL((conv_deep_kernel<0, true>), dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
   else hipLaunchKernelGGL(conv_deep_kernel<0>, dim3((unsigned)nblk), dim3(NT), LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());
   return RS_OK;
@@ -543,6 +596,7 @@ int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const 
   long long tiles = 0;
   for (int i = 0; i < nseg; ++i) {
     RS_CHECK(segs[i].in && segs[i].w && segs[i].bias && segs[i].out && m_per_image[i] > 0, RS_ERR_ARG, "conv_deep_multi: map %d incomplete", i);
+    RS_CHECK(!common.split || segs[i].wscale, RS_ERR_ARG, "conv_deep_multi: map %d has no row scales (split-operand mode)", i);
     p.seg[i] = segs[i];
     p.seg[i].M = images * m_per_image[i];
     p.seg[i].tile0 = (int)tiles;
@@ -560,7 +614,14 @@ int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const 
   static bool done = false;
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     done = true;
+  }
+  if (p.split) {
+    RS_CHECK(!p.head_w, RS_ERR_UNSUPPORTED, "conv_deep_multi: no fused head in the split-operand mode");
+    hipLaunchKernelGGL((conv_deep_kernel<0, false, 8, true>), dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, p);
+    RS_HIP(hipGetLastError());
+    return RS_OK;
   }
   hipLaunchKernelGGL(conv_deep_kernel<0>, dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, p);
   RS_HIP(hipGetLastError());

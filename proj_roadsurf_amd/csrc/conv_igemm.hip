@@ -40,7 +40,9 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
 // TRAIN: instantiation with the backward-epilogue options (down / res32 / mask / out_stride).  They are compiled out of the
 // inference instantiations: carrying them as run-time branches cost the small-tile, occupancy-sensitive layers 20-70 %
 // (measured: fused deconv 0.33 -> 0.58 ms, fpn_lateral2 0.24 -> 0.35 ms, 1760 -> 1530 tiles/s end to end).
-template <int WPX, int WCH, int MI, int NJ, bool SMALLC, bool GLDS, bool PERSIST, bool TRAIN = false>
+// SPLIT: the split-operand precision mode (ConvParams::split, common.h): three passes per 64-channel slice over the hi / lo planes of both
+// operands, per-row weight descale in the epilogue, outputs written as hi / lo planes.  Compiled out of the fp16 instantiations.
+template <int WPX, int WCH, int MI, int NJ, bool SMALLC, bool GLDS, bool PERSIST, bool TRAIN = false, bool SPLIT = false>
 __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvParams p) {
   using T = Tile<WPX, WCH, MI, NJ>;
   constexpr int NW = T::NW, BM = T::BM, BN = T::BN;
@@ -114,7 +116,8 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     }
   };
 
-  const int nk = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> 6) + (p.in2 ? (p.Cin2 >> 6) : 0));
+  const int nkb = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> 6) + (p.in2 ? (p.Cin2 >> 6) : 0));
+  const int nk = SPLIT ? 3 * nkb : nkb;
   const int nst = p.stages == 1 ? 1 : 2;   // LDS K-step buffers: 1 = shallow-K layers (more workgroups per CU)
   int* koff_s = (int*)(smem + nst * T::STAGE);
   if constexpr (SMALLC) {
@@ -123,9 +126,16 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   }
 
   int w_koff = 0;               // element offset of the current K step inside a weight row (set by next_off())
+  long long a_pl = 0, w_pl = 0; // SPLIT: plane offsets (elements) of the current K step's operands (0 = hi plane)
   auto stage = [&](int buf, int t, int a_off) {
     char* abase = smem + buf * T::STAGE;
     char* wbase = abase + BM * 128;
+    if constexpr (SPLIT && SMALLC) {      // the stem: pass outermost (hi.hi, hi.lo, lo.hi over the whole padded K)
+      const int pass = t / nkb;
+      t -= pass * nkb;
+      a_pl = pass == 1 ? p.in_lo : 0;
+      w_pl = pass == 2 ? p.w_lo : 0;
+    }
 #pragma unroll
     for (int ps = 0; ps < PA; ++ps) {
       const half_t* g;
@@ -134,6 +144,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       } else {
         g = aptr[ps] + a_off;
       }
+      if constexpr (SPLIT) g += a_pl;
       char* dst = abase + (ps * NW * 8 + wave * 8) * 128;
       if constexpr (GLDS) {
         glds16(g, dst);
@@ -145,6 +156,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     for (int ps = 0; ps < PW; ++ps) {
       if (ps * NW * 8 + wave * 8 < BN) {   // wave-uniform
         const half_t* g = wptr[ps] + (SMALLC ? t * 64 : w_koff);
+        if constexpr (SPLIT) g += w_pl;
         char* dst = wbase + (ps * NW * 8 + wave * 8) * 128;
         if constexpr (GLDS) {
           glds16(g, dst);
@@ -171,6 +183,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   const int c1_off = ((4 + fq) ^ fkey) * 16;    // kk = 1
 
   int kh = 0, kw = 0, c0 = 0;   // position of the NEXT K step to stage
+  int pass = 0;                 // SPLIT: 0 = W_hi.X_hi, 1 = W_hi.X_lo, 2 = W_lo.X_hi; order (slice outer, pass, taps inner)
   // K-step order: 64-channel slice OUTER, filter taps INNER.  All KH*KW taps of one channel slice touch the
   // same ~(rows+2) x W x 128 B of the input, so a tile's live footprint between re-reads is 1/(Cin/64) of the
   // taps-outer order and stays L2-resident (256-ch 3x3 @200x200: 85 KB instead of 338 KB per tile, 32 tiles
@@ -180,14 +193,31 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       if (c0 == p.Cin) setup_acts(true);     // the first source's pointers are dead from here on: reuse the registers
       const int off = c0 - p.Cin;
       w_koff = p.KH * p.KW * p.Cin + off;
-      c0 += 64;
+      if constexpr (SPLIT) {
+        a_pl = pass == 1 ? p.in2_lo : 0;
+        w_pl = pass == 2 ? p.w_lo : 0;
+        if (++pass == 3) { pass = 0; c0 += 64; }
+      } else {
+        c0 += 64;
+      }
       return off;
     }
     const int off = (kh * p.in_Wp + kw) * p.in_Cs + c0;
     w_koff = (kh * p.KW + kw) * p.Cin + c0;
+    if constexpr (SPLIT) {
+      a_pl = pass == 1 ? p.in_lo : 0;
+      w_pl = pass == 2 ? p.w_lo : 0;
+    }
     if (++kw == p.KW) {
       kw = 0;
-      if (++kh == p.KH) { kh = 0; c0 += 64; }
+      if (++kh == p.KH) {
+        kh = 0;
+        if constexpr (SPLIT) {
+          if (++pass == 3) { pass = 0; c0 += 64; }
+        } else {
+          c0 += 64;
+        }
+      }
     }
     return off;
   };
@@ -230,7 +260,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
           stage((gs + 1) & 1, t + 1, SMALLC ? 0 : next_off());
         } else if (PERSIST && q + G < ntiles) {     // last K step of this tile: start on the next tile
           setup_tile(q + G);
-          kh = 0; kw = 0; c0 = 0;
+          kh = 0; kw = 0; c0 = 0; pass = 0;
           stage((gs + 1) & 1, 0, SMALLC ? 0 : next_off());
         }
       }
@@ -291,6 +321,14 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       const f32x4 b4 = *(const f32x4*)(p.bias + crow + i * 4);
       bias[i * 4 + 0] = b4[0]; bias[i * 4 + 1] = b4[1]; bias[i * 4 + 2] = b4[2]; bias[i * 4 + 3] = b4[3];
     }
+    float wsc[SPLIT ? 4 * MI : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const f32x4 s4 = *(const f32x4*)(p.wscale + crow + i * 4);
+        wsc[i * 4 + 0] = s4[0]; wsc[i * 4 + 1] = s4[1]; wsc[i * 4 + 2] = s4[2]; wsc[i * 4 + 3] = s4[3];
+      }
+    }
     float dotp[NJ];
     long long dot_idx[NJ];
 #pragma unroll
@@ -311,14 +349,23 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (SPLIT) v[i * 4 + r] = acc[i][j][r] * wsc[i * 4 + r] + bias[i * 4 + r];
+          else v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+        }
       if (p.res) {
         const half_t* rp = p.res + opix * p.out_Cs + cb;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const half4 h = *(const half4*)(rp + i * 4);
+          if constexpr (SPLIT) {
+            const half4 l = *(const half4*)(rp + p.res_lo + i * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r] + (float)l[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+          }
         }
       }
       if (p.up) {
@@ -327,8 +374,14 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const half4 h = *(const half4*)(up + i * 4);
+          if constexpr (SPLIT) {
+            const half4 l = *(const half4*)(up + p.up_lo + i * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r] + (float)l[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] += (float)h[r];
+          }
         }
       }
       if (TRAIN && p.down) {      // backward of the nearest 2x upsample: add the 2x2 block of the finer gradient map
@@ -388,26 +441,30 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
         if constexpr (MI % 2 == 0) {
 #pragma unroll
           for (int i = 0; i < MI; i += 2) {          // one 16-byte store per 8 channels (STORES_F16 per pixel)
-            half8 h;
+            half8 h, l;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               float f = v[i * 4 + r];
               f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
               h[r] = (half_t)f;
+              if constexpr (SPLIT) l[r] = (half_t)(f - (float)h[r]);
             }
             *(half8*)(op + i * 4) = h;
+            if constexpr (SPLIT) *(half8*)(op + p.out_lo + i * 4) = l;
           }
         } else {
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
-            half4 h;
+            half4 h, l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float f = v[i * 4 + r];
               f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
               h[r] = (half_t)f;
+              if constexpr (SPLIT) l[r] = (half_t)(f - (float)h[r]);
             }
             *(half4*)(op + i * 4) = h;
+            if constexpr (SPLIT) *(half4*)(op + p.out_lo + i * 4) = l;
           }
         }
       }
@@ -447,7 +504,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     if (q >= ntiles) break;
     if (nst == 1) {                    // single buffer: no cross-tile prefetch; restart on the next tile
       setup_tile(q);
-      kh = 0; kw = 0; c0 = 0;
+      kh = 0; kw = 0; c0 = 0; pass = 0;
       __syncthreads();
       stage(0, 0, SMALLC ? 0 : next_off());
     }
@@ -472,7 +529,10 @@ int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
                           !(p.down || p.res32 || p.mask || p.out_stride > 1);
   const bool train = p.down || p.res32 || p.mask || p.out_stride > 1;
   const void* k;
-  if (train) {
+  if (p.split) {
+    RS_CHECK(use_glds > 0 && !train && p.wscale, RS_ERR_UNSUPPORTED, "conv: the split-operand mode needs LDS-DMA staging, the row scales and no training epilogue");
+    k = (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, true, false, false, true>;
+  } else if (train) {
     RS_CHECK(use_glds && !SMALLC, RS_ERR_UNSUPPORTED, "conv: training epilogue options need LDS-DMA staging and Cin >= 64");
     if constexpr (!SMALLC) k = (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, false, true, false, true>;
     else k = nullptr;
@@ -484,13 +544,13 @@ int launch_variant(const ConvParams& p, hipStream_t stream, int use_glds) {
     k = use_glds ? (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, true, false>
                  : (const void*)conv_igemm_kernel<WPX, WCH, MI, NJ, SMALLC, false, false>;
   }
-  static bool attr[4] = {false, false, false, false};
-  const int ai = train ? 3 : (persistent ? 2 : (use_glds ? 1 : 0));
+  static bool attr[5] = {false, false, false, false, false};
+  const int ai = p.split ? 4 : (train ? 3 : (persistent ? 2 : (use_glds ? 1 : 0)));
   if (!attr[ai]) {
     RS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS));
     attr[ai] = true;
   }
-  const unsigned grid = persistent ? 256u * (unsigned)bpc : (unsigned)nblk;
+  const unsigned grid = (persistent && !p.split) ? 256u * (unsigned)bpc : (unsigned)nblk;
   ConvParams pc = p;
   void* args[] = {&pc};
   RS_HIP(hipLaunchKernel(k, dim3(grid), dim3(T::NT), args, lds, stream));
@@ -515,14 +575,15 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
   const RsDebug& D = rs_debug();
   const int nk2 = p.in2 ? (p.Cin2 >> 6) : 0;   // K steps of the second source
   const bool smallc = p.Cin < 64;
-  const int nk = smallc ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6) + nk2;
+  // split-operand mode: three passes per slice = a layer with three times the K steps (same LDS and matrix work per step)
+  const int nk = (p.split ? 3 : 1) * (smallc ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6) + nk2);
   if (p.stages == 0) {
     // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second LDS buffer; a
     // single buffer halves the LDS footprint so 4 workgroups fit per CU and their loads/epilogues overlap each other.
     // (RS_CONV_PERSIST >= 1: persistent + double buffered instead -- correct, measured not faster: 0.221 vs 0.225 ms on
     // res2 conv3, slower on conv1; these layers sit at ~3.3 TB/s either way.)
     const bool shallow = nk <= D.conv_single_stage_nk;
-    if (D.conv_persist >= 1 && shallow && p.mode != 2) { p.stages = 2; p.persist = 2; }
+    if (D.conv_persist >= 1 && shallow && p.mode != 2 && !p.split) { p.stages = 2; p.persist = 2; }
     else { p.stages = shallow ? 1 : 2; p.persist = D.conv_persist >= 2 && p.mode != 2 ? -1 : 0; }
   }
   if (force_variant >= 0) return force_variant;
@@ -566,7 +627,7 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
   // conv_igemm tile: fpn_lateral2 at batch 16 / 8 / 3 / 2 / 1: 152 / 82 / 34.1 / 26.2 / 19.6 against 210 / 108 / 34.5 / 26.3 / 16.4;
   // res4.x.conv3 at batch 16 / 8 / 4: 40.0 / 26.1 / 20.0 against 45.4 / 27.0 / 16.8 -- the break-even is a walk of ~4.8 tiles per workgroup
   // (its prologue loads 128 KB of weights into registers)
-  if (D.conv_wreg && use_glds > 0 && conv_wreg_ok(p) && (long long)cdiv(p.M, 32) * (p.Cout >> 8) * 5 >= 48ll * rs_device_cu_count()) return 22;
+  if (D.conv_wreg && !p.split && use_glds > 0 && conv_wreg_ok(p) && (long long)cdiv(p.M, 32) * (p.Cout >> 8) * 5 >= 48ll * rs_device_cu_count()) return 22;
   if (rows % 256 == 0 && nkd <= 4 && p.M >= 40000) return D.conv_wide_px == 64 ? 10 : 14;
   if (nkd <= 4 || tiles0 < 1250) return 7;                                // few tiles or shallow K: 64x128 keeps more workgroups in flight
   return 0;

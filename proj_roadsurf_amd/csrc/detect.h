@@ -70,7 +70,9 @@ struct RoiAlignParams {
   int* out_level;           // optional [entry]
   const int* order;         // optional [S]: workgroup k processes entry order[remap(k)] (remap = the XCD-aware bijection of the conv
                             // kernels: each XCD's L2 sees one contiguous run of the order); results land in the entry's own slot
-  int f32;                  // fp32 validation mode: features and output are float
+  int f32;                  // 1: fp32 validation mode, features and output are float; 2: split-operand mode, features and output are hi / lo
+                            // fp16 planes (feat[l] / out = the hi plane, the lo plane feat_lo[l] / out_lo elements behind it)
+  long long feat_lo[4], out_lo;
   // backward (roi_align_bwd_kernel): `out` holds the incoming gradient [entry][P+2*out_pad]^2[256] fp16 and the
   // gradient of the feature maps is accumulated (float atomics) into dfeat[level], fp32, same geometry as feat[level]
   float* dfeat[4];
@@ -121,7 +123,8 @@ struct MaskPredictParams {
   const int* n_entries;
   float* out;               // [slots][S][S]
   int S;
-  int f32;                  // fp32 validation mode: `in` is float
+  int f32;                  // 1: fp32 validation mode, `in` is float; 2: split-operand mode, `in` is the hi plane, the lo plane in_lo elements behind
+  long long in_lo;
 };
 
 struct PasteParams {

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   const int slot = p.slot_list ? p.slot_list[entry] : entry;
   const int n = slot / p.slots_per_image;
   const int P = p.P, PP = P + 2 * p.out_pad;
-  const int es = p.f32 ? 4 : 2;                 // element size of features / output
+  const int es = p.f32 == 1 ? 4 : 2;            // element size of features / output (p.f32 == 2: split-operand mode, two fp16 planes)
   char* out = (char*)p.out + (long long)entry * PP * PP * 256 * es;
   const int hw = tid >> 5, l32 = tid & 31;       // half-wave id, lane inside it (8 channels each)
   bool valid = true;
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
     for (int b = hw; b < P * P; b += 8) {
       const int ph = b / P, pw = b - ph * P;
       char* o = out + (((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) * es;
-      if (p.f32) { ((f32x4*)o)[0] = f32x4{0.f, 0.f, 0.f, 0.f}; ((f32x4*)o)[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      else { half8 z; for (int i = 0; i < 8; ++i) z[i] = (half_t)0.f; *(half8*)o = z; }
+      if (p.f32 == 1) { ((f32x4*)o)[0] = f32x4{0.f, 0.f, 0.f, 0.f}; ((f32x4*)o)[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      else { half8 z; for (int i = 0; i < 8; ++i) z[i] = (half_t)0.f; *(half8*)o = z; if (p.f32 == 2) *(half8*)(o + p.out_lo * 2) = z; }
     }
     return;
   }
@@ -570,7 +570,18 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
         }
         const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
         float f1[8], f2[8], f3[8], f4[8];
-        if (p.f32) {
+        if (p.f32 == 2) {
+          const long long lo2 = p.feat_lo[lvl] * 2;
+          const half8 v1 = *(const half8*)(feat + (long long)(ylo + xlo) * 2), u1 = *(const half8*)(feat + lo2 + (long long)(ylo + xlo) * 2);
+          const half8 v2 = *(const half8*)(feat + (long long)(ylo + xhi) * 2), u2 = *(const half8*)(feat + lo2 + (long long)(ylo + xhi) * 2);
+          const half8 v3 = *(const half8*)(feat + (long long)(yhi + xlo) * 2), u3 = *(const half8*)(feat + lo2 + (long long)(yhi + xlo) * 2);
+          const half8 v4 = *(const half8*)(feat + (long long)(yhi + xhi) * 2), u4 = *(const half8*)(feat + lo2 + (long long)(yhi + xhi) * 2);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {      // fp32(hi) + fp32(lo) is exact
+            f1[c] = (float)v1[c] + (float)u1[c]; f2[c] = (float)v2[c] + (float)u2[c];
+            f3[c] = (float)v3[c] + (float)u3[c]; f4[c] = (float)v4[c] + (float)u4[c];
+          }
+        } else if (p.f32) {
           const f32x4* q1 = (const f32x4*)(feat + (long long)(ylo + xlo) * 4);
           const f32x4* q2 = (const f32x4*)(feat + (long long)(ylo + xhi) * 4);
           const f32x4* q3 = (const f32x4*)(feat + (long long)(yhi + xlo) * 4);
@@ -594,14 +605,19 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
     }
     if (live) {
       char* op = out + (((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) * es;
-      if (p.f32) {
+      if (p.f32 == 1) {
         ((f32x4*)op)[0] = f32x4{acc[0] / count, acc[1] / count, acc[2] / count, acc[3] / count};
         ((f32x4*)op)[1] = f32x4{acc[4] / count, acc[5] / count, acc[6] / count, acc[7] / count};
       } else {
-        half8 o;
+        half8 o, ol;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] / count);
+        for (int c = 0; c < 8; ++c) {
+          const float f = acc[c] / count;
+          o[c] = (half_t)f;
+          ol[c] = (half_t)(f - (float)o[c]);
+        }
         *(half8*)op = o;
+        if (p.f32 == 2) *(half8*)(op + p.out_lo * 2) = ol;
       }
     }
   }
@@ -1373,7 +1389,12 @@ __global__ __launch_bounds__(256) void mask_predict_kernel(const MaskPredictPara
   const int cls = p.det_classes[slot];
   const float* w = p.w + (long long)cls * 256 + sub * 16;
   float xv[16];
-  if (p.f32) {
+  if (p.f32 == 2) {         // split-operand mode: hi + lo planes
+    const half_t* x = p.in + pix * 256 + sub * 16;
+    const half8 a = *(const half8*)x, b = *(const half8*)(x + 8), al = *(const half8*)(x + p.in_lo), bl = *(const half8*)(x + p.in_lo + 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xv[i] = (float)a[i] + (float)al[i]; xv[8 + i] = (float)b[i] + (float)bl[i]; }
+  } else if (p.f32) {
     const float* x = (const float*)p.in + pix * 256 + sub * 16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) xv[i] = x[i];

@@ -49,8 +49,9 @@ void rs_set_error(const char* fmt, ...) {
 
 namespace {
 
-enum { DT_F16 = 1, DT_F32 = 2, DT_I32 = 3, DT_U8 = 4 };
-static size_t dt_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_U8 ? 1 : 4); }
+// DT_SPLIT16: an activation of the split-operand mode -- two fp16 planes of the registered shape back to back (hi, then lo); value = hi + lo
+enum { DT_F16 = 1, DT_F32 = 2, DT_I32 = 3, DT_U8 = 4, DT_SPLIT16 = 5 };
+static size_t dt_size(int dt) { return (dt == DT_F16 || dt == DT_SPLIT16) ? 2 : (dt == DT_U8 ? 1 : 4); }
 
 struct TensorInfo {
   std::string name;
@@ -62,6 +63,7 @@ struct TensorInfo {
 
 struct Act {   // NHWC fp16 activation with halo
   half_t* p = nullptr;
+  long long lo = 0;   // split-operand mode: element offset of the lo plane behind p (0 = single plane)
   int N = 0, H = 0, W = 0, C = 0, pad = 0;
   int Hp() const { return H + 2 * pad; }
   int Wp() const { return W + 2 * pad; }
@@ -157,6 +159,7 @@ struct rs_engine {
   int net_h = 0, net_w = 0, pad_h = 0, pad_w = 0;
   int use_glds = 1;    // -1 = fp32 validation path (launch_conv forwards to launch_conv_f32)
   bool f32 = false;    // rs_spec.precision == 1: activations and weights are float
+  bool split = false;  // rs_spec.precision == 2: split-operand mode -- activations and weights as hi + lo fp16 planes, three MFMA passes (common.h ConvParams::split)
   int profiling = 0;   // 0 off, 1 = events + host sync per stage, 2 = events only (resolved later)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // mode 2
@@ -210,15 +213,16 @@ struct rs_engine {
     t.name = name; t.p = p; t.dtype = dtype; t.ndim = (int)dims.size(); t.halo = halo;
     size_t nb = dt_size(dtype);
     for (size_t i = 0; i < dims.size(); ++i) { t.dims[i] = dims[i]; nb *= (size_t)dims[i]; }
-    t.bytes = nb;
+    t.bytes = dtype == DT_SPLIT16 ? 2 * nb : nb;
     tensors.push_back(t);
   }
   int new_act(Act* a, const std::string& name, int N, int H, int W, int C, int pad) {
     a->N = N; a->H = H; a->W = W; a->C = C; a->pad = pad;
-    const size_t bytes = (size_t)N * a->Hp() * a->Wp() * C * (f32 ? 4 : 2);
+    const size_t bytes = (size_t)N * a->Hp() * a->Wp() * C * (f32 ? 4 : 2) * (split ? 2 : 1);
     int rc = alloc((void**)&a->p, bytes);
     if (rc) return rc;
-    reg(name, a->p, f32 ? DT_F32 : DT_F16, {N, a->Hp(), a->Wp(), C}, pad);
+    a->lo = split ? (long long)N * a->Hp() * a->Wp() * C : 0;
+    reg(name, a->p, f32 ? DT_F32 : (split ? DT_SPLIT16 : DT_F16), {N, a->Hp(), a->Wp(), C}, pad);
     return RS_OK;
   }
   const BlobEntry* find(const std::string& n) {
@@ -226,7 +230,24 @@ struct rs_engine {
     return it == blob.end() ? nullptr : &it->second;
   }
   // GEMM weights of a layer: "<layer>.w" (fp16) or "<layer>.w32" in the fp32 validation mode
-  const BlobEntry* findw(const std::string& layer) { return find(layer + (f32 ? ".w32" : ".w")); }
+  // split-operand mode: "<layer>.ws" = fp16 [2][rows][Kpad] (hi rows, then lo rows, of the row-scaled weight) + "<layer>.wsi" fp32 [rows] (inverse scales)
+  const BlobEntry* findw(const std::string& layer) { return find(layer + (f32 ? ".w32" : (split ? ".ws" : ".w"))); }
+  int wrows(const BlobEntry* w) const { return (int)(split ? w->dims[0] / 2 : w->dims[0]); }
+  // fills the split-operand fields of a conv whose weight entry is w (no-op in the other modes)
+  int set_split(ConvParams* p, const std::string& wname, const BlobEntry* w, const Act* in, const Act* out, const Act* res, const Act* up, const Act* in2) {
+    if (!split) return RS_OK;
+    const BlobEntry* si = find(wname + ".wsi");
+    RS_CHECK(si && si->dtype == DT_F32 && si->dims[0] >= w->dims[0] / 2 && (w->dims[0] & 1) == 0, RS_ERR_BLOB, "row scales of %s missing from blob (split-operand mode)", wname.c_str());
+    p->split = 1;
+    p->wscale = (const float*)si->dev;
+    p->w_lo = (long long)(w->dims[0] / 2) * w->dims[1];
+    if (in) p->in_lo = in->lo;
+    if (out) p->out_lo = out->lo;
+    if (res) p->res_lo = res->lo;
+    if (up) p->up_lo = up->lo;
+    if (in2) p->in2_lo = in2->lo;
+    return RS_OK;
+  }
   int parse_blob(const void* data, size_t nbytes);
   int build();
   struct DeferredConv { ConvParams p; int m_per_image = 0; double flops = 0, bytes = 0; };
@@ -295,6 +316,7 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
   RS_CHECK(w->dtype == (f32 ? DT_F32 : DT_F16) && b->dtype == DT_F32, RS_ERR_BLOB, "weights for %s have wrong dtype", wname.c_str());
   ConvParams p;
   memset(&p, 0, sizeof p);
+  { int rc = set_split(&p, wname, w, &in, &out, res, up, in2); if (rc) return rc; }
   p.in = in.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev; p.out = out.p;
   p.res = res ? res->p : nullptr;
   p.up = up ? up->p : nullptr;
@@ -312,7 +334,7 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
     p.stride2 = stride2; p.Cin2 = in2->C;
   }
   RS_CHECK(in.pad >= pad, RS_ERR_ARG, "%s: input halo %d < conv pad %d", name.c_str(), in.pad, pad);
-  RS_CHECK((int)w->dims[0] >= out.C, RS_ERR_BLOB, "%s: weight rows %lld < Cout %d", name.c_str(), (long long)w->dims[0], out.C);
+  RS_CHECK(wrows(w) >= out.C, RS_ERR_BLOB, "%s: weight rows %d < Cout %d", name.c_str(), wrows(w), out.C);
   RS_CHECK((out.H - 1) * stride + k - 2 * pad <= in.H + (stride - 1), RS_ERR_ARG, "%s: geometry", name.c_str());
   if (res) RS_CHECK(res->H == out.H && res->W == out.W && res->C == out.C && res->pad == out.pad, RS_ERR_ARG, "%s: residual geometry", name.c_str());
   if (in.C < 64) {
@@ -344,7 +366,7 @@ int rs_engine::add_conv(const std::string& name, const std::string& wname, const
   // algorithmic bytes: the input pixels the convolution actually reads (a stride-s 1x1 touches every s-th pixel of every
   // s-th row only), the output once, the residual once, the second K source at the output's pixel count
   const double in_px = k >= stride ? (double)in.H * in.W : (double)out.H * out.W * k * k;
-  st.bytes_per_image = 2.0 * (in_px * in.C * units_per_tile + (double)m_per_image * out.C * (1 + (res ? 1 : 0)) +
+  st.bytes_per_image = (split ? 4.0 : 2.0) * (in_px * in.C * units_per_tile + (double)m_per_image * out.C * (1 + (res ? 1 : 0)) +
                               (in2 ? (double)m_per_image * in2->C : 0.0));
   const int glds = use_glds;
   if (defer) {           // the caller merges this convolution into a multi-map launch (add_merged_convs)
@@ -374,7 +396,9 @@ int rs_engine::add_merged_convs(const std::string& name, const std::vector<Defer
                  !q.res && !q.up && !q.in2 && !q.m_count && q.mode == 0 && !q.out_f32,
              RS_ERR_ARG, "%s: map %d does not share the launch parameters of map 0", name.c_str(), (int)i);
     RS_CHECK(q.head_w == common.head_w && q.head_b == common.head_b, RS_ERR_ARG, "%s: map %d has another fused head", name.c_str(), (int)i);
+    RS_CHECK(q.split == common.split && q.w_lo == common.w_lo, RS_ERR_ARG, "%s: map %d differs in the split-operand fields", name.c_str(), (int)i);
     segs[i].in = q.in; segs[i].w = q.w; segs[i].bias = q.bias; segs[i].out = q.out; segs[i].head_out = q.head_out;
+    segs[i].in_lo = q.in_lo; segs[i].out_lo = q.out_lo; segs[i].wscale = q.wscale;
     segs[i].Ho = q.Ho; segs[i].Wo = q.Wo; segs[i].in_Hp = q.in_Hp; segs[i].in_Wp = q.in_Wp; segs[i].out_Hp = q.out_Hp; segs[i].out_Wp = q.out_Wp;
     mpi[i] = d[i].m_per_image;
     st.flops_per_image += d[i].flops;
@@ -473,22 +497,24 @@ int rs_engine::build() {
   Act x0;
   if ((rc = new_act(&x0, "net_input", NB, pad_h, pad_w, 4, 3))) return rc;
   pp.out = x0.p; pp.H = tile_h; pp.W = tile_w; pp.C = tile_c; pp.new_h = net_h; pp.new_w = net_w;
-  pp.out_Hp = x0.Hp(); pp.out_Wp = x0.Wp(); pp.flip = S.flip_channels; pp.out_f32 = f32 ? 1 : 0;
+  pp.out_Hp = x0.Hp(); pp.out_Wp = x0.Wp(); pp.flip = S.flip_channels; pp.out_f32 = f32 ? 1 : (split ? 2 : 0);
+  pp.out_lo = x0.lo;
   for (int c = 0; c < 4; ++c) { pp.mean[c] = S.pixel_mean[c]; pp.stdv[c] = S.pixel_std[c] == 0.f ? 1.f : S.pixel_std[c]; }
   {
     Stage st;
     st.name = "preprocess";
     st.bytes_per_image = (double)tile_h * tile_w * tile_c + (double)net_h * net_w * 8;
     pp.tiles = tiles_dev;
-    const size_t x0_bytes = (size_t)NB * x0.Hp() * x0.Wp() * 4 * (f32 ? 4 : 2);
-    st.fn = [this, pp, x0_bytes](int n, hipStream_t s) mutable {
+    const size_t x0_bytes = (size_t)NB * x0.Hp() * x0.Wp() * 4 * (f32 ? 4 : 2);       // one plane
+    const int planes = split ? 2 : 1;
+    st.fn = [this, pp, x0_bytes, planes](int n, hipStream_t s) mutable {
       if (img_new_h.empty()) {
         pp.N = n;
         return launch_preprocess(pp, s);
       }
       // images of different sizes in one canvas: zeros (the padding value of ImageList.from_tensors) outside each image
       RS_CHECK((int)img_new_h.size() >= n, RS_ERR_ARG, "per-image sizes set for %d images, batch of %d", (int)img_new_h.size(), n);
-      RS_HIP(hipMemsetAsync((void*)pp.out, 0, x0_bytes, s));
+      RS_HIP(hipMemsetAsync((void*)pp.out, 0, x0_bytes * planes, s));
       for (int i = 0; i < n; ++i) {
         PreprocParams q = pp;
         ResizeTab th, tv;
@@ -518,7 +544,7 @@ int rs_engine::build() {
   if ((rc = new_act(&c1, "stem", NB, h4, w4, S.stem_out_channels, 1))) return rc;
   const BlobEntry* stem_w = findw(bu + "stem.conv1f");          // fragment-ordered copy of the 64 x 256 stem matrix
   const BlobEntry* stem_b = find(bu + "stem.conv1.b");
-  if (fuse_stem && !f32 && use_glds > 0 && S.stem_out_channels == 64 && x0.C == 4 && x0.pad == 3 && stem_w && stem_b &&
+  if (fuse_stem && !f32 && !split && use_glds > 0 && S.stem_out_channels == 64 && x0.C == 4 && x0.pad == 3 && stem_w && stem_b &&
       (long long)stem_w->dims[0] * stem_w->dims[1] == 7 * 4 * 64 * 8 && (pad_h & 3) == 0 && (pad_w & 3) == 0) {
     // conv 7x7 s2 + FrozenBN + ReLU + max-pool 3x3 s2 in one launch (stem_fused.hip): the 400 x 400 x 64 map never reaches HBM
     StemPoolParams sp;
@@ -538,8 +564,9 @@ int rs_engine::build() {
     Stage st;
     st.name = "stem.maxpool";
     st.bytes_per_image = 2.0 * ((double)h2 * w2 + (double)h4 * w4) * S.stem_out_channels;
-    const bool f = f32;
-    st.fn = [stem, c1, f](int n, hipStream_t s) {
+    const bool f = f32, sp = split;
+    st.fn = [stem, c1, f, sp](int n, hipStream_t s) {
+      if (sp) return launch_maxpool_split(stem.p, stem.lo, c1.p, c1.lo, n, stem.H, stem.W, c1.H, c1.W, c1.C, s);
       return f ? launch_maxpool_f32((const float*)stem.p, (float*)c1.p, n, stem.H, stem.W, c1.H, c1.W, c1.C, s)
                : launch_maxpool(stem.p, c1.p, n, stem.H, stem.W, c1.H, c1.W, c1.C, s);
     };
@@ -568,9 +595,9 @@ int rs_engine::build() {
       // Wsc . x0 as two more K steps instead of the identity residual (needs the folded conv3sc bias = conv3's + the shortcut's).
       const bool may_fuse = !frozen_fusions_only || si == 0;          // a trainer fuses only inside the frozen res2
       const bool fuse_bneck = this->fuse_bneck && may_fuse, fuse_shortcut = this->fuse_shortcut && may_fuse;
-      const bool tail0 = !f32 && fuse_bneck && fuse_shortcut && bi == 0 && bott == 64 && cout == 256 && stride == 1 && cur.C == 64 &&
+      const bool tail0 = !f32 && !split && fuse_bneck && fuse_shortcut && bi == 0 && bott == 64 && cout == 256 && stride == 1 && cur.C == 64 &&
                          findw(wn + ".conv3p") != nullptr && findw(wn + ".shortcut") != nullptr && find(wn + ".conv3sc.b") != nullptr;
-      const bool tail = tail0 || (!f32 && fuse_bneck && bi > 0 && (bott == 64 || bott == 128) && cout == 4 * bott && stride == 1 && findw(wn + ".conv3p") != nullptr);
+      const bool tail = tail0 || (!f32 && !split && fuse_bneck && bi > 0 && (bott == 64 || bott == 128) && cout == 4 * bott && stride == 1 && findw(wn + ".conv3p") != nullptr);
       const bool tail_next = tail && bi + 1 < S.res_blocks[si] &&
                              findw(bu + "res" + std::to_string(si + 2) + "." + std::to_string(bi + 1) + ".conv1p") != nullptr;
       if (have_t1) t1 = t1_pre;
@@ -659,8 +686,9 @@ int rs_engine::build() {
     Stage st;
     st.name = "fpn.p6";
     Act a = P[3], b = P[4];
-    const bool f = f32;
-    st.fn = [a, b, f](int n, hipStream_t s) {
+    const bool f = f32, sp = split;
+    st.fn = [a, b, f, sp](int n, hipStream_t s) {
+      if (sp) return launch_subsample2_split(a.p, a.lo, b.p, b.lo, n, a.H, a.W, b.H, b.W, 256, s);
       return f ? launch_subsample2_f32((const float*)a.p, (float*)b.p, n, a.H, a.W, b.H, b.W, 256, s)
                : launch_subsample2(a.p, b.p, n, a.H, a.W, b.H, b.W, 256, s);
     };
@@ -683,7 +711,7 @@ int rs_engine::build() {
   // inference engines: the 16-row head runs inside the epilogue of the merged 3x3 launch (conv_deep.hip, ConvParams::head_w), so the
   // 256-channel "rpn_conv" maps are never written
   const BlobEntry* headsp = findw("proposal_generator.rpn_head.headsp");
-  const bool fuse_heads = merge && rs_debug().fuse_rpn_heads && head_cs == 16 && headsp != nullptr;
+  const bool fuse_heads = merge && !split && rs_debug().fuse_rpn_heads && head_cs == 16 && headsp != nullptr;
   for (int l = 0; l < L; ++l) {
     const std::string ln = std::to_string(l + 2);
     Act t;
@@ -713,9 +741,10 @@ int rs_engine::build() {
       const BlobEntry* w = findw("proposal_generator.rpn_head.heads");
       const BlobEntry* b = find("proposal_generator.rpn_head.heads.b");
       RS_CHECK(w && b, RS_ERR_BLOB, "rpn head weights missing");
-      RS_CHECK((int)w->dims[0] == head_cs, RS_ERR_BLOB, "rpn head rows %lld != %d", (long long)w->dims[0], head_cs);
+      RS_CHECK(wrows(w) == head_cs, RS_ERR_BLOB, "rpn head rows %d != %d", wrows(w), head_cs);
       ConvParams p;
       memset(&p, 0, sizeof p);
+      if ((rc = set_split(&p, "proposal_generator.rpn_head.heads", w, &t, nullptr, nullptr, nullptr, nullptr))) return rc;
       p.in = t.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev; p.out = ho;
       p.Ho = t.H; p.Wo = t.W; p.in_Hp = t.Hp(); p.in_Wp = t.Wp(); p.in_Cs = 256; p.in_off = t.pad; p.stride = 1;
       p.KH = p.KW = 1; p.Cin = 256; p.Kpad = (int)w->dims[1]; p.Cout = head_cs;
@@ -784,7 +813,7 @@ int rs_engine::build() {
   // visiting order of box.roi_align (RpnMergeParams::prop_order): inference engines on the windowed fp16 kernel only -- a training
   // engine overwrites the proposal buffer with its sampled RoIs after this stage
   int* prop_order = nullptr;
-  const bool roi_order = !f32 && !g_trainer_unfused_shortcut && rs_debug().roi_order != 0;
+  const bool roi_order = !f32 && !split && !g_trainer_unfused_shortcut && rs_debug().roi_order != 0;
   if (roi_order) {
     if ((rc = alloc((void**)&prop_order, (size_t)NB * PC * 4))) return rc;
     reg("proposal_order", prop_order, DT_I32, {NB, PC}, 0);
@@ -806,7 +835,8 @@ int rs_engine::build() {
   RoiAlignParams ra;
   memset(&ra, 0, sizeof ra);
   for (int l = 0; l < 4; ++l) { ra.feat[l] = P[l].p; ra.H[l] = P[l].H; ra.W[l] = P[l].W; ra.scale[l] = 1.0f / (float)(4 << l); }
-  ra.nlevels = 4; ra.C = 256; ra.f32 = f32 ? 1 : 0;
+  ra.nlevels = 4; ra.C = 256; ra.f32 = f32 ? 1 : (split ? 2 : 0);
+  for (int l = 0; l < 4; ++l) ra.feat_lo[l] = P[l].lo;
   Act boxfeat;   // [NB*PC] "images" of PR x PR x 256
   if ((rc = new_act(&boxfeat, "box_pooled", NB * PC, PR, PR, 256, 0))) return rc;
   int* box_level = nullptr;
@@ -814,19 +844,19 @@ int rs_engine::build() {
   reg("box_roi_level", box_level, DT_I32, {NB, PC}, 0);
   {
     RoiAlignParams q = ra;
-    q.rois = prop_boxes; q.per_image_count = prop_count; q.slots_per_image = PC; q.out = boxfeat.p; q.P = PR; q.out_pad = 0;
+    q.rois = prop_boxes; q.per_image_count = prop_count; q.slots_per_image = PC; q.out = boxfeat.p; q.out_lo = boxfeat.lo; q.P = PR; q.out_pad = 0;
     q.out_level = box_level;
     q.order = prop_order;
     Stage st;
     st.name = "box.roi_align";
-    st.bytes_per_image = (double)PC * PR * PR * 256 * 2 * 2;
+    st.bytes_per_image = (double)PC * PR * PR * 256 * 2 * 2 * (split ? 2 : 1);
     st.fn = [q](int n, hipStream_t s) mutable { q.S = n * PC; return launch_roi_align(q, s); };
     stages.push_back(st);
   }
   // FC layers as 1x1 "convs" over a (M x 1) image
   const int FC = S.box_fc_dim;
   Act fin, f1, f2;
-  fin.p = boxfeat.p; fin.N = 1; fin.H = NB * PC; fin.W = 1; fin.C = PR * PR * 256; fin.pad = 0;
+  fin.p = boxfeat.p; fin.lo = boxfeat.lo; fin.N = 1; fin.H = NB * PC; fin.W = 1; fin.C = PR * PR * 256; fin.pad = 0;
   if ((rc = new_act(&f1, "box_fc1", 1, NB * PC, 1, FC, 0))) return rc;
   if ((rc = new_act(&f2, "box_fc2", 1, NB * PC, 1, FC, 0))) return rc;
   auto add_fc = [&](const std::string& name, const std::string& wn, const Act& in, const Act& out, bool relu, float* out32, int rows32) -> int {
@@ -835,19 +865,20 @@ int rs_engine::build() {
     RS_CHECK(w && b, RS_ERR_BLOB, "weights for %s missing", wn.c_str());
     ConvParams p;
     memset(&p, 0, sizeof p);
+    { int rc2 = set_split(&p, wn, w, &in, out32 ? nullptr : &out, nullptr, nullptr, nullptr); if (rc2) return rc2; }
     p.in = in.p; p.w = (const half_t*)w->dev; p.bias = (const float*)b->dev;
     p.Ho = NB * PC; p.Wo = 1; p.in_Hp = NB * PC; p.in_Wp = 1; p.in_Cs = in.C; p.stride = 1; p.KH = p.KW = 1; p.Cin = in.C;
     p.Kpad = (int)w->dims[1];
     p.out_Hp = NB * PC; p.out_Wp = 1; p.relu = relu;
     if (out32) { p.out = out32; p.Cout = rows32; p.out_Cs = rows32; p.out_f32 = 1; }
     else { p.out = out.p; p.Cout = out.C; p.out_Cs = out.C; }
-    RS_CHECK((int)w->dims[0] >= p.Cout && p.Kpad >= in.C, RS_ERR_BLOB, "%s: weight shape", wn.c_str());
+    RS_CHECK(wrows(w) >= p.Cout && p.Kpad >= in.C, RS_ERR_BLOB, "%s: weight shape", wn.c_str());
     const int glds = use_glds;
     const int variant = out32 ? 2 : -1;
     Stage st;
     st.name = name;
     st.flops_per_image = 2.0 * PC * (double)in.C * p.Cout;
-    st.bytes_per_image = (double)PC * (in.C * 2 + p.Cout * (out32 ? 4 : 2));
+    st.bytes_per_image = (double)PC * (in.C * 2 * (split ? 2 : 1) + p.Cout * (out32 ? 4 : (split ? 4 : 2)));
     st.fn = [p, glds, variant](int n, hipStream_t s) mutable { p.M = n * PC; return launch_conv(p, s, variant, glds); };
     stages.push_back(st);
     return RS_OK;
@@ -944,10 +975,10 @@ int rs_engine::build() {
     {
       RoiAlignParams q = ra;
       q.rois = det_boxes_net; q.slot_list = slot_list; q.n_entries = det_total; q.slots_per_image = D;
-      q.out = mx.p; q.P = MR; q.out_pad = 1;
+      q.out = mx.p; q.out_lo = mx.lo; q.P = MR; q.out_pad = 1;
       Stage st;
       st.name = "mask.roi_align";
-      st.bytes_per_image = (double)D * MR * MR * 256 * 2 * 2;
+      st.bytes_per_image = (double)D * MR * MR * 256 * 2 * 2 * (split ? 2 : 1);
       const int Dc = D;
       st.fn = [q, Dc](int n, hipStream_t s) mutable { q.S = n * Dc; return launch_roi_align(q, s); };
       stages.push_back(st);
@@ -966,11 +997,12 @@ int rs_engine::build() {
     const BlobEntry* db = find("roi_heads.mask_head.deconv.b");
     const BlobEntry* pw = find("roi_heads.mask_head.predictor.w");
     const BlobEntry* pb = find("roi_heads.mask_head.predictor.b");
-    RS_CHECK(dw && db && dw->dims[0] == 1024, RS_ERR_BLOB, "deconv weights missing / wrong rows");
+    RS_CHECK(dw && db && wrows(dw) == 1024, RS_ERR_BLOB, "deconv weights missing / wrong rows");
     RS_CHECK(pw && pb && pw->dtype == DT_F32, RS_ERR_BLOB, "mask predictor weights missing");
     const bool fuse = f32 ? false : rs_debug().fuse_mask_predictor != 0;
     ConvParams dp;
     memset(&dp, 0, sizeof dp);
+    if ((rc = set_split(&dp, "roi_heads.mask_head.deconv", dw, &curm, nullptr, nullptr, nullptr, nullptr))) return rc;
     dp.in = curm.p; dp.w = (const half_t*)dw->dev; dp.bias = (const float*)db->dev;
     dp.Ho = MR; dp.Wo = MR; dp.in_Hp = curm.Hp(); dp.in_Wp = curm.Wp(); dp.in_Cs = 256; dp.in_off = 1; dp.stride = 1; dp.KH = dp.KW = 1;
     dp.Cin = 256; dp.Kpad = (int)dw->dims[1]; dp.Cout = 256; dp.out_Hp = 2 * MR; dp.out_Wp = 2 * MR; dp.out_Cs = 256; dp.out_pad = 0; dp.relu = 1;
@@ -983,19 +1015,20 @@ int rs_engine::build() {
       dp.dot_w = (const float*)pw->dev; dp.dot_cls = det_classes; dp.dot_slot = slot_list; dp.dot_out = mask_probs;
       dp.dot_k = (int)pw->dims[0];
       const int glds = use_glds, Dc = D;
+      const bool sp = split;
       float* probs = mask_probs;
       const size_t zero_per_tile = (size_t)D * RS_MASK_SIDE * RS_MASK_SIDE * 4;
       Stage st;
       st.name = "mask.deconv_predict";
       st.flops_per_image = 2.0 * D * per_roi * 256 * 1024 + 2.0 * D * RS_MASK_SIDE * RS_MASK_SIDE * 256;
-      st.bytes_per_image = (double)D * per_roi * 256 * 2 + (double)D * RS_MASK_SIDE * RS_MASK_SIDE * 4;
-      st.fn = [dp, per_roi, Dc, glds, probs, zero_per_tile](int n, hipStream_t s) mutable {
+      st.bytes_per_image = (double)D * per_roi * 256 * 2 * (split ? 2 : 1) + (double)D * RS_MASK_SIDE * RS_MASK_SIDE * 4;
+      st.fn = [dp, per_roi, Dc, glds, probs, zero_per_tile, sp](int n, hipStream_t s) mutable {
         RS_HIP(hipMemsetAsync(probs, 0, zero_per_tile * n, s));
         dp.M = n * Dc * per_roi;
         // conv_wreg.hip (22: persistent, a (dy, dx) group's weights in registers) or conv_igemm's tile where one workgroup holds all 256
         // channels of a group (14 / 10); the two give the same bits
         const int dv = rs_debug().deconv_variant;
-        return launch_conv(dp, s, (dv == 22 && !(rs_debug().conv_wreg && glds > 0)) ? 14 : dv, glds);
+        return launch_conv(dp, s, (dv == 22 && (sp || !(rs_debug().conv_wreg && glds > 0))) ? 14 : dv, glds);
       };
       stages.push_back(st);
       MaskPredictParams mp;
@@ -1009,7 +1042,7 @@ int rs_engine::build() {
     } else {
       Act dec;
       if ((rc = new_act(&dec, "mask_deconv", R, 2 * MR, 2 * MR, 256, 0))) return rc;
-      dp.mode = 1; dp.out = dec.p;
+      dp.mode = 1; dp.out = dec.p; dp.out_lo = dec.lo;
       {
         const int glds = use_glds, Dc = D;
         Stage st;
@@ -1021,7 +1054,7 @@ int rs_engine::build() {
       }
       MaskPredictParams mp;
       mp.in = dec.p; mp.w = (const float*)pw->dev; mp.b = (const float*)pb->dev; mp.slot_list = slot_list; mp.det_classes = det_classes;
-      mp.n_entries = det_total; mp.out = mask_probs; mp.S = RS_MASK_SIDE; mp.f32 = f32 ? 1 : 0;
+      mp.n_entries = det_total; mp.out = mask_probs; mp.S = RS_MASK_SIDE; mp.f32 = f32 ? 1 : (split ? 2 : 0); mp.in_lo = dec.lo;
       Stage st;
       st.name = "mask.predict_sigmoid";
       st.bytes_per_image = (double)D * RS_MASK_SIDE * RS_MASK_SIDE * (256 * 2 + 4);
@@ -1218,7 +1251,13 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   rs_debug_reload();
   e->use_glds = rs_debug().use_glds;
   e->f32 = spec->precision == 1;
+  e->split = spec->precision == 2;
   if (e->f32) e->use_glds = -1;
+  if (e->split && (e->use_glds <= 0 || g_trainer_unfused_shortcut)) {
+    rs_set_error("precision 2 (split operands) needs LDS-DMA staging and is an inference mode");
+    delete e;
+    return RS_ERR_UNSUPPORTED;
+  }
   e->fuse_shortcut = rs_debug().fuse_shortcut;
   e->fuse_bneck = rs_debug().fuse_bneck;
   e->fuse_stem = rs_debug().fuse_stem;
@@ -1467,6 +1506,10 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
                                 "conv1x1_wreg_kernel 32 px x 256 ch (persistent, weights in registers, operand tiles by LDS-DMA, two workgroups per CU)"};
   const int v = e->stages[i].variant;
   const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 22 ? names[v] : "");
+  if (e->split && v >= 0 && v <= 22) {
+    snprintf(name_out, 96, "%.70s [split hi+lo, 3 passes]", s);
+    return RS_OK;
+  }
   strncpy(name_out, s, 95);
   name_out[95] = 0;
   return RS_OK;
@@ -1525,10 +1568,11 @@ int rs_engine_net_shape(rs_engine* e, int* rh, int* rw, int* ph, int* pw) {
 
 // ------------------------------------------------------------------------- stand-alone operators
 static long long* g_conv_probe = nullptr;   // -DRS_CLOCK_PROBE diagnostic builds: see rs_debug_set_conv_probe
+struct SplitArgs { long long in_lo, w_lo, out_lo, res_lo, up_lo; const float* wscale; };
 static int op_conv2d(const void* in, const void* w, const float* bias, void* out, const void* residual, const void* upsample_add,
                      int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
                      int out_halo, int relu, int out_f32, int deconv2x, int variant, int use_glds, void* stream,
-                     const void* in2, int h2, int w2, int cin2, int in2_halo, int stride2) {
+                     const void* in2, int h2, int w2, int cin2, int in2_halo, int stride2, const SplitArgs* sa = nullptr) {
   RS_CHECK(in && w && bias && out, RS_ERR_ARG, "null argument");
   RS_CHECK(in_halo >= pad, RS_ERR_ARG, "input halo %d < pad %d", in_halo, pad);
   const int ho = (hi + 2 * pad - kh) / stride + 1, wo = (wi + 2 * pad - kw) / stride + 1;
@@ -1544,6 +1588,10 @@ static int op_conv2d(const void* in, const void* w, const float* bias, void* out
   if (upsample_add) { p.up_Hp = ho / 2 + 2 * out_halo; p.up_Wp = wo / 2 + 2 * out_halo; p.up_Cs = cout; p.up_pad = out_halo; }
   p.relu = relu; p.mode = deconv2x ? 1 : 0; p.out_f32 = out_f32;
   p.probe = g_conv_probe;
+  if (sa) {
+    RS_CHECK(sa->wscale && !in2, RS_ERR_ARG, "split-operand conv: row scales missing (or a second K source, which the operator does not take)");
+    p.split = 1; p.in_lo = sa->in_lo; p.w_lo = sa->w_lo; p.out_lo = sa->out_lo; p.res_lo = sa->res_lo; p.up_lo = sa->up_lo; p.wscale = sa->wscale;
+  }
   if (in2) {
     RS_CHECK(stride2 >= 1 && (ho - 1) * stride2 < h2 && (wo - 1) * stride2 < w2, RS_ERR_ARG, "second source geometry");
     p.in2 = (const half_t*)in2; p.in2_Hp = h2 + 2 * in2_halo; p.in2_Wp = w2 + 2 * in2_halo; p.in2_Cs = cin2;
@@ -1573,6 +1621,17 @@ int rs_op_conv2d(const void* in, const void* w, const float* bias, void* out, co
                  int out_halo, int relu, int out_f32, int deconv2x, int variant, int use_glds, void* stream) {
   return op_conv2d(in, w, bias, out, residual, upsample_add, n, hi, wi, cin, in_halo, kh, kw, stride, pad, cout, kpad, out_halo,
                    relu, out_f32, deconv2x, variant, use_glds, stream, nullptr, 0, 0, 0, 0, 1);
+}
+
+// The same convolution in the split-operand precision mode (rs_spec.precision == 2): every fp16 tensor is a hi plane with its lo plane `*_lo`
+// ELEMENTS behind it (value = hi + lo), the weight rows are scaled by a power of two per row and `wscale` holds the inverses.
+int rs_op_conv2d_split(const void* in, int64_t in_lo, const void* w, int64_t w_lo, const float* wscale, const float* bias, void* out, int64_t out_lo,
+                       const void* residual, int64_t res_lo, const void* upsample_add, int64_t up_lo,
+                       int n, int hi, int wi, int cin, int in_halo, int kh, int kw, int stride, int pad, int cout, int kpad,
+                       int out_halo, int relu, int out_f32, int deconv2x, int variant, void* stream) {
+  SplitArgs sa = {in_lo, w_lo, out_lo, res_lo, up_lo, wscale};
+  return op_conv2d(in, w, bias, out, residual, upsample_add, n, hi, wi, cin, in_halo, kh, kw, stride, pad, cout, kpad, out_halo,
+                   relu, out_f32, deconv2x, variant, 1, stream, nullptr, 0, 0, 0, 0, 1, &sa);
 }
 
 int rs_op_conv2d_dual(const void* in, const void* in2, const void* w, const float* bias, void* out,

@@ -74,10 +74,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) 
     }
   }
   const long long oidx = (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 4;
-  if (p.out_f32) {
+  if (p.out_f32 == 1) {
     *(f32x4*)((float*)p.out + oidx) = f32x4{of[0], of[1], of[2], of[3]};
   } else {
     *(half4*)(p.out + oidx) = o;
+    if (p.out_f32 == 2) {      // split-operand mode: the lo plane holds what fp16 rounding left behind
+      half4 lo;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) lo[c] = (half_t)(of[c] - (float)o[c]);
+      *(half4*)(p.out + p.out_lo + oidx) = lo;
+    }
   }
 }
 
@@ -183,8 +189,16 @@ __global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreprocParam
       }
     }
     const long long oidx = (((long long)n * p.out_Hp + Y + 3) * p.out_Wp + X + 3) * 4;
-    if (p.out_f32) *(f32x4*)((float*)p.out + oidx) = f32x4{of[0], of[1], of[2], of[3]};
-    else *(half4*)(p.out + oidx) = o;
+    if (p.out_f32 == 1) *(f32x4*)((float*)p.out + oidx) = f32x4{of[0], of[1], of[2], of[3]};
+    else {
+      *(half4*)(p.out + oidx) = o;
+      if (p.out_f32 == 2) {
+        half4 lo;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lo[c] = (half_t)(of[c] - (float)o[c]);
+        *(half4*)(p.out + p.out_lo + oidx) = lo;
+      }
+    }
   }
 }
 
@@ -309,6 +323,67 @@ int launch_maxpool_f32(const float* in, float* out, int N, int Hi, int Wi, int H
 int launch_subsample2_f32(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s) {
   const long long total = (long long)N * Ho * Wo * C;
   hipLaunchKernelGGL(subsample2_f32_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, N, Hi, Wi, Ho, Wo, C);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
+// ---- split-operand variants (rs_spec.precision == 2): a value is hi + lo on two fp16 planes.  fp32(hi) + fp32(lo) is exact (22 significand
+// bits), so the maximum is taken on the sums and the winner's two halves are copied: no re-rounding ----
+__global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const half_t* in, long long in_lo, half_t* out, long long out_lo, int N, int Hi, int Wi, int Ho, int Wo, int C) {
+  const int cv = C >> 3;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Ho * Wo * cv;
+  if (gid >= total) return;
+  const int c8 = (int)(gid % cv);
+  long long t = gid / cv;
+  const int x = (int)(t % Wo); t /= Wo;
+  const int y = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  const int Hip = Hi + 2, Wip = Wi + 2;
+  half8 mh, ml;
+  float m[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { mh[i] = (half_t)0.f; ml[i] = (half_t)0.f; m[i] = 0.f; }
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const long long idx = (((long long)n * Hip + 2 * y + dy) * Wip + 2 * x + dx) * C + c8 * 8;
+      const half8 vh = *(const half8*)(in + idx), vl = *(const half8*)(in + in_lo + idx);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = (float)vh[i] + (float)vl[i];
+        if (v > m[i]) { m[i] = v; mh[i] = vh[i]; ml[i] = vl[i]; }
+      }
+    }
+  const long long o = (((long long)n * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * C + c8 * 8;
+  *(half8*)(out + o) = mh;
+  *(half8*)(out + out_lo + o) = ml;
+}
+__global__ __launch_bounds__(256) void subsample2_split_kernel(const half_t* in, long long in_lo, half_t* out, long long out_lo, int N, int Hi, int Wi, int Ho, int Wo, int C) {
+  const int cv = C >> 3;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Ho * Wo * cv;
+  if (gid >= total) return;
+  const int c8 = (int)(gid % cv);
+  long long t = gid / cv;
+  const int x = (int)(t % Wo); t /= Wo;
+  const int y = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  const long long i = (((long long)n * (Hi + 2) + 2 * y + 1) * (Wi + 2) + 2 * x + 1) * C + c8 * 8;
+  const long long o = (((long long)n * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * C + c8 * 8;
+  *(half8*)(out + o) = *(const half8*)(in + i);
+  *(half8*)(out + out_lo + o) = *(const half8*)(in + in_lo + i);
+}
+int launch_maxpool_split(const half_t* in, long long in_lo, half_t* out, long long out_lo, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s) {
+  const long long total = (long long)N * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(maxpool3x3s2_split_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, in_lo, out, out_lo, N, Hi, Wi, Ho, Wo, C);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+int launch_subsample2_split(const half_t* in, long long in_lo, half_t* out, long long out_lo, int N, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s) {
+  const long long total = (long long)N * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(subsample2_split_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, in, in_lo, out, out_lo, N, Hi, Wi, Ho, Wo, C);
   RS_HIP(hipGetLastError());
   return RS_OK;
 }

@@ -23,7 +23,8 @@ _LIB: Optional[C.CDLL] = None
 # RS_ENGINE_LIB: another build of the library (diagnostic builds of tools/ubench: ablations, clock probes); default = the in-tree one
 LIB_PATH = os.environ.get("RS_ENGINE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librs_engine.so")
 MAX_LEVELS, MAX_ANCHORS, MASK_SIDE = 5, 8, 28
-DT_NP = {1: np.float16, 2: np.float32, 3: np.int32, 4: np.uint8}
+DT_NP = {1: np.float16, 2: np.float32, 3: np.int32, 4: np.uint8, 5: np.float16}       # 5: two fp16 planes (split-operand mode), value = hi + lo
+DT_SPLIT16 = 5
 
 
 class RsError(RuntimeError):
@@ -113,6 +114,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_op_conv2d.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 17 + [vp]
     lib.rs_op_bneck_tail.argtypes = [vp] * 12 + [i32, i32, i32, i32, vp]
     lib.rs_op_conv2d_dual.argtypes = [vp, vp, vp, vp, vp] + [i32] * 19 + [vp]
+    i64 = C.c_int64
+    lib.rs_op_conv2d_split.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp, i64] + [i32] * 16 + [vp]
     lib.rs_op_conv2d_dgrad.argtypes = [vp] * 7 + [i32] * 14 + [vp]
     lib.rs_op_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i32] * 13 + [vp]
     lib.rs_op_nms.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp]
@@ -202,7 +205,7 @@ def make_rs_spec(spec: EngineSpec) -> RsSpec:
     s.mask_on, s.mask_pooler_resolution = int(spec.mask_on), spec.mask_pooler_resolution
     s.mask_num_conv, s.mask_conv_dim = spec.mask_num_conv, spec.mask_conv_dim
     s.mask_threshold, s.scale_clamp = spec.mask_threshold, spec.scale_clamp
-    s.precision = {"fp16": 0, "fp32": 1}[spec.precision]
+    s.precision = {"fp16": 0, "fp32": 1, "split": 2}[spec.precision]
     return s
 
 
@@ -520,13 +523,26 @@ class Engine:
         """Copy an intermediate tensor to the host.  NHWC activations lose their halo; ``n`` limits the
         leading (batch) dimension."""
         ptr, dt, shape, halo = self.tensor_ptr(name)
-        if n is not None:
-            shape = (min(n, shape[0]),) + shape[1:]
-        a = np.empty(shape, dt)
-        _check(self.lib, self.lib.rs_memcpy_d2h(a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), a.nbytes), "rs_memcpy_d2h")
+        if self.tensor_is_split(name):
+            # split-operand mode: two fp16 planes of the full shape back to back; fp32(hi) + fp32(lo) is exact
+            planes = np.empty((2,) + shape, np.float16)
+            _check(self.lib, self.lib.rs_memcpy_d2h(planes.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), planes.nbytes), "rs_memcpy_d2h")
+            a = planes[0].astype(np.float32) + planes[1].astype(np.float32)
+            if n is not None:
+                a = a[: min(n, shape[0])]
+        else:
+            if n is not None:
+                shape = (min(n, shape[0]),) + shape[1:]
+            a = np.empty(shape, dt)
+            _check(self.lib, self.lib.rs_memcpy_d2h(a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), a.nbytes), "rs_memcpy_d2h")
         if strip_halo and halo:
             a = a[:, halo:-halo, halo:-halo]
         return a
+
+    def tensor_is_split(self, name: str) -> bool:
+        dt = C.c_int32()
+        _check(self.lib, self.lib.rs_engine_tensor(self._h, name.encode(), None, C.byref(dt), None, None, None), f"rs_engine_tensor({name})")
+        return dt.value == DT_SPLIT16
 
     def set_profiling(self, mode: int) -> None:
         """0 off, 1 per-stage events + host wait, 2 events only (read back by ``stage_times``)."""

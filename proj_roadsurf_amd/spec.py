@@ -102,7 +102,8 @@ class EngineSpec:
     mask_pooler_sampling_ratio: int = 0       # R:220
     mask_pooler_type: str = "ROIAlignV2"      # R:221
     mask_threshold: float = 0.5               # detector_postprocess default
-    # ---- engine option (not a detectron2 key): "fp16" = production MFMA path, "fp32" = validation mode
+    # ---- engine option (not a detectron2 key): "fp16" = production MFMA path, "fp32" = the reference's arithmetic on the fp32 matrix cores,
+    # "split" = reference-equivalent arithmetic on the fp16 matrix cores (hi + lo operand planes, three products; inference engines)
     precision: str = "fp16"
     # ---- derived constants
     scale_clamp: float = field(default=math.log(1000.0 / 16.0))   # Box2BoxTransform default

@@ -542,4 +542,32 @@ def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False
                 T[k + "32"] = v
         if train and "roi_heads.mask_head.predictor16.m32" in T:      # the reference-precision trainer's 16-row mask predictor operand
             T["roi_heads.mask_head.predictor16.w32"] = T["roi_heads.mask_head.predictor16.m32"]
+    if spec.precision == "split":
+        # split-operand mode (csrc/common.h ConvParams::split): every GEMM weight as hi + lo fp16 planes of the row-scaled fp32 weight
+        T32 = engine_tensors(spec, W, w_dtype=np.float32)
+        for k, v in T32.items():
+            if k.endswith(".w") and k != "roi_heads.mask_head.predictor.w":
+                T[k + "s"], T[k + "si"] = split_planes(v)
+        # first block of every res stage: conv3 and the projection shortcut as one GEMM over K = [conv2 out | block input] (engine_tensors
+        # builds this operand for the fp16 path only)
+        for name in [n for n in T32 if n.endswith(".shortcut.w")]:
+            blk = name[: -len(".shortcut.w")]
+            w3, wsc = T32[blk + ".conv3.w"], T32[blk + ".shortcut.w"]
+            if w3.shape[1] % 64 == 0 and wsc.shape[1] % 64 == 0 and blk + ".conv3sc.b" in T:
+                T[blk + ".conv3sc.ws"], T[blk + ".conv3sc.wsi"] = split_planes(np.concatenate([w3, wsc], 1))
     return serialize(T)
+
+
+def split_planes(w32: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """fp32 GEMM weight [rows][K] -> (fp16 [2 * rows][K]: hi rows then lo rows of ``w * 2**e(row)``, fp32 [rows]: ``2**-e(row)``).
+    The power of two puts the row's largest magnitude in [2**13, 2**14): the lo parts (<= 2**-11 of their hi) then stay normal fp16
+    numbers for every element down to 2**-17 of the row maximum, and hi + lo carries 22 significand bits of the scaled weight."""
+    w32 = np.ascontiguousarray(w32, np.float32)
+    mx = np.abs(w32).max(axis=1)
+    e = np.where(mx > 0, 13 - np.floor(np.log2(np.maximum(mx, np.float32(1e-38)))), 0.0)
+    e = np.clip(e, -100, 100)
+    scale = np.exp2(e).astype(np.float32)
+    ws = (w32.astype(np.float64) * scale[:, None].astype(np.float64)).astype(np.float32)        # exact: a power of two
+    hi = ws.astype(np.float16)
+    lo = (ws - hi.astype(np.float32)).astype(np.float16)
+    return np.concatenate([hi, lo], 0), (1.0 / scale.astype(np.float64)).astype(np.float32)

@@ -13,7 +13,8 @@ from proj_roadsurf_amd.synthetic import synthetic_tiles
 from proj_roadsurf_amd.weights import synthetic_weights
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-spec = EngineSpec(num_classes=2, precision="fp32")
+PREC = sys.argv[2] if len(sys.argv) > 2 else "fp32"      # "fp32" (fp32 matrix cores) or "split" (hi + lo planes on the fp16 matrix cores)
+spec = EngineSpec(num_classes=2, precision=PREC)
 W = synthetic_weights(spec, seed=0)
 tiles = synthetic_tiles(B, 512, 512, 3, seed=1234)
 e = Engine(spec, W, (512, 512, 3), max_batch=B)
