@@ -160,6 +160,8 @@ struct ConvParams {
   int split;
   long long in_lo, w_lo, out_lo, res_lo, up_lo, in2_lo;
   const float* wscale;  // [rows] fp32, power of two
+  long long head_w_lo;        // fused head (head_w) in the split-operand mode: offset of its lo plane, and
+  const float* head_scale;    // its inverse row scales [16]
   ConvSeg seg[RS_MAX_SEGS];
 };
 

@@ -249,6 +249,60 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
       wsc[i * 4 + 0] = s4[0]; wsc[i * 4 + 1] = s4[1]; wsc[i * 4 + 2] = s4[2]; wsc[i * 4 + 3] = s4[3];
     }
   }
+  if (!TRAIN && SPLIT && p.head_w) {
+    // The fused 16-row head in the split-operand mode: relu(acc * scale + bias) is split into hi + lo exactly as the store would split it, and
+    // the head is three MFMA products per 32-deep step (H_hi.B_hi, H_hi.B_lo, H_lo.B_hi) on the head's own hi / lo planes (row-scaled; the
+    // inverse scale is applied when the four channel waves' partial sums are added).
+    const half_t* hw = p.head_w + (long long)fi * 256 + wch * 64 + fq * 8;
+    const half8 ha0 = *(const half8*)hw, ha1 = *(const half8*)(hw + 32);
+    const half8 hl0 = *(const half8*)(hw + p.head_w_lo), hl1 = *(const half8*)(hw + p.head_w_lo + 32);
+    f32x4 hacc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      half8 b0, b1, l0, l1;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float f = acc[i][j][r] * wsc[i * 4 + r] + bias[i * 4 + r];
+          if (p.relu) f = f > 0.f ? f : 0.f;
+          f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+          const half_t h = (half_t)f;
+          const half_t l = (half_t)(f - (float)h);
+          if (i < 2) { b0[i * 4 + r] = h; l0[i * 4 + r] = l; } else { b1[(i - 2) * 4 + r] = h; l1[(i - 2) * 4 + r] = l; }
+        }
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha0, b0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha1, b1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha0, l0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha1, l1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(hl0, b0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(hl1, b1, a, 0, 0, 0);
+      hacc[j] = a;
+    }
+    asm volatile("s_barrier" ::: "memory");          // every wave is past its last fragment reads: the stage buffers are free
+    float* part = (float*)smem;                      // [4 channel waves][2 WPX pixels][16] partial sums
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) *(f32x4*)(part + ((wch * 2 * WPX + wpx * WPX + j * 16 + fi) * 16 + fq * 4)) = hacc[j];
+    __syncthreads();
+    const int px = tid >> 1, oh = (tid & 1) * 8;
+    const int m = m0 + px;
+    if (px < 2 * WPX && m < M) {
+      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s0 += *(const f32x4*)(part + ((w * 2 * WPX + px) * 16 + oh));
+        s1 += *(const f32x4*)(part + ((w * 2 * WPX + px) * 16 + oh + 4));
+      }
+      s0 = s0 * *(const f32x4*)(p.head_scale + oh) + *(const f32x4*)(p.head_b + oh);
+      s1 = s1 * *(const f32x4*)(p.head_scale + oh + 4) + *(const f32x4*)(p.head_b + oh + 4);
+      const int x = m % Wo, t = m / Wo, y = t % Ho, n = t / Ho;
+      float* op = g_head_out + ((long long)(n * Ho + y) * Wo + x) * 16 + oh;
+      *(f32x4*)op = s0;
+      *(f32x4*)(op + 4) = s1;
+    }
+    return;
+  }
   if (!TRAIN && !SPLIT && p.head_w) {
     // Fused 16-row 1x1 head on top of this convolution (RPN: objectness + anchor deltas): the 256-channel output tile never leaves
     // the CU.  relu(acc + bias), rounded to fp16 exactly as the store would round it, is per lane 16 consecutive channels of a
@@ -521,7 +575,7 @@ int launch_conv_deep(const ConvParams& p0, hipStream_t stream, int tile_px) {
   RS_CHECK(!p.head_w || (p.Cout == BN && p.head_b && p.head_out && !p.res && !p.up && !p.down && !p.res32 && !p.mask), RS_ERR_ARG,
            "conv_deep: the fused head needs Cout == 256, its bias and output, and no other epilogue option");
   RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
-  RS_CHECK(!p.split || (p.wscale && !p.head_w && !p.down && !p.res32 && !p.mask), RS_ERR_UNSUPPORTED, "conv_deep: the split-operand mode needs the row scales and has no fused head / training epilogue");
+  RS_CHECK(!p.split || (p.wscale && (!p.head_w || p.head_scale) && !p.down && !p.res32 && !p.mask), RS_ERR_UNSUPPORTED, "conv_deep: the split-operand mode needs the row scales (the fused head's too) and has no training epilogue");
   if (tile_px != 256) {
     RS_CHECK(tile_px >= 64 && tile_px <= 224 && tile_px % 32 == 0 && !p.down && !p.res32 && !p.mask, RS_ERR_ARG,
              "conv_deep: tile height %d (256, or 64 .. 224 in steps of 32 without training epilogue options)", tile_px);
@@ -618,7 +672,7 @@ int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const 
     done = true;
   }
   if (p.split) {
-    RS_CHECK(!p.head_w, RS_ERR_UNSUPPORTED, "conv_deep_multi: no fused head in the split-operand mode");
+    RS_CHECK(!p.head_w || p.head_scale, RS_ERR_ARG, "conv_deep_multi: the fused head of the split-operand mode needs its row scales");
     hipLaunchKernelGGL((conv_deep_kernel<0, false, 8, true>), dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, p);
     RS_HIP(hipGetLastError());
     return RS_OK;

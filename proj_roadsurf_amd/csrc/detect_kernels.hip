@@ -636,7 +636,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
 // ---------------------------------------------------------------------------------------------
 #define RS_ROI_WMAX 24   // window rows/cols per bin held in LDS (g <= 22)
 #define RS_ROI_PMAX 14
-__global__ __launch_bounds__(256, 6) void roi_align_win_kernel(const RoiAlignParams p) {
+// SPLIT: the split-operand precision mode (p.f32 == 2): features and output are hi / lo fp16 planes; a cell is fp32(hi) + fp32(lo) (exact).
+template <bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 4 : 6) void roi_align_win_kernel(const RoiAlignParams p) {
   __shared__ float s_w[2][RS_ROI_PMAX][RS_ROI_WMAX];   // [0] = wy[ph][j], [1] = wx[pw][i]
   __shared__ int s_base[2][RS_ROI_PMAX], s_len[2][RS_ROI_PMAX];
   int entry = blockIdx.x;
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(256, 6) void roi_align_win_kernel(const RoiAlignPar
     for (int b = hw; b < P * P; b += 8) {
       const int ph = b / P, pw = b - ph * P;
       *(half8*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) = z;
+      if constexpr (SPLIT) *(half8*)(out + p.out_lo + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) = z;
     }
     return;
   }
@@ -675,6 +678,19 @@ __global__ __launch_bounds__(256, 6) void roi_align_win_kernel(const RoiAlignPar
   const int H = p.H[lvl], W = p.W[lvl];
   const float sc = p.scale[lvl];
   const half_t* feat = p.feat[lvl] + ((long long)n * (H + 2) * (W + 2) + (W + 2) + 1) * 256 + l32 * 8;   // cell (0,0)
+  const long long flo = SPLIT ? p.feat_lo[lvl] : 0;
+  // a cell's 8 channels as floats
+  auto cell = [&](const half_t* q, float (&f)[8]) {
+    const half8 v = *(const half8*)q;
+    if constexpr (SPLIT) {
+      const half8 u = *(const half8*)(q + flo);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) f[c] = (float)v[c] + (float)u[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) f[c] = (float)v[c];
+    }
+  };
   const float roi_start_w = x1 * sc - 0.5f;
   const float roi_start_h = y1 * sc - 0.5f;
   const float roi_w = (x2 * sc - 0.5f) - roi_start_w;
@@ -734,19 +750,21 @@ __global__ __launch_bounds__(256, 6) void roi_align_win_kernel(const RoiAlignPar
         const half_t* fr = f0 + (long long)j * (W + 2) * 256;
         int i = 0;
         for (; i + 2 <= nx; i += 2) {
-          const half8 v0 = *(const half8*)(fr + i * 256);
-          const half8 v1 = *(const half8*)(fr + (i + 1) * 256);
+          float v0[8], v1[8];
+          cell(fr + i * 256, v0);
+          cell(fr + (i + 1) * 256, v1);
           const float w0 = wj * wx[i], w1 = wj * wx[i + 1];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) acc[c] += w0 * (float)v0[c];
+          for (int c = 0; c < 8; ++c) acc[c] += w0 * v0[c];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) acc[c] += w1 * (float)v1[c];
+          for (int c = 0; c < 8; ++c) acc[c] += w1 * v1[c];
         }
         if (i < nx) {
-          const half8 v0 = *(const half8*)(fr + i * 256);
+          float v0[8];
+          cell(fr + i * 256, v0);
           const float w0 = wj * wx[i];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) acc[c] += w0 * (float)v0[c];
+          for (int c = 0; c < 8; ++c) acc[c] += w0 * v0[c];
         }
       }
     } else {
@@ -765,20 +783,26 @@ __global__ __launch_bounds__(256, 6) void roi_align_win_kernel(const RoiAlignPar
           int xlo = (int)x, xhi;
           if (xlo >= W - 1) { xhi = xlo = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
           const float lx = x - (float)xlo, hx = 1.f - lx;
-          const half8 v1 = *(const half8*)(feat + ((long long)ylo * (W + 2) + xlo) * 256);
-          const half8 v2 = *(const half8*)(feat + ((long long)ylo * (W + 2) + xhi) * 256);
-          const half8 v3 = *(const half8*)(feat + ((long long)yhi * (W + 2) + xlo) * 256);
-          const half8 v4 = *(const half8*)(feat + ((long long)yhi * (W + 2) + xhi) * 256);
+          float v1[8], v2[8], v3[8], v4[8];
+          cell(feat + ((long long)ylo * (W + 2) + xlo) * 256, v1);
+          cell(feat + ((long long)ylo * (W + 2) + xhi) * 256, v2);
+          cell(feat + ((long long)yhi * (W + 2) + xlo) * 256, v3);
+          cell(feat + ((long long)yhi * (W + 2) + xhi) * 256, v4);
           const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) acc[c] += w1 * (float)v1[c] + w2 * (float)v2[c] + w3 * (float)v3[c] + w4 * (float)v4[c];
+          for (int c = 0; c < 8; ++c) acc[c] += w1 * v1[c] + w2 * v2[c] + w3 * v3[c] + w4 * v4[c];
         }
       }
     }
-    half8 o;
+    half8 o, ol;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = (half_t)(acc[c] / count);
+    for (int c = 0; c < 8; ++c) {
+      const float f = acc[c] / count;
+      o[c] = (half_t)f;
+      if constexpr (SPLIT) ol[c] = (half_t)(f - (float)o[c]);
+    }
     *(half8*)(out + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) = o;
+    if constexpr (SPLIT) *(half8*)(out + p.out_lo + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) = ol;
   }
 }
 
@@ -1623,7 +1647,10 @@ int launch_roi_align(const RoiAlignParams& p, hipStream_t s) {
   RS_CHECK(p.C == 256, RS_ERR_UNSUPPORTED, "roi_align: C must be 256 (got %d)", p.C);
   RS_CHECK(p.S > 0, RS_ERR_ARG, "roi_align: S");
   const int use_win = rs_debug().roi_window;
-  if (!p.f32 && use_win && p.P <= RS_ROI_PMAX) hipLaunchKernelGGL(roi_align_win_kernel, dim3(p.S), dim3(256), 0, s, p);
+  // the windowed kernel pre-sums the sample weights per feature row / column (fp32 rounding of the weights: ~1e-7 relative); the fp32 validation
+  // mode keeps torchvision's per-sample order, the split-operand mode takes the window (RS_ROI_WINDOW=2: per-sample there too)
+  if (!p.f32 && use_win && p.P <= RS_ROI_PMAX) hipLaunchKernelGGL(roi_align_win_kernel<false>, dim3(p.S), dim3(256), 0, s, p);
+  else if (p.f32 == 2 && use_win == 1 && p.P <= RS_ROI_PMAX) hipLaunchKernelGGL(roi_align_win_kernel<true>, dim3(p.S), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(roi_align_kernel, dim3(p.S), dim3(256), 0, s, p);
   RS_HIP(hipGetLastError());
   return RS_OK;

@@ -395,7 +395,7 @@ int rs_engine::add_merged_convs(const std::string& name, const std::vector<Defer
                  q.in_off == common.in_off && q.out_Cs == common.out_Cs && q.out_pad == common.out_pad && q.Kpad == common.Kpad && q.relu == common.relu &&
                  !q.res && !q.up && !q.in2 && !q.m_count && q.mode == 0 && !q.out_f32,
              RS_ERR_ARG, "%s: map %d does not share the launch parameters of map 0", name.c_str(), (int)i);
-    RS_CHECK(q.head_w == common.head_w && q.head_b == common.head_b, RS_ERR_ARG, "%s: map %d has another fused head", name.c_str(), (int)i);
+    RS_CHECK(q.head_w == common.head_w && q.head_b == common.head_b && q.head_scale == common.head_scale, RS_ERR_ARG, "%s: map %d has another fused head", name.c_str(), (int)i);
     RS_CHECK(q.split == common.split && q.w_lo == common.w_lo, RS_ERR_ARG, "%s: map %d differs in the split-operand fields", name.c_str(), (int)i);
     segs[i].in = q.in; segs[i].w = q.w; segs[i].bias = q.bias; segs[i].out = q.out; segs[i].head_out = q.head_out;
     segs[i].in_lo = q.in_lo; segs[i].out_lo = q.out_lo; segs[i].wscale = q.wscale;
@@ -711,7 +711,8 @@ int rs_engine::build() {
   // inference engines: the 16-row head runs inside the epilogue of the merged 3x3 launch (conv_deep.hip, ConvParams::head_w), so the
   // 256-channel "rpn_conv" maps are never written
   const BlobEntry* headsp = findw("proposal_generator.rpn_head.headsp");
-  const bool fuse_heads = merge && !split && rs_debug().fuse_rpn_heads && head_cs == 16 && headsp != nullptr;
+  const BlobEntry* headsp_si = split ? find("proposal_generator.rpn_head.headsp.wsi") : nullptr;
+  const bool fuse_heads = merge && rs_debug().fuse_rpn_heads && head_cs == 16 && headsp != nullptr && (!split || headsp_si != nullptr);
   for (int l = 0; l < L; ++l) {
     const std::string ln = std::to_string(l + 2);
     Act t;
@@ -720,10 +721,11 @@ int rs_engine::build() {
       if ((rc = add_conv("rpn.conv" + ln, "proposal_generator.rpn_head.conv", P[l], t, 3, 1, 1, true, nullptr, nullptr, 256, 1, nullptr, nullptr, 1, &rpn_conv[l]))) return rc;
       if (fuse_heads) {
         const BlobEntry* hb = find("proposal_generator.rpn_head.heads.b");
-        RS_CHECK(hb && (int)headsp->dims[0] == 16 && (int)headsp->dims[1] == 256, RS_ERR_BLOB, "rpn head weights (chained order) missing or not 16 x 256");
+        RS_CHECK(hb && wrows(headsp) == 16 && (int)headsp->dims[1] == 256, RS_ERR_BLOB, "rpn head weights (chained order) missing or not 16 x 256");
         rpn_conv[l].p.head_w = (const half_t*)headsp->dev; rpn_conv[l].p.head_b = (const float*)hb->dev; rpn_conv[l].p.head_out = rpn_ho[l];
+        if (split) { rpn_conv[l].p.head_w_lo = 16 * 256; rpn_conv[l].p.head_scale = (const float*)headsp_si->dev; }
         rpn_conv[l].flops += 2.0 * P[l].H * P[l].W * 256 * 5 * A;
-        rpn_conv[l].bytes += (double)P[l].H * P[l].W * (head_cs * 4 - 256 * 2);       // the heads' output instead of the 256-channel map
+        rpn_conv[l].bytes += (double)P[l].H * P[l].W * (head_cs * 4 - 256 * 2 * (split ? 2 : 1));       // the heads' output instead of the 256-channel map
       }
       if (l == L - 1 && (rc = add_merged_convs(fuse_heads ? "rpn.conv+heads2-6" : "rpn.conv2-6", rpn_conv))) return rc;
       rpn_t[l] = t;
@@ -813,7 +815,7 @@ int rs_engine::build() {
   // visiting order of box.roi_align (RpnMergeParams::prop_order): inference engines on the windowed fp16 kernel only -- a training
   // engine overwrites the proposal buffer with its sampled RoIs after this stage
   int* prop_order = nullptr;
-  const bool roi_order = !f32 && !split && !g_trainer_unfused_shortcut && rs_debug().roi_order != 0;
+  const bool roi_order = !f32 && !(split && rs_debug().roi_window != 1) && !g_trainer_unfused_shortcut && rs_debug().roi_order != 0;
   if (roi_order) {
     if ((rc = alloc((void**)&prop_order, (size_t)NB * PC * 4))) return rc;
     reg("proposal_order", prop_order, DT_I32, {NB, PC}, 0);

@@ -548,6 +548,10 @@ def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False
         for k, v in T32.items():
             if k.endswith(".w") and k != "roi_heads.mask_head.predictor.w":
                 T[k + "s"], T[k + "si"] = split_planes(v)
+        # the RPN's 16 x 256 head with its K columns in the register-chaining order: it runs inside the epilogue of the RPN's 3x3 convolution
+        hp = "proposal_generator.rpn_head."
+        if T32[hp + "heads.w"].shape == (16, 256):
+            T[hp + "headsp.ws"], T[hp + "headsp.wsi"] = split_planes(_perm_k64(T32[hp + "heads.w"], 64))
         # first block of every res stage: conv3 and the projection shortcut as one GEMM over K = [conv2 out | block input] (engine_tensors
         # builds this operand for the fp16 path only)
         for name in [n for n in T32 if n.endswith(".shortcut.w")]:
