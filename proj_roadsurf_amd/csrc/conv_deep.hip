@@ -30,9 +30,12 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
 
 // One tile: NJ * 32 pixels x 256 channels.  TRAIN: instantiation with the backward-epilogue options down / res32 / mask (conv_igemm.hip),
 // compiled out of the inference kernel
-// SPLIT: the split-operand precision mode (ConvParams::split, common.h): the K walk makes three passes per 64-channel slice (W_hi.X_hi, W_hi.X_lo,
-// W_lo.X_hi -- plane offsets added to the staged addresses, nothing else in the loop changes), the epilogue descales by the row's power of two and
-// writes hi / lo planes.
+// SPLIT: the split-operand precision mode (ConvParams::split, common.h).  A K step covers 32 channels and its 128-byte LDS rows are [32 hi halfs | 32 lo
+// halfs] (data chunks 0-3 from the hi plane, 4-7 from the lo plane: a per-lane constant in the LDS-DMA source pointers), so the stages, the LDS-DMA pieces
+// and the fragment reads of a step are those of the fp16 kernel -- the "first half" fragments are the hi ones, the "second half" the lo ones -- while the
+// step runs THREE MFMA blocks, W_hi.X_lo, W_hi.X_hi, W_lo.X_hi (the order conv_igemm.hip uses), with the reads of the other fragment sets in flight under
+// them (own main loop below): 96 MFMAs per 24 fragment reads and 8 LDS-DMA pieces instead of 64, so the LDS port that co-bounds the fp16 kernel has slack.
+// The epilogue descales by the row's power of two and writes hi / lo planes.
 template <int DBG, bool TRAIN, int NJ, bool SPLIT>
 __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, const half_t* g_in, const half_t* g_w, const float* g_bias, void* g_out,
                                                float* g_head_out, const int Ho, const int Wo, const int in_Hp, const int in_Wp, const int out_Hp, const int out_Wp,
@@ -61,28 +64,25 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
     const int n = t / Ho;
     const long long base =
         ((long long)(n * in_Hp + y * p.stride + p.in_off) * in_Wp + x * p.stride + p.in_off) * p.in_Cs;
-    aptr[ps] = g_in + base + (lchk ^ lrow) * 8;
+    if constexpr (SPLIT) aptr[ps] = g_in + base + ((lchk ^ lrow) & 3) * 8 + ((lchk ^ lrow) >> 2) * in_lo;
+    else aptr[ps] = g_in + base + (lchk ^ lrow) * 8;
   }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int row = ps * 64 + wave * 8 + lrow;
     const int key = (row & 3) | (((row >> 4) & 1) << 2);
-    wptr[ps] = g_w + (long long)(n0 + row) * p.Kpad + (lchk ^ key) * 8;
+    if constexpr (SPLIT) wptr[ps] = g_w + (long long)(n0 + row) * p.Kpad + ((lchk ^ key) & 3) * 8 + ((lchk ^ key) >> 2) * p.w_lo;
+    else wptr[ps] = g_w + (long long)(n0 + row) * p.Kpad + (lchk ^ key) * 8;
   }
-  const int nk = (SPLIT ? 3 : 1) * p.KH * p.KW * (p.Cin >> 6);
+  constexpr int KST = SPLIT ? 32 : 64;      // channels a K step covers
+  const int nk = p.KH * p.KW * (p.Cin / KST);
 
   // two independent walkers over the K steps (64-channel slice outer, taps inner -- conv_igemm.hip): the
   // activation walker runs one step ahead of the weight walker
   int akh = 0, akw = 0, ac0 = 0, an = 0;      // an = index of the next activation step to issue
-  int apass = 0, wpass = 0;                   // SPLIT: order (slice outer, pass, taps inner), as conv_igemm.hip
   auto stage_a = [&]() {
-    long long off = (akh * in_Wp + akw) * p.in_Cs + ac0;
-    if constexpr (SPLIT) {
-      if (apass == 1) off += in_lo;
-      if (++akw == p.KW) { akw = 0; if (++akh == p.KH) { akh = 0; if (++apass == 3) { apass = 0; ac0 += 64; } } }
-    } else {
-      if (++akw == p.KW) { akw = 0; if (++akh == p.KH) { akh = 0; ac0 += 64; } }
-    }
+    const int off = (akh * in_Wp + akw) * p.in_Cs + ac0;
+    if (++akw == p.KW) { akw = 0; if (++akh == p.KH) { akh = 0; ac0 += KST; } }
     char* abase = smem + (an % 3) * ASTAGE;
     ++an;
     if (DBG & 1) return;   // ceiling experiment: no global traffic
@@ -92,13 +92,8 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
   };
   int wkh = 0, wkw = 0, wc0 = 0, wn = 0;
   auto stage_w = [&]() {
-    long long koff = (wkh * p.KW + wkw) * p.Cin + wc0;
-    if constexpr (SPLIT) {
-      if (wpass == 2) koff += p.w_lo;
-      if (++wkw == p.KW) { wkw = 0; if (++wkh == p.KH) { wkh = 0; if (++wpass == 3) { wpass = 0; wc0 += 64; } } }
-    } else {
-      if (++wkw == p.KW) { wkw = 0; if (++wkh == p.KH) { wkh = 0; wc0 += 64; } }
-    }
+    const int koff = (wkh * p.KW + wkw) * p.Cin + wc0;
+    if (++wkw == p.KW) { wkw = 0; if (++wkh == p.KH) { wkh = 0; wc0 += KST; } }
     char* wbase = smem + W_BASE + (wn & 1) * WSTAGE;
     ++wn;
     if (DBG & 1) return;
@@ -174,6 +169,91 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
   __builtin_amdgcn_sched_barrier(0);
   if (nk > 1) stage_w();
   if (nk > 2) stage_a();
+  if constexpr (SPLIT) {
+    // Split-operand main loop.  Register sets: wf0 = W_hi, wf1 = W_lo, xf0 = X_hi, xf1 = X_lo of the current step.  Per step, three MFMA blocks with
+    // the reads of the sets they do not touch in flight, one barrier:
+    //
+    //   reads X_hi(t) | MFMA W_hi.X_lo | reads W_lo(t) | MFMA W_hi.X_hi | own pieces of t+1 landed, barrier | issue w(t+2), acts(t+3),
+    //   reads W_hi(t+1), X_lo(t+1) | MFMA W_lo.X_hi
+    //
+    // At the barrier every wave has read all four sets of step t (lgkmcnt(0)), so step t's buffers are refilled there.  The two waves of a SIMD take
+    // the last block and the issue work in opposite order, as in the fp16 loop below.
+#define RS_RD_W(wf, wa) RS_DSR(wf[0], wa, 0); RS_DSR(wf[1], wa, 512); RS_DSR(wf[2], wa, 1024); RS_DSR(wf[3], wa, 1536);
+#define RS_RD_X(xf, xa)                                                                             \
+  RS_DSR(xf[0], xa, 0); RS_DSR(xf[1], xa, 2048);                                                    \
+  if constexpr (NJ > 2) { RS_DSR(xf[2], xa, 4096); }                                                \
+  if constexpr (NJ > 3) { RS_DSR(xf[3], xa, 6144); }                                                \
+  if constexpr (NJ > 4) { RS_DSR(xf[4], xa, 8192); }                                                \
+  if constexpr (NJ > 5) { RS_DSR(xf[5], xa, 10240); }                                               \
+  if constexpr (NJ > 6) { RS_DSR(xf[6], xa, 12288); }                                               \
+  if constexpr (NJ > 7) { RS_DSR(xf[7], xa, 14336); }
+    {
+      const unsigned wa = wa0, xa = xa1;         // W_hi(0), X_lo(0)
+      RS_RD_W(wf0, wa)
+      RS_RD_X(xf1, xa)
+    }
+    int sab = 0;                                 // t % 3
+    for (int t = 0; t < nk; ++t) {
+      const unsigned wst = (t & 1) * WSTAGE, ast = sab * ASTAGE;
+      __builtin_amdgcn_sched_barrier(0);
+      { const unsigned xa = xa0 + ast; RS_RD_X(xf0, xa) }                 // X_hi(t)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NJ) : "memory");        // W_hi, X_lo (older) have landed; X_hi stays in flight
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf1[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      { const unsigned wa = wa1 + wst; RS_RD_W(wf1, wa) }                 // W_lo(t)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                  // X_hi has landed
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int snext = sab == 2 ? 0 : sab + 1;
+      if (t + 1 < nk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // W_lo landed = my reads of step t's buffers are done
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APS) : "memory");   // my pieces of step t+1 (all but acts(t+2))
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (wpx) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf0[j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 2 < nk) stage_w();                 // w(t+2)    -> weight buffer of step t
+        if (t + 3 < nk) stage_a();                 // acts(t+3) -> activation buffer of step t
+        {
+          const unsigned wa = wa0 + ((t + 1) & 1) * WSTAGE, xa = xa1 + snext * ASTAGE;      // W_hi(t+1), X_lo(t+1)
+          RS_RD_W(wf0, wa)
+          RS_RD_X(xf1, xa)
+        }
+        if (wpx) { sab = snext; continue; }
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // last step: W_lo has landed
+      }
+      sab = snext;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf0[j], acc[i][j], 0, 0, 0);
+    }
+#undef RS_RD_W
+#undef RS_RD_X
+  } else {
   reads0(0, 0);
   int abuf = 0;                                  // t % 3
   for (int t = 0; t < nk; ++t) {
@@ -225,6 +305,7 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+  }
   }
 
 #ifdef RS_CLOCK_PROBE

@@ -40,8 +40,12 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
 // TRAIN: instantiation with the backward-epilogue options (down / res32 / mask / out_stride).  They are compiled out of the
 // inference instantiations: carrying them as run-time branches cost the small-tile, occupancy-sensitive layers 20-70 %
 // (measured: fused deconv 0.33 -> 0.58 ms, fpn_lateral2 0.24 -> 0.35 ms, 1760 -> 1530 tiles/s end to end).
-// SPLIT: the split-operand precision mode (ConvParams::split, common.h): three passes per 64-channel slice over the hi / lo planes of both
-// operands, per-row weight descale in the epilogue, outputs written as hi / lo planes.  Compiled out of the fp16 instantiations.
+// SPLIT: the split-operand precision mode (ConvParams::split, common.h).  A K step covers 32 channels: the 128-byte LDS row of an operand is
+// [32 hi halfs | 32 lo halfs] of the same channels (data chunks 0-3 from the hi plane, 4-7 from the lo plane -- a per-lane constant added to the
+// LDS-DMA source address), so that both planes of both operands are staged ONCE and the three products W_hi.X_lo, W_hi.X_hi, W_lo.X_hi (in this
+// order, the same in conv_deep.hip: every tile accumulates an output in the same order) run on fragments of one stage.  K order: 32-channel slice
+// outer, taps inner.  The stem (SMALLC: per-chunk tap table) keeps three passes over its padded K instead (hi.hi, hi.lo, lo.hi).  Per-row weight
+// descale in the epilogue, outputs written as hi / lo planes.  Compiled out of the fp16 instantiations.
 template <int WPX, int WCH, int MI, int NJ, bool SMALLC, bool GLDS, bool PERSIST, bool TRAIN = false, bool SPLIT = false>
 __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvParams p) {
   using T = Tile<WPX, WCH, MI, NJ>;
@@ -88,14 +92,17 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       const int y = t % p.Ho;
       const int n = t / p.Ho;
       // LDS slot lchk of row r holds data chunk (lchk ^ (r & 7)); r & 7 == lrow here.
+      const int dch = lchk ^ lrow;      // data chunk this lane stages
       if (second) {
         const long long base =
             ((long long)(n * p.in2_Hp + y * p.stride2 + p.in2_off) * p.in2_Wp + x2 * p.stride2 + p.in2_off) * p.in2_Cs;
-        aptr[ps] = p.in2 + base + (lchk ^ lrow) * 8;
+        if constexpr (SPLIT) aptr[ps] = p.in2 + base + (dch & 3) * 8 + (dch >> 2) * p.in2_lo;
+        else aptr[ps] = p.in2 + base + dch * 8;
       } else {
         const long long base =
             ((long long)(n * p.in_Hp + y * p.stride + p.in_off) * p.in_Wp + x2 * p.stride + p.in_off) * p.in_Cs;
-        aptr[ps] = p.in + base + (SMALLC ? 0 : ((lchk ^ lrow) * 8));
+        if constexpr (SPLIT && !SMALLC) aptr[ps] = p.in + base + (dch & 3) * 8 + (dch >> 2) * p.in_lo;
+        else aptr[ps] = p.in + base + (SMALLC ? 0 : (dch * 8));
       }
     }
   };
@@ -112,12 +119,15 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       const int row = ps * NW * 8 + wave * 8 + lrow;
       const int key = (row & 3) | (((row / (4 * MI)) & 1) << 2);
       const int rr = row < BN ? row : BN - 1;
-      wptr[ps] = p.w + (long long)(n0 + rr) * p.Kpad + (lchk ^ key) * 8;
+      if constexpr (SPLIT && !SMALLC) wptr[ps] = p.w + (long long)(n0 + rr) * p.Kpad + ((lchk ^ key) & 3) * 8 + ((lchk ^ key) >> 2) * p.w_lo;
+      else wptr[ps] = p.w + (long long)(n0 + rr) * p.Kpad + (lchk ^ key) * 8;
     }
   };
 
-  const int nkb = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> 6) + (p.in2 ? (p.Cin2 >> 6) : 0));
-  const int nk = SPLIT ? 3 * nkb : nkb;
+  constexpr int KSH = (SPLIT && !SMALLC) ? 5 : 6;      // log2 of the channels a K step covers
+  constexpr int KST = 1 << KSH;
+  const int nkb = SMALLC ? (p.Kpad >> 6) : (p.KH * p.KW * (p.Cin >> KSH) + (p.in2 ? (p.Cin2 >> KSH) : 0));
+  const int nk = (SPLIT && SMALLC) ? 3 * nkb : nkb;
   const int nst = p.stages == 1 ? 1 : 2;   // LDS K-step buffers: 1 = shallow-K layers (more workgroups per CU)
   int* koff_s = (int*)(smem + nst * T::STAGE);
   if constexpr (SMALLC) {
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   }
 
   int w_koff = 0;               // element offset of the current K step inside a weight row (set by next_off())
-  long long a_pl = 0, w_pl = 0; // SPLIT: plane offsets (elements) of the current K step's operands (0 = hi plane)
+  long long a_pl = 0, w_pl = 0; // SPLIT && SMALLC: plane offsets (elements) of the current pass's operands (0 = hi plane)
   auto stage = [&](int buf, int t, int a_off) {
     char* abase = smem + buf * T::STAGE;
     char* wbase = abase + BM * 128;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       } else {
         g = aptr[ps] + a_off;
       }
-      if constexpr (SPLIT) g += a_pl;
+      if constexpr (SPLIT && SMALLC) g += a_pl;
       char* dst = abase + (ps * NW * 8 + wave * 8) * 128;
       if constexpr (GLDS) {
         glds16(g, dst);
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     for (int ps = 0; ps < PW; ++ps) {
       if (ps * NW * 8 + wave * 8 < BN) {   // wave-uniform
         const half_t* g = wptr[ps] + (SMALLC ? t * 64 : w_koff);
-        if constexpr (SPLIT) g += w_pl;
+        if constexpr (SPLIT && SMALLC) g += w_pl;
         char* dst = wbase + (ps * NW * 8 + wave * 8) * 128;
         if constexpr (GLDS) {
           glds16(g, dst);
@@ -183,7 +193,6 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
   const int c1_off = ((4 + fq) ^ fkey) * 16;    // kk = 1
 
   int kh = 0, kw = 0, c0 = 0;   // position of the NEXT K step to stage
-  int pass = 0;                 // SPLIT: 0 = W_hi.X_hi, 1 = W_hi.X_lo, 2 = W_lo.X_hi; order (slice outer, pass, taps inner)
   // K-step order: 64-channel slice OUTER, filter taps INNER.  All KH*KW taps of one channel slice touch the
   // same ~(rows+2) x W x 128 B of the input, so a tile's live footprint between re-reads is 1/(Cin/64) of the
   // taps-outer order and stays L2-resident (256-ch 3x3 @200x200: 85 KB instead of 338 KB per tile, 32 tiles
@@ -193,31 +202,14 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
       if (c0 == p.Cin) setup_acts(true);     // the first source's pointers are dead from here on: reuse the registers
       const int off = c0 - p.Cin;
       w_koff = p.KH * p.KW * p.Cin + off;
-      if constexpr (SPLIT) {
-        a_pl = pass == 1 ? p.in2_lo : 0;
-        w_pl = pass == 2 ? p.w_lo : 0;
-        if (++pass == 3) { pass = 0; c0 += 64; }
-      } else {
-        c0 += 64;
-      }
+      c0 += KST;
       return off;
     }
     const int off = (kh * p.in_Wp + kw) * p.in_Cs + c0;
     w_koff = (kh * p.KW + kw) * p.Cin + c0;
-    if constexpr (SPLIT) {
-      a_pl = pass == 1 ? p.in_lo : 0;
-      w_pl = pass == 2 ? p.w_lo : 0;
-    }
     if (++kw == p.KW) {
       kw = 0;
-      if (++kh == p.KH) {
-        kh = 0;
-        if constexpr (SPLIT) {
-          if (++pass == 3) { pass = 0; c0 += 64; }
-        } else {
-          c0 += 64;
-        }
-      }
+      if (++kh == p.KH) { kh = 0; c0 += KST; }
     }
     return off;
   };
@@ -260,12 +252,34 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
           stage((gs + 1) & 1, t + 1, SMALLC ? 0 : next_off());
         } else if (PERSIST && q + G < ntiles) {     // last K step of this tile: start on the next tile
           setup_tile(q + G);
-          kh = 0; kw = 0; c0 = 0; pass = 0;
+          kh = 0; kw = 0; c0 = 0;
           stage((gs + 1) & 1, 0, SMALLC ? 0 : next_off());
         }
       }
       const char* sb = smem + (nst == 2 ? (gs & 1) : 0) * T::STAGE;
-      if constexpr (NJ == 8) {
+      if constexpr (SPLIT && !SMALLC) {
+        // chunks 0-3 of a row = the hi halfs, 4-7 = the lo halfs of the step's 32 channels: c0_off reads this lane's hi fragment, c1_off its lo one
+        half8 wh[MI], wl[MI], xh[NJ], xl[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { wh[i] = *(const half8*)(sb + w_off[i] + c0_off); wl[i] = *(const half8*)(sb + w_off[i] + c1_off); }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { xh[j] = *(const half8*)(sb + x_off[j] + c0_off); xl[j] = *(const half8*)(sb + x_off[j] + c1_off); }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+      } else if constexpr (NJ == 8) {
         // 8 waves in lockstep behind one barrier: all of them read fragments at the same time, so the second
         // half-step's fragments are requested before the first half-step's MFMAs instead of after them.
         half8 wf0[MI], xf0[NJ], wf1[MI], xf1[NJ];
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(WPX* WCH * 64) void conv_igemm_kernel(const ConvPar
     if (q >= ntiles) break;
     if (nst == 1) {                    // single buffer: no cross-tile prefetch; restart on the next tile
       setup_tile(q);
-      kh = 0; kw = 0; c0 = 0; pass = 0;
+      kh = 0; kw = 0; c0 = 0;
       __syncthreads();
       stage(0, 0, SMALLC ? 0 : next_off());
     }
@@ -575,7 +589,8 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
   const RsDebug& D = rs_debug();
   const int nk2 = p.in2 ? (p.Cin2 >> 6) : 0;   // K steps of the second source
   const bool smallc = p.Cin < 64;
-  // split-operand mode: three passes per slice = a layer with three times the K steps (same LDS and matrix work per step)
+  // split-operand mode: K steps of 32 channels x (hi, lo) with three MFMA blocks each = three times the matrix work of an fp16 layer over
+  // twice the steps; the tile rule treats it as a layer of three times the depth
   const int nk = (p.split ? 3 : 1) * (smallc ? (p.Kpad >> 6) : p.KH * p.KW * (p.Cin >> 6) + nk2);
   if (p.stages == 0) {
     // Shallow-K layers (1x1 convs of res2/res3, laterals) are HBM-bound and gain nothing from a second LDS buffer; a
