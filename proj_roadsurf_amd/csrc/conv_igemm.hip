@@ -629,6 +629,10 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
     }
     if (best != 8) return 10 + best;                                      // 15 / 16 / 17
   }
+  // Split-operand mode, deep K on few pixels (res5 at batch 16: 80-320 tiles of 256 x 256): three MFMA blocks per staged byte make conv_deep's big tile
+  // the fastest from a quarter of the chip up, where the fp16 layers are bound by the weight traffic of every tile shape (tools/ubench/split_shapes.py,
+  // profiles/r04/split_shapes_b16.txt: res5.x.conv2 156 us against 195 on the 64 x 128 tile, res5.x.conv1 77 against 91)
+  if (p.split && rows % 256 == 0 && nkd >= 8 && tiles4 >= 64 && tiles4 < 240 && D.conv_deep && use_glds > 0 && !p.in2 && p.out_stride <= 1) return 12;
   // conv3 + projection shortcut over two K sources (conv_igemm only).  tools/ubench/dual_shapes.py, batch 16: res3.0 (1250 tiles of
   // 256x256) 106 us on 256x256 vs 129 on 128x128; res4.0 (628) 88 vs 88; res5.0 (320) 91.5 vs 79
   if (p.in2 && rows % 256 == 0 && nkd >= 6) return tiles4 >= 600 ? 4 : (tiles0 < 1250 ? 7 : 0);

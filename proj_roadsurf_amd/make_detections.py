@@ -112,9 +112,10 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--decode-procs", type=int, default=None,
                     help="worker PROCESSES that decode tiles into shared memory (decode_pool.DecodePool); 0 = decode on the --host-workers threads (default: as --host-workers)")
     ap.add_argument("--vector-threads", type=int, default=None, help="threads inside one rs_vectorize_masks call (default: as --host-workers)")
-    ap.add_argument("--precision", choices=("fp16", "fp32"), default="fp16",
-                    help="fp16: fp16 operands / fp32 accumulate on the matrix cores (production mode, SURVEY 8d tolerance); fp32: the reference's own "
-                         "arithmetic -- fp32 activations and weights on the fp32 matrix cores, about 7x slower (DESIGN.md section 3.1c)")
+    ap.add_argument("--precision", choices=("fp16", "split", "fp32"), default="fp16",
+                    help="fp16: fp16 operands / fp32 accumulate on the matrix cores (fastest; meets the SURVEY 8d tolerance on a trained detector); "
+                         "split: the reference's fp32 results on the fp16 matrix cores -- every operand as hi + lo fp16 planes, three products, about 2.7x "
+                         "slower than fp16 (DESIGN.md section 3.1d); fp32: fp32 activations and weights on the fp32 matrix cores, about 7x slower (section 3.1c)")
     ap.add_argument("--geojson", action="store_true", help="also write <dataset>_detections_..._threshold.geojson (slow: Python feature dicts)")
     ap.add_argument("--tagged-samples", type=int, default=10,
                     help="tagged preview PNGs per dataset in sample_tagged_img_subfolder (0 = none)")
@@ -161,7 +162,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
 
     if args.precision != spec.precision:
         spec = spec.replace(precision=args.precision)
-        log.info("inference in %s", "reference precision (fp32 on the matrix cores)" if args.precision == "fp32" else "fp16 operands / fp32 accumulate")
+        log.info("inference in %s", {"fp32": "reference precision (fp32 on the matrix cores)", "split": "reference-equivalent precision (hi + lo fp16 operand planes, three products)",
+                                     "fp16": "fp16 operands / fp32 accumulate"}[args.precision])
     from .engine import Predictor      # fails loudly without librs_engine.so / a HIP device
     predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank)
 

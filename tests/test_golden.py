@@ -64,16 +64,17 @@ def test_engine_reproduces_golden(gpu_required):
     finally:
         eng.close()
     # reference-precision mode: the fixture's detections to the stated tolerance (>= 98 % both ways)
-    spec32 = EngineSpec(**dict(SPEC_KW, precision="fp32"))
-    eng = Engine(spec32, synthetic_weights(spec32, 0), (128, 128, 3), max_batch=2)
-    try:
-        dets = eng.infer(g["tiles"])
-        for i in range(2):
-            ref = {"boxes": g[f"boxes{i}"], "scores": g[f"scores{i}"], "classes": g[f"classes{i}"], "masks": _unpack(g[f"masks{i}"], 128)}
-            got = {"boxes": dets[i].pred_boxes, "scores": dets[i].scores, "classes": dets[i].pred_classes, "masks": dets[i].pred_masks}
-            fw, bw = match_detections(ref, got), match_detections(got, ref)
-            print("golden fp32", i, fw, bw)
-            assert fw["frac_matched"] >= 0.98 and bw["frac_matched"] >= 0.98, (fw, bw)
-            assert fw["max_dscore"] <= 1e-4 and fw["agg_mask_iou"] >= 0.995, fw
-    finally:
-        eng.close()
+    for precision in ("fp32", "split"):      # fp32 matrix cores; hi + lo fp16 operand planes on the fp16 matrix cores
+        spec32 = EngineSpec(**dict(SPEC_KW, precision=precision))
+        eng = Engine(spec32, synthetic_weights(spec32, 0), (128, 128, 3), max_batch=2)
+        try:
+            dets = eng.infer(g["tiles"])
+            for i in range(2):
+                ref = {"boxes": g[f"boxes{i}"], "scores": g[f"scores{i}"], "classes": g[f"classes{i}"], "masks": _unpack(g[f"masks{i}"], 128)}
+                got = {"boxes": dets[i].pred_boxes, "scores": dets[i].scores, "classes": dets[i].pred_classes, "masks": dets[i].pred_masks}
+                fw, bw = match_detections(ref, got), match_detections(got, ref)
+                print("golden", precision, i, fw, bw)
+                assert fw["frac_matched"] >= 0.98 and bw["frac_matched"] >= 0.98, (fw, bw)
+                assert fw["max_dscore"] <= 1e-4 and fw["agg_mask_iou"] >= 0.995, fw
+        finally:
+            eng.close()

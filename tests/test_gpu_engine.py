@@ -412,10 +412,23 @@ def _strict_compare(ref, det, tag):
     assert fw["max_dbox"] <= 1e-2, fw          # matched pairs (two detections with scores 1e-6 apart may swap rank)
 
 
-def test_fp32_mode_end_to_end_small(gpu_required):
+# Both reference-precision modes are held to the same bounds: "fp32" = fp32 operands on the fp32 matrix cores (csrc/ref_f32.hip), "split" = hi + lo
+# fp16 operand planes, three products on the fp16 matrix cores (csrc/common.h ConvParams::split; operator tests in tests/test_gpu_split.py).
+REF_MODES = ["fp32", "split"]
+
+
+def _net_input_equal(x, want, precision):
+    """fp32 mode: bit-exact.  split mode: the fp32 value to the 22 significand bits its two planes hold."""
+    if precision == "split":
+        return bool(np.abs(x - want).max() <= 2.0 ** -22 * np.abs(want).max())
+    return np.array_equal(x, want)
+
+
+@pytest.mark.parametrize("precision", REF_MODES)
+def test_fp32_mode_end_to_end_small(gpu_required, precision):
     O = _oracle()
     spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300,
-                      precision="fp32")
+                      precision=precision)
     W = synthetic_weights(spec, seed=0)
     tiles = synthetic_tiles(3, 256, 256, 3, seed=77)
     eng = Engine(spec, W, (256, 256, 3), max_batch=3)
@@ -435,9 +448,10 @@ def test_fp32_mode_end_to_end_small(gpu_required):
         eng.close()
 
 
-def test_fp32_mode_full_size_tile(gpu_required):
+@pytest.mark.parametrize("precision", REF_MODES)
+def test_fp32_mode_full_size_tile(gpu_required, precision):
     O = _oracle()
-    spec = EngineSpec(num_classes=2, precision="fp32")
+    spec = EngineSpec(num_classes=2, precision=precision)
     W = synthetic_weights(spec, seed=0)
     tiles = synthetic_tiles(1, 512, 512, 3, seed=1234)
     eng = Engine(spec, W, (512, 512, 3), max_batch=1)
@@ -465,35 +479,38 @@ def _run_strict(spec, tiles, tag):
         for i in range(tiles.shape[0]):
             want = ref[i]["inter"]["net_input"].permute(1, 2, 0).numpy()
             c = want.shape[2]
-            assert np.array_equal(x[i, :, :, :c], want), f"{tag}: pre-processing differs"
+            assert _net_input_equal(x[i, :, :, :c], want, spec.precision), f"{tag}: pre-processing differs"
             _strict_compare(ref[i], dets[i], f"{tag}[{i}]")
         return eng.net_shape()
     finally:
         eng.close()
 
 
-def test_fp32_mode_4band_downscaled_tiles(gpu_required):
+@pytest.mark.parametrize("precision", REF_MODES)
+def test_fp32_mode_4band_downscaled_tiles(gpu_required, precision):
     """RGB+NIR tiles, 400x400 -> 320x320: Pillow's antialiased down-scaling path, 4 input channels,
     channel reversal of all 4 bands (what `im[:, :, ::-1]` does in DefaultPredictor)."""
     spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300,
-                      pixel_mean=(103.53, 116.28, 123.675, 110.0), pixel_std=(1.0, 1.0, 1.0, 1.0), precision="fp32")
+                      pixel_mean=(103.53, 116.28, 123.675, 110.0), pixel_std=(1.0, 1.0, 1.0, 1.0), precision=precision)
     tiles = synthetic_tiles(2, 400, 400, 4, seed=31)
     assert _run_strict(spec, tiles, "4band") == (320, 320, 320, 320)
 
 
-def test_fp32_mode_non_square_tile_with_padding(gpu_required):
+@pytest.mark.parametrize("precision", REF_MODES)
+def test_fp32_mode_non_square_tile_with_padding(gpu_required, precision):
     """200x300 tile -> ResizeShortestEdge gives 224x336, padded to 224x352 (size_divisibility 32): the padded
     columns are zeros at the network input but real pixels from the stem on."""
     spec = EngineSpec(num_classes=2, min_size_test=224, max_size_test=400, rpn_pre_nms_topk_test=200, rpn_post_nms_topk_test=200,
-                      precision="fp32")
+                      precision=precision)
     tiles = synthetic_tiles(2, 200, 300, 3, seed=41)
     assert _run_strict(spec, tiles, "nonsquare") == (224, 336, 224, 352)
 
 
-def test_fp32_mode_single_class(gpu_required):
+@pytest.mark.parametrize("precision", REF_MODES)
+def test_fp32_mode_single_class(gpu_required, precision):
     """ROI_HEADS.NUM_CLASSES = 1 as written in the reference YAML (R:config/detectron2_config_3bands.yaml:191)."""
     spec = EngineSpec(num_classes=1, min_size_test=256, max_size_test=426, rpn_pre_nms_topk_test=200, rpn_post_nms_topk_test=200,
-                      precision="fp32")
+                      precision=precision)
     tiles = synthetic_tiles(2, 192, 192, 3, seed=51)
     _run_strict(spec, tiles, "k1")
 
@@ -745,18 +762,18 @@ def test_config1_batch16_of_512_tiles(gpu_required):
             assert _same_instances(alone, batch[i]), f"fp16: tile {i} differs between batch 16 and batch 1"
     finally:
         eng.close()
-    spec32 = spec.replace(precision="fp32")
-    eng = Engine(spec32, W, (512, 512, 3), max_batch=16)
-    try:
-        batch = eng.infer(tiles)
-        for i in (0, 15):
-            alone = eng.infer(tiles[i:i + 1])[0]
-            assert _same_instances(alone, batch[i]), f"fp32: tile {i} differs between batch 16 and batch 1"
-        ref = O.OracleModel(spec32, W)([tiles[0], tiles[15]])
-        _strict_compare(ref[0], batch[0], "config1_b16[0]")
-        _strict_compare(ref[1], batch[15], "config1_b16[15]")
-    finally:
-        eng.close()
+    ref = O.OracleModel(spec, W)([tiles[0], tiles[15]])
+    for precision in REF_MODES:
+        eng = Engine(spec.replace(precision=precision), W, (512, 512, 3), max_batch=16)
+        try:
+            batch = eng.infer(tiles)
+            for i in (0, 15):
+                alone = eng.infer(tiles[i:i + 1])[0]
+                assert _same_instances(alone, batch[i]), f"{precision}: tile {i} differs between batch 16 and batch 1"
+            _strict_compare(ref[0], batch[0], f"config1_b16[0] {precision}")
+            _strict_compare(ref[1], batch[15], f"config1_b16[15] {precision}")
+        finally:
+            eng.close()
 
 
 def test_config3_4band_1024_tiles_batch8(gpu_required):
@@ -769,14 +786,15 @@ def test_config3_4band_1024_tiles_batch8(gpu_required):
     W = synthetic_weights(spec, seed=0)
     tiles = synthetic_tiles(8, 1024, 1024, 4, seed=4321)
     ref = O.OracleModel(spec, W)([tiles[0]], keep=True)[0]
-    eng = Engine(spec.replace(precision="fp32"), W, (1024, 1024, 4), max_batch=1)
-    try:
-        d32 = eng.infer(tiles[:1])[0]
-        x = eng.tensor("net_input", n=1)
-        assert np.array_equal(x[0], ref["inter"]["net_input"].permute(1, 2, 0).numpy()), "4-band antialiased resize differs"
-        _strict_compare(ref, d32, "config3_fp32")
-    finally:
-        eng.close()
+    for precision in REF_MODES:
+        eng = Engine(spec.replace(precision=precision), W, (1024, 1024, 4), max_batch=1)
+        try:
+            d32 = eng.infer(tiles[:1])[0]
+            x = eng.tensor("net_input", n=1)
+            assert _net_input_equal(x[0], ref["inter"]["net_input"].permute(1, 2, 0).numpy(), precision), "4-band antialiased resize differs"
+            _strict_compare(ref, d32, f"config3_{precision}")
+        finally:
+            eng.close()
     eng = Engine(spec, W, (1024, 1024, 4), max_batch=8)
     try:
         assert eng.net_shape() == (800, 800, 800, 800)
