@@ -135,6 +135,9 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=os.environ.get("RS_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+        import torch
+        local_rank = local_rank % max(1, torch.cuda.device_count())      # several ranks may share a card (tests on a one-GPU box); counting devices does not initialise the GPU
+        logging.getLogger("make_detections").info("rank %d of %d ranks on device %d", rank, world, local_rank)
 
     os.chdir(cfg["working_directory"])
     os.makedirs(cfg.get("log_subfolder", "logs"), exist_ok=True)
@@ -255,29 +258,53 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             source = pool_source if pool is not None else None
         try:
             try:
-                per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
+                per_tile = run_sharded(images, predict_batch, args.batch, rank, world, gather=False, prepare=prepare, finish=finish,
                                        workers=args.host_workers, predict_stream=predict_stream, prepared_source=source)
             except TileShapeError as ex:
                 # the COCO sizes (or the band count of the first tile) did not hold for every file: this dataset again on the thread path
                 log.warning("%s: %s -- running the dataset again with thread decoding", dataset, ex)
                 predictor.close()
                 predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank)
-                per_tile = run_sharded(images, predict_batch, args.batch, rank, world, prepare=prepare, finish=finish,
+                per_tile = run_sharded(images, predict_batch, args.batch, rank, world, gather=False, prepare=prepare, finish=finish,
                                        workers=args.host_workers, predict_stream=predict_stream, prepared_source=None)
         except BaseException:
             _close_pools(pools)
             raise
-        if rank != 0:
-            continue
+        # Every rank writes the rows of ITS block of tiles into its own GeoPackage shard (rank 0: the output file itself); rank 0 then appends the
+        # other ranks' shards in rank order = tile order with SQLite ATTACH -- no row travels between processes ("each rank ...
+        # its own output shard; host merges shards into one GeoPackage per dataset").  The ranks of one node share the working directory.
         base = f"{dataset}_detections_at_{thr_tag(thr)}_threshold"
         t_w = time.time()
-        gw = GpkgWriter(base + ".gpkg", table=base, epsg=epsg)
+        shard_path = base + ".gpkg" if rank == 0 else f"{base}.rank{rank}.gpkg"
+        if rank != 0 and os.path.exists(shard_path):
+            os.remove(shard_path)
+        gw = GpkgWriter(shard_path, table=base, epsg=epsg)
         for rows, bbox, _ in per_tile:
             gw.add_rows(rows, bbox)
+        if args.geojson and world > 1:
+            with open(f"{base}.rank{rank}.features.json", "w") as f:
+                f.write(json.dumps([ft for _, _, fs in per_tile for ft in fs]))
+        if rank != 0:
+            gw.close()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()                                   # every shard is complete on disk
+        if rank != 0:
+            continue
+        for r in range(1, world):
+            sp = f"{base}.rank{r}.gpkg"
+            gw.append_shard(sp)
+            os.remove(sp)
         n = gw.close()
         dt_write = time.time() - t_w
         if args.geojson:
             feats = [f for _, _, fs in per_tile for f in fs]
+            for r in range(world if world > 1 else 0):
+                fp = f"{base}.rank{r}.features.json"
+                if r > 0:
+                    with open(fp) as f:
+                        feats += json.load(f)
+                os.remove(fp)
             with open(base + ".geojson", "w") as f:
                 f.write(json.dumps({"type": "FeatureCollection", "features": feats}))   # dumps() = C encoder; dump() streams through the slow Python one
         dt = time.time() - t0

@@ -2,6 +2,7 @@
 ``make_detections`` CLI end to end on a small synthetic tileset (GPU)."""
 import json
 import os
+import sys
 import sqlite3
 
 import numpy as np
@@ -229,6 +230,112 @@ def test_features_georeference_and_gpkg_roundtrip(tmp_path):
     assert con.execute("SELECT geometry_type_name, srs_id FROM gpkg_geometry_columns").fetchone() == ("POLYGON", 3857)
     assert con.execute("SELECT data_type FROM gpkg_contents").fetchone()[0] == "features"
     con.close()
+
+
+def test_gpkg_shards_appended_with_attach_equal_one_writer(tmp_path):
+    """Per-rank GeoPackage shards merged on the host: rows of three shards appended in rank order with SQLite ATTACH == the same rows
+    written by one writer, row for row (fid order), bounding box and feature count included; an empty shard in the middle changes nothing."""
+    from proj_roadsurf_amd.gpkg import GpkgWriter, gpkg_geom
+    rng = np.random.default_rng(3)
+    tab = "val_detections_at_0dot05_threshold"
+
+    def rows_of(k, n):
+        out, bx = [], [np.inf, np.inf, -np.inf, -np.inf]
+        for i in range(n):
+            x, y = float(rng.uniform(0, 5000)), float(rng.uniform(0, 5000))
+            ring = [[x, y], [x + 3.0, y], [x + 3.0, y + 2.0], [x, y + 2.0], [x, y]]
+            out.append((gpkg_geom([ring], 3857), float(rng.uniform(0.05, 1.0)), int(rng.integers(0, 2)), f"18_{k}_{i}.tif"))
+            bx = [min(bx[0], x), min(bx[1], y), max(bx[2], x + 3.0), max(bx[3], y + 2.0)]
+        return out, (bx if n else None)
+
+    shards = [rows_of(k, n) for k, n in enumerate((7, 0, 12, 5))]
+    one = GpkgWriter(str(tmp_path / "one.gpkg"), table=tab, epsg=3857)
+    for rows, bx in shards:
+        one.add_rows(rows, bx)
+    assert one.close() == 24
+    paths = []
+    for k, (rows, bx) in enumerate(shards):
+        pth = str(tmp_path / ("merged.gpkg" if k == 0 else f"merged.rank{k}.gpkg"))
+        w = GpkgWriter(pth, table=tab, epsg=3857)
+        w.add_rows(rows, bx)
+        paths.append((pth, w))
+    for pth, w in paths[1:]:
+        w.close()
+    head = paths[0][1]
+    assert [head.append_shard(pth) for pth, _ in paths[1:]] == [0, 12, 5]
+    assert head.close() == 24
+    q = f'SELECT fid, geom, score, det_class, image FROM "{tab}" ORDER BY fid'
+    a, b = sqlite3.connect(str(tmp_path / "one.gpkg")), sqlite3.connect(str(tmp_path / "merged.gpkg"))
+    try:
+        assert a.execute(q).fetchall() == b.execute(q).fetchall()
+        cq = "SELECT table_name, data_type, min_x, min_y, max_x, max_y, srs_id FROM gpkg_contents"
+        assert a.execute(cq).fetchall() == b.execute(cq).fetchall()
+    finally:
+        a.close(); b.close()
+    with pytest.raises(ValueError):                      # a shard of another SRS is refused, not silently mixed in
+        w2 = GpkgWriter(str(tmp_path / "other.gpkg"), table=tab, epsg=2056)
+        w2.close()
+        w3 = GpkgWriter(str(tmp_path / "m2.gpkg"), table=tab, epsg=3857)
+        w3.append_shard(str(tmp_path / "other.gpkg"))
+
+
+def _cli_dataset(tmp_path, n_tiles, tile=128):
+    """Working directory of the reference CLI (R:config/config_obj_detec.yaml:74-90) with n synthetic TIFF tiles; returns (config path, wd)."""
+    from PIL import Image
+    import yaml
+    from tests.util import synthetic_tiles
+    wd = tmp_path / "outputs" / "obj_detector"
+    (wd / "val-images").mkdir(parents=True)
+    tiles = synthetic_tiles(n_tiles, tile, tile, 3, seed=9)
+    images, meta = [], {}
+    for i in range(n_tiles):
+        fn = f"val-images/18_{100 + i}_200.tif"
+        Image.fromarray(tiles[i][:, :, ::-1]).save(str(wd / fn))           # tiles are BGR; files hold RGB
+        images.append({"id": i, "file_name": fn, "width": tile, "height": tile})
+        meta[fn] = {"extent": [1000.0 * i, 0.0, 1000.0 * i + 52.0, 52.0], "crs": "EPSG:3857"}
+    cats = [{"id": 1, "name": "artificial"}, {"id": 2, "name": "natural"}]
+    json.dump({"images": images, "annotations": [], "categories": cats}, open(wd / "COCO_val.json", "w"))
+    json.dump(meta, open(wd / "img_metadata.json", "w"))
+    d2 = {"INPUT": {"FORMAT": "RGB", "MIN_SIZE_TEST": 192, "MAX_SIZE_TEST": 320},
+          "MODEL": {"RPN": {"PRE_NMS_TOPK_TEST": 200, "POST_NMS_TOPK_TEST": 200}, "ROI_HEADS": {"NUM_CLASSES": 1}},
+          "TEST": {"DETECTIONS_PER_IMAGE": 20}}
+    yaml.safe_dump(d2, open(tmp_path / "d2.yaml", "w"))
+    cfg = {"make_detections.py": {"working_directory": str(wd), "log_subfolder": "logs", "image_metadata_json": "img_metadata.json", "COCO_files": {"val": "COCO_val.json"},
+                                  "detectron2_config_file": str(tmp_path / "d2.yaml"), "model_weights": {"pth_file": "logs/model_0005999.pth"},
+                                  "rdp_simplification": {"enabled": True, "epsilon": 0.75}, "score_lower_threshold": 0.05}}
+    yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
+    return str(tmp_path / "config.yaml"), wd
+
+
+@pytest.mark.gpu
+def test_make_detections_two_ranks_write_the_one_rank_geopackage(gpu_required, tmp_path):
+    """BASELINE configs[2] in small: the CLI itself under `torch.distributed.run --nproc-per-node 2` (both ranks on the one GPU of the box, gloo rendezvous) on
+    41 TIFF tiles -- rank 0 takes 21, rank 1 takes 20, a ragged last batch on each.  Each rank writes its own GeoPackage shard and rank 0 appends the other's
+    with SQLite ATTACH: the merged file equals the one-rank run row for row (geometry blob, score, class, image, order), and so does the GeoJSON."""
+    import subprocess
+    cfg, wd = _cli_dataset(tmp_path, 41)
+    name = "val_detections_at_0dot05_threshold"
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), RS_DIST_BACKEND="gloo")
+    common = ["-m", "proj_roadsurf_amd.make_detections", cfg, "--synthetic-weights", "--batch", "4", "--geojson", "--tagged-samples", "0"]
+    r1 = subprocess.run([sys.executable] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    os.rename(wd / f"{name}.gpkg", wd / "one_rank.gpkg")
+    os.rename(wd / f"{name}.geojson", wd / "one_rank.geojson")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631"] + common,
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert not [f for f in os.listdir(wd) if ".rank" in f], "shard files left behind"
+    q = f'SELECT fid, geom, score, det_class, image FROM "{name}" ORDER BY fid'
+    a, b = sqlite3.connect(str(wd / "one_rank.gpkg")), sqlite3.connect(str(wd / f"{name}.gpkg"))
+    try:
+        ra, rb = a.execute(q).fetchall(), b.execute(q).fetchall()
+        assert len(ra) > 41 and ra == rb, f"{len(ra)} rows against {len(rb)}"
+        cq = "SELECT min_x, min_y, max_x, max_y, srs_id FROM gpkg_contents"
+        assert a.execute(cq).fetchall() == b.execute(cq).fetchall()
+    finally:
+        a.close(); b.close()
+    assert json.load(open(wd / "one_rank.geojson")) == json.load(open(wd / f"{name}.geojson"))
+    assert "rank 1 of 2 ranks on device 0" in r2.stderr
 
 
 @pytest.mark.gpu
