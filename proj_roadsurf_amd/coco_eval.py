@@ -11,7 +11,10 @@ PythonAPI/pycocotools/cocoeval.py]).  pycocotools is not available offline, so t
     thresholds, IoU thresholds 0.50:0.05:0.95, categories; area ranges all / small / medium / large (32^2, 96^2).
 
 PARITY UNPINNED against pycocotools (absent); tests/test_coco_eval.py pins closed-form cases (perfect detections AP = 1, a
-known precision/recall staircase, score ordering, area ranges, crowd handling).  Masks are numpy bool arrays here (the engine's
+known precision/recall staircase, score ordering, area ranges, crowd handling) and checks this module on 220 random detection /
+ground-truth sets (crowd regions, empty images, tied scores, max_dets caps, annotated areas; bbox and segm) against an independent
+brute-force statement of the definitions (oracle/coco_ap_oracle.py: declarative matching, interpolated precision by its definition;
+test infrastructure, never imported here) to 1e-9.  Masks are numpy bool arrays here (the engine's
 ``Instances.pred_masks`` / rasterised ground-truth polygons), boxes XYXY."""
 from __future__ import annotations
 

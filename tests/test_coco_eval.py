@@ -133,3 +133,71 @@ def test_cocoeval_rules_crowd_area_range_maxdets_ties():
     fp_first = [_img([[50, 50, 60, 60], [0, 0, 10, 10]], [0, 0], scores=[0.5, 0.5])]
     tp_first = [_img([[0, 0, 10, 10], [50, 50, 60, 60]], [0, 0], scores=[0.5, 0.5])]
     assert evaluate(g, fp_first, 1, "bbox")["AP50"] == pytest.approx(50.0) and evaluate(g, tp_first, 1, "bbox")["AP50"] == pytest.approx(100.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Independent checker (oracle/coco_ap_oracle.py): a brute-force statement of the published definitions -- declarative matching, interpolated
+# precision by its definition, explicit ranked lists -- against the COCOeval-shaped implementation, on random scenes.  Both remain PARITY
+# UNPINNED against pycocotools (absent offline); what this pins is that two differently built statements of the rules agree.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _random_scene(rng, n_img, n_cls, with_masks, side=64):
+    gts, dets = [], []
+    for _ in range(n_img):
+        ng = int(rng.integers(0, 7)) if rng.random() > 0.15 else 0           # some images without ground truth
+        gb, gc, gm = [], [], []
+        for _ in range(ng):
+            s = float(rng.choice([6.0, 14.0, 30.0, 45.0]))                     # areas on both sides of 32^2 (and of 96^2 through "area" below)
+            x, y = float(rng.uniform(0, side - s)), float(rng.uniform(0, side - s))
+            gb.append([x, y, x + s * float(rng.uniform(0.6, 1.0)), y + s * float(rng.uniform(0.6, 1.0))])
+            gc.append(int(rng.integers(0, n_cls)))
+        g = {"boxes": np.asarray(gb, np.float64).reshape(-1, 4), "classes": np.asarray(gc, np.int64), "crowd": rng.random(ng) < 0.15}
+        db, dc, ds = [], [], []
+        for k in range(ng):                                                    # jittered copies (some twice: duplicates), some with the wrong class
+            for _ in range(int(rng.integers(0, 3))):
+                j = rng.normal(0, 1.5, 4)
+                db.append((g["boxes"][k] + j).tolist())
+                dc.append(gc[k] if rng.random() > 0.1 else int(rng.integers(0, n_cls)))
+                ds.append(round(float(rng.uniform(0.05, 1.0)), 1 if rng.random() < 0.5 else 3))      # coarse scores: many ties
+        for _ in range(int(rng.integers(0, 5))):                               # false positives anywhere
+            s = float(rng.uniform(4, 40))
+            x, y = float(rng.uniform(0, side - 4)), float(rng.uniform(0, side - 4))
+            db.append([x, y, x + s, y + s]); dc.append(int(rng.integers(0, n_cls))); ds.append(round(float(rng.uniform(0.05, 1.0)), 2))
+        d = {"boxes": np.asarray(db, np.float64).reshape(-1, 4), "classes": np.asarray(dc, np.int64), "scores": np.asarray(ds, np.float64)}
+        if with_masks:
+            def raster(boxes):
+                m = np.zeros((len(boxes), side, side), bool)
+                for i, b in enumerate(boxes):
+                    x0, y0, x1, y1 = (int(round(v)) for v in np.clip(b, 0, side))
+                    m[i, y0:max(y1, y0 + 1), x0:max(x1, x0 + 1)] = True
+                    if rng.random() < 0.5:                                     # not a rectangle: cut a corner
+                        m[i, y0:(y0 + y1) // 2, x0:(x0 + x1) // 2] = False
+                return m
+            g["masks"], d["masks"] = raster(g["boxes"]), raster(d["boxes"])
+        elif rng.random() < 0.3 and ng:
+            g["area"] = rng.choice([100.0, 2000.0, 20000.0], ng)               # annotated areas (COCO's `area` field) reach the "large" range
+        gts.append(g); dets.append(d)
+    return gts, dets
+
+
+@pytest.mark.parametrize("iou_type,n_sets", [("bbox", 160), ("segm", 60)])
+def test_ap_equals_the_independent_brute_force_checker(iou_type, n_sets):
+    from oracle.coco_ap_oracle import average_precision
+    rng = np.random.default_rng(20260 + (iou_type == "segm"))
+    seen = {"crowd": 0, "empty_img": 0, "capped": 0, "nan": 0}
+    for s in range(n_sets):
+        n_cls = int(rng.integers(1, 4))
+        gts, dets = _random_scene(rng, int(rng.integers(1, 9)), n_cls, iou_type == "segm")
+        max_dets = int(rng.choice([1, 3, 100]))
+        seen["crowd"] += any(g["crowd"].any() for g in gts)
+        seen["empty_img"] += any(len(g["classes"]) == 0 for g in gts)
+        seen["capped"] += any(len(d["classes"]) > max_dets for d in dets)
+        got = evaluate(gts, dets, n_cls, iou_type, max_dets)
+        want = average_precision(gts, dets, n_cls, iou_type, max_dets)
+        assert set(got) == set(want)
+        for k in want:
+            if np.isnan(want[k]):
+                seen["nan"] += 1
+                assert np.isnan(got[k]), (s, k, got[k])
+            else:
+                assert got[k] == pytest.approx(want[k], abs=1e-9), (s, k, got[k], want[k])
+    assert min(seen.values()) > 0, seen          # the random sets did exercise crowd regions, empty images, the max_dets cap and undefined ranges
