@@ -597,6 +597,8 @@ int conv_choose_variant(ConvParams& p, int force_variant, int use_glds) {
     // single buffer halves the LDS footprint so 4 workgroups fit per CU and their loads/epilogues overlap each other.
     // (RS_CONV_PERSIST >= 1: persistent + double buffered instead -- correct, measured not faster: 0.221 vs 0.225 ms on
     // res2 conv3, slower on conv1; these layers sit at ~3.3 TB/s either way.)
+    // (split-operand mode, nk = three times the fp16 layer's: res2.x.conv3 has two K steps of 32 channels x (hi, lo) and would take one buffer by its
+    // step count; measured slower on one buffer than on two, 339 against 329 us, res3.x.conv3 213 against 203: the rule stays on the tripled count)
     const bool shallow = nk <= D.conv_single_stage_nk;
     if (D.conv_persist >= 1 && shallow && p.mode != 2 && !p.split) { p.stages = 2; p.persist = 2; }
     else { p.stages = shallow ? 1 : 2; p.persist = D.conv_persist >= 2 && p.mode != 2 ? -1 : 0; }
