@@ -370,6 +370,10 @@ int rs_trainer_set_targets(rs_trainer* t, const float* gt_boxes, const int32_t* 
  * the shared head accumulated over the levels, d:p2..d:p6 overwritten with the head's input gradient.  external_labels = 1 keeps
  * the caller's "rpn_labels" / "rpn_matched" (parity tests feed the oracle's sample). */
 int rs_trainer_rpn_step(rs_trainer* t, int n, uint32_t seed, int external_labels);
+/* Optional: the RPN's targets of the coming step (anchor Matcher + label subsampling: functions of the ground truth and the seed only) computed
+ * ahead on the trainer's side stream.  Call after rs_trainer_set_targets, before rs_trainer_forward_trunk; the rs_trainer_rpn_step of the same
+ * seed then only waits for them.  Same kernels and seed as inside the step: identical labels. */
+int rs_trainer_rpn_targets_async(rs_trainer* t, int n, uint32_t seed);
 /* RPN head forward alone (rs_trainer_rpn_step runs it itself), then the RoI box head of the training step:
  * RPN proposals in training mode (PRE_NMS_TOPK_TRAIN 2000 per level, NMS 0.7, POST_NMS_TOPK_TRAIN 1000 per image: R:245-250;
  * rs_trainer_set_rpn_topk overrides) + gt boxes (R:193), Matcher at 0.5, subsample_labels (1024 @ 0.25, R:178,192), box-head forward on the sample,

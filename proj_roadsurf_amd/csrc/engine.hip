@@ -712,7 +712,7 @@ int rs_engine::build() {
   // 256-channel "rpn_conv" maps are never written
   const BlobEntry* headsp = findw("proposal_generator.rpn_head.headsp");
   const BlobEntry* headsp_si = split ? find("proposal_generator.rpn_head.headsp.wsi") : nullptr;
-  const bool fuse_heads = merge && rs_debug().fuse_rpn_heads && head_cs == 16 && headsp != nullptr && (!split || headsp_si != nullptr);
+  const bool fuse_heads = merge && !frozen_fusions_only && rs_debug().fuse_rpn_heads && head_cs == 16 && headsp != nullptr && (!split || headsp_si != nullptr);
   for (int l = 0; l < L; ++l) {
     const std::string ln = std::to_string(l + 2);
     Act t;
@@ -1266,7 +1266,9 @@ int rs_engine_create(const rs_spec* spec, const void* weights, size_t nbytes, in
   e->merge_levels = rs_debug().merge_levels;
   // the training engine differentiates every convolution of res3..res5 / FPN / heads separately and needs every layer output there; the frozen
   // stem and res2 (FREEZE_AT 2, what rs_trainer implements) keep the inference engine's fused stem and fused bottleneck tails
-  if (g_trainer_unfused_shortcut) { e->frozen_fusions_only = true; e->merge_levels = 0; }
+  // (the multi-map launches of the FPN output convolutions and of the RPN 3x3 stay: every map still gets its own output tensor; only the RPN heads
+  //  leave the 3x3's epilogue, because the trainer differentiates through the 256-channel rpn_conv maps)
+  if (g_trainer_unfused_shortcut) e->frozen_fusions_only = true;
   e->use_graph = rs_debug().use_graph;   // measured: replay == eager (11.54 ms/step either way), so off by default
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
   else {

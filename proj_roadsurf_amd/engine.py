@@ -827,6 +827,7 @@ class Trainer:
         lib.rs_trainer_set_image_sizes.argtypes = [vp, vp, vp, i32]
         lib.rs_trainer_rpn_step.argtypes = [vp, i32, C.c_uint32, i32]
         lib.rs_trainer_rpn_forward.argtypes = [vp, i32]
+        lib.rs_trainer_rpn_targets_async.argtypes = [vp, i32, C.c_uint32]
         lib.rs_trainer_roi_step.argtypes = [vp, i32, C.c_uint32]
         lib.rs_trainer_set_sampling.argtypes = [vp, i32, C.c_float, i32, C.c_float]
         lib.rs_trainer_set_rpn_topk.argtypes = [vp, i32, i32]
@@ -998,6 +999,8 @@ class Trainer:
         if sizes is not None:
             self.set_image_sizes(sizes if any(int(s) != self.spec.min_size_test for s in sizes) else None)
         self.set_targets(gt_boxes, gt_classes)
+        # the RPN's targets depend on the ground truth and the seed only: on the side stream, ahead of the forward pass
+        _check(self.lib, self.lib.rs_trainer_rpn_targets_async(self._h, n, seed & 0xFFFFFFFF), "rs_trainer_rpn_targets_async")
         self.forward_trunk(self.upload_tiles(tiles), n)
         self.rpn_forward(n)
         self.roi_step(n, seed)
