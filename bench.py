@@ -618,12 +618,26 @@ def main():
                     traffic = k["hbm_bytes_per_launch_corrected"]
                     traffic_src = f"{os.path.relpath(pmc, ROOT)}: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, (2*FETCH+WRITE)*1024 per launch"
                     break
+        # matrix-pipe busy fraction, clock under load and wave-state split of the same kernel from the SQ / GRBM counter passes of tools/profile_bench.sh
+        counters = None
+        pmf = os.path.join(ROOT, "profiles", "pmc_mfma_latest_split.json" if split else "pmc_mfma_latest.json")
+        if traffic is not None and os.path.exists(pmf):
+            key = "conv_deep_kernel<0, false, 8, true>" if split else "conv_deep_kernel<0, false, 8, false>"
+            for k in json.load(open(pmf)):
+                if key in k["kernel"] and dom.startswith("conv_deep_kernel 256x256"):
+                    counters = {kk: k.get(kk) for kk in ("mfma_busy_frac", "clock_ghz_under_load", "wave_parked_frac", "issue_stall_frac", "issuing_frac", "lds_issue_stall_frac",
+                                                         "avg_duration_us_under_pmc")}
+                    counters["source"] = f"{os.path.relpath(pmf, ROOT)} (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / kernel time)"
+                    counters["measured_in_this_run"] = False
+                    counters["measured"] = json.load(open(pmf + ".meta")) if os.path.exists(pmf + ".meta") else None
+                    break
         roofline = {"bound": "mfma", "kernel": dom + (" (fp16 MFMA 16x16x32, fp32 accumulate)" if args.precision != "fp32" else " (fp32 MFMA 16x16x4)"),
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "peak_is": ("2500 TFLOP/s dense fp16 MFMA / 3: the split-operand mode spends three matrix-core products (hi.hi, hi.lo, lo.hi) per real product; "
                                 "`achieved` counts ALGORITHMIC FLOP (2 per real multiply-add), matrix_core_tflops = 3 x achieved is what the MFMA pipe delivers"
                                 if split else "dense MFMA peak of the operand type (MI355X_MICROARCH.md)"),
                     "matrix_core_tflops": achieved * (3.0 if split else 1.0),
+                    "counters": counters,
                     "traffic": traffic, "traffic_source": traffic_src,
                     # the PMC passes need rocprofv3 and run separately (tools/profile_bench.sh); the file is that run's summary, not this run's
                     "traffic_measured_in_this_run": False if traffic is not None else None,

@@ -1511,7 +1511,7 @@ int rs_engine_stage_kernel(rs_engine* e, int i, char* name_out) {
   const int v = e->stages[i].variant;
   const char* s = v == -1 ? "conv_f32_mfma_kernel" : (v >= 0 && v <= 22 ? names[v] : "");
   if (e->split && v >= 0 && v <= 22) {
-    snprintf(name_out, 96, "%.70s [split hi+lo, 3 passes]", s);
+    snprintf(name_out, 96, "%.62s [split: hi+lo planes, 3 MFMA blocks]", s);
     return RS_OK;
   }
   strncpy(name_out, s, 95);
