@@ -515,12 +515,14 @@ def test_fp32_mode_single_class(gpu_required, precision):
     _run_strict(spec, tiles, "k1")
 
 
-def test_no_detections_and_mixed_batches(gpu_required):
+@pytest.mark.parametrize("precision", ["fp16", "split"])
+def test_no_detections_and_mixed_batches(gpu_required, precision):
     """Edge cases of the detection bookkeeping: a score threshold nothing passes (zero detections on every tile: the mask head's
     GEMMs run over a device-side count of 0), then a batch in which only SOME tiles have detections (compacted mask-head list with
-    empty images in the middle), each compared with the same tile run alone."""
+    empty images in the middle), each compared with the same tile run alone.  In the fp16 and in the split-operand mode (other kernels
+    behind the mask head's device-side row count)."""
     spec_hi = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300,
-                         score_thresh_test=0.9999)
+                         score_thresh_test=0.9999, precision=precision)
     W = synthetic_weights(spec_hi, seed=0)
     tiles = synthetic_tiles(3, 256, 256, 3, seed=77)
     eng = Engine(spec_hi, W, (256, 256, 3), max_batch=4)
@@ -534,7 +536,7 @@ def test_no_detections_and_mixed_batches(gpu_required):
     finally:
         eng.close()
     # a threshold between the tiles' best scores: some images keep detections, others none
-    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300)
+    spec = EngineSpec(num_classes=2, min_size_test=320, max_size_test=533, rpn_pre_nms_topk_test=300, rpn_post_nms_topk_test=300, precision=precision)
     eng = Engine(spec, W, (256, 256, 3), max_batch=4)
     try:
         best = sorted(float(o.scores.max()) for o in eng.infer(tiles))

@@ -376,6 +376,16 @@ def test_make_detections_cli_end_to_end(gpu_required, tmp_path):
         os.chdir(cwd)
         ref_feats = read_gpkg(str(wd / "val_detections_at_0dot05_threshold.gpkg"), "val_detections_at_0dot05_threshold")
         assert len(ref_feats) > 0
+        # ... the same job with split operands (the reference's fp32 results on the fp16 matrix cores): the detections of the fp32 run, feature for feature
+        assert make_detections.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--batch", "2", "--precision", "split"]) == 0
+        os.chdir(cwd)
+        split_feats = read_gpkg(str(wd / "val_detections_at_0dot05_threshold.gpkg"), "val_detections_at_0dot05_threshold")
+        assert len(split_feats) == len(ref_feats)
+        for a, b in zip(split_feats, ref_feats):
+            assert a["properties"]["image"] == b["properties"]["image"] and a["properties"]["det_class"] == b["properties"]["det_class"]
+            assert abs(a["properties"]["score"] - b["properties"]["score"]) <= 1e-4
+        same = sum(a["geometry"]["coordinates"] == b["geometry"]["coordinates"] for a, b in zip(split_feats, ref_feats))
+        assert same >= 0.98 * len(ref_feats), f"{same} of {len(ref_feats)} polygons identical"
         # ... then the production mode, which overwrites the outputs
         assert make_detections.main([str(tmp_path / "config.yaml"), "--synthetic-weights", "--batch", "2", "--geojson"]) == 0
     finally:

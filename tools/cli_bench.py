@@ -27,6 +27,7 @@ def main():
                     help="random: synthetic_weights (speckle masks, ~1900 polygons per tile); trained: synthetic.train_trained_like on "
                          "synthetic scenes (a handful of clean objects per tile, like a trained detector on real tiles)")
     ap.add_argument("--train-steps", type=int, default=300)
+    ap.add_argument("--precision", choices=["fp16", "split", "fp32"], default="fp16", help="make_detections --precision")
     args = ap.parse_args()
     import yaml
     from PIL import Image
@@ -68,11 +69,11 @@ def main():
         t0 = time.time()
         rc = make_detections.main([os.path.join(td, "config.yaml"), *extra, "--batch", str(args.batch),
                                    "--host-workers", str(args.host_workers), "--vector-threads", str(args.vector_threads),
-                                   "--decode-procs", str(args.decode_procs)])
+                                   "--decode-procs", str(args.decode_procs), "--precision", args.precision])
         dt = time.time() - t0
         os.chdir(cwd)
         size = os.path.getsize(os.path.join(wd, "oth_detections_at_0dot05_threshold.gpkg"))
-    print(json.dumps({"cli_tiles": args.tiles, "weights": args.weights, "seconds_total_incl_engine_build": dt, "rc": rc, "gpkg_bytes": size}))
+    print(json.dumps({"cli_tiles": args.tiles, "weights": args.weights, "precision": args.precision, "seconds_total_incl_engine_build": dt, "rc": rc, "gpkg_bytes": size}))
 
 
 if __name__ == "__main__":
