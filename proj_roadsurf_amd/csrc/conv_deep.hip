@@ -54,6 +54,10 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
   const int lrow = lane >> 3, lchk = lane & 7;
   const half_t* aptr[APS];
   const half_t* wptr[4];
+  // SPLIT: the same per-lane source positions as 32-bit BYTE offsets from the (wave-uniform) tensor bases, so that an LDS-DMA piece is addressed as
+  // SGPR base + VGPR offset: half the address registers and one 32-bit add per piece instead of a 64-bit one -- the registers the split loop's
+  // placement of the pieces between its MFMA blocks needs (launch_conv_deep checks that both planes of a tensor lie within 4 GB of its base)
+  unsigned aoffb[APS], woffb[4];
 #pragma unroll
   for (int ps = 0; ps < APS; ++ps) {
     int m = m0 + ps * 64 + wave * 8 + lrow;
@@ -64,14 +68,14 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
     const int n = t / Ho;
     const long long base =
         ((long long)(n * in_Hp + y * p.stride + p.in_off) * in_Wp + x * p.stride + p.in_off) * p.in_Cs;
-    if constexpr (SPLIT) aptr[ps] = g_in + base + ((lchk ^ lrow) & 3) * 8 + ((lchk ^ lrow) >> 2) * in_lo;
+    if constexpr (SPLIT) aoffb[ps] = (unsigned)((base + ((lchk ^ lrow) & 3) * 8 + ((lchk ^ lrow) >> 2) * in_lo) * 2);
     else aptr[ps] = g_in + base + (lchk ^ lrow) * 8;
   }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int row = ps * 64 + wave * 8 + lrow;
     const int key = (row & 3) | (((row >> 4) & 1) << 2);
-    if constexpr (SPLIT) wptr[ps] = g_w + (long long)(n0 + row) * p.Kpad + ((lchk ^ key) & 3) * 8 + ((lchk ^ key) >> 2) * p.w_lo;
+    if constexpr (SPLIT) woffb[ps] = (unsigned)(((long long)(n0 + row) * p.Kpad + ((lchk ^ key) & 3) * 8 + ((lchk ^ key) >> 2) * p.w_lo) * 2);
     else wptr[ps] = g_w + (long long)(n0 + row) * p.Kpad + (lchk ^ key) * 8;
   }
   constexpr int KST = SPLIT ? 32 : 64;      // channels a K step covers
@@ -87,8 +91,13 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
     ++an;
     if (DBG & 1) return;   // ceiling experiment: no global traffic
     if (DBG & 8) return;   // ... no activation traffic only
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int ps = 0; ps < APS; ++ps) glds16(aptr[ps] + off, abase + (ps * 64 + wave * 8) * 128);
+      for (int ps = 0; ps < APS; ++ps) glds16((const half_t*)((const char*)g_in + (aoffb[ps] + (unsigned)(off * 2))), abase + (ps * 64 + wave * 8) * 128);
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < APS; ++ps) glds16(aptr[ps] + off, abase + (ps * 64 + wave * 8) * 128);
+    }
   };
   int wkh = 0, wkw = 0, wc0 = 0, wn = 0;
   auto stage_w = [&]() {
@@ -98,8 +107,13 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
     ++wn;
     if (DBG & 1) return;
     if (DBG & 4) return;   // ... no weight traffic only
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) glds16(wptr[ps] + koff, wbase + (ps * 64 + wave * 8) * 128);
+      for (int ps = 0; ps < 4; ++ps) glds16((const half_t*)((const char*)g_w + (woffb[ps] + (unsigned)(koff * 2))), wbase + (ps * 64 + wave * 8) * 128);
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) glds16(wptr[ps] + koff, wbase + (ps * 64 + wave * 8) * 128);
+    }
   };
 
   const int fi = lane & 15, fq = lane >> 4, fkey = lane & 7;
@@ -159,6 +173,10 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
   // buffer nothing else reads
   const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime(), pr_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef RS_SPLIT_PHASES
+  const unsigned long long ph_entry = __builtin_amdgcn_s_memtime();
+  unsigned long long ph_loop0 = 0, ph_loop1 = 0;
+#endif
   // prologue: w(0), acts(0), acts(1); publish step 0; then w(1), acts(2) and the first fragments
   stage_w();
   stage_a();
@@ -168,7 +186,11 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
   asm volatile("s_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   if (nk > 1) stage_w();
+#ifndef RS_SPLIT_SCHED_V1
+  if constexpr (!SPLIT) { if (nk > 2) stage_a(); }      // the split loop issues acts(t+2) inside step t, acts(2) included
+#else
   if (nk > 2) stage_a();
+#endif
   if constexpr (SPLIT) {
     // Split-operand main loop.  Register sets: wf0 = W_hi, wf1 = W_lo, xf0 = X_hi, xf1 = X_lo of the current step.  Per step, three MFMA blocks with
     // the reads of the sets they do not touch in flight, one barrier:
@@ -193,6 +215,12 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
       RS_RD_X(xf1, xa)
     }
     int sab = 0;                                 // t % 3
+#ifdef RS_SPLIT_PHASES
+    // diagnostic build (tools/ubench/split_phases.py): shader-clock stamps at the three points of a step where no LDS read is in flight (s_memtime is
+    // counted in lgkmcnt, so it cannot sit between the counted waits): before the vmcnt wait, before the barrier, after the barrier
+    unsigned long long ph_work = 0, ph_vm = 0, ph_bar = 0, ph_last = __builtin_amdgcn_s_memtime();
+    ph_loop0 = ph_last;
+#endif
     for (int t = 0; t < nk; ++t) {
       const unsigned wst = (t & 1) * WSTAGE, ast = sab * ASTAGE;
       __builtin_amdgcn_sched_barrier(0);
@@ -206,6 +234,13 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], xf1[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+#ifndef RS_SPLIT_SCHED_V1
+      // The activation pieces acts(t+2) are issued HERE, between the first two MFMA blocks, not together with the weight pieces behind the barrier: that
+      // chunk (8 LDS-DMA pieces with their address arithmetic + 12 fragment reads, ~900 cycles) was longer than the 512-cycle MFMA block the partner wave
+      // of the SIMD covers it with -- in-kernel stamps (tools/ubench/split_phases.py) showed waves 0-3 waiting 1 085 cycles per step at the barrier for
+      // waves 4-7.  (acts(t+2) goes to the buffer of step t-1, free since the last barrier -- for t = 0 a buffer nothing has used yet.)
+      if (t + 2 < nk) stage_a();
+#endif
       { const unsigned wa = wa1 + wst; RS_RD_W(wf1, wa) }                 // W_lo(t)
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                  // X_hi has landed
@@ -219,10 +254,27 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
       const int snext = sab == 2 ? 0 : sab + 1;
       if (t + 1 < nk) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // W_lo landed = my reads of step t's buffers are done
+#ifdef RS_SPLIT_PHASES
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ph1 = __builtin_amdgcn_s_memtime();
+        ph_work += ph1 - ph_last;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APS) : "memory");   // my pieces of step t+1 (all but acts(t+2))
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RS_SPLIT_PHASES
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
+        ph_vm += ph2 - ph1;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#ifdef RS_SPLIT_PHASES
+        ph_last = __builtin_amdgcn_s_memtime();
+        ph_bar += ph_last - ph2;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (wpx) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
@@ -232,7 +284,9 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
           __builtin_amdgcn_sched_barrier(0);
         }
         if (t + 2 < nk) stage_w();                 // w(t+2)    -> weight buffer of step t
+#ifdef RS_SPLIT_SCHED_V1
         if (t + 3 < nk) stage_a();                 // acts(t+3) -> activation buffer of step t
+#endif
         {
           const unsigned wa = wa0 + ((t + 1) & 1) * WSTAGE, xa = xa1 + snext * ASTAGE;      // W_hi(t+1), X_lo(t+1)
           RS_RD_W(wf0, wa)
@@ -253,6 +307,14 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
     }
 #undef RS_RD_W
 #undef RS_RD_X
+#ifdef RS_SPLIT_PHASES
+    ph_loop1 = __builtin_amdgcn_s_memtime();
+    if (p.probe && lane == 0) {
+      long long* o = p.probe + ((long long)q * 8 + wave) * 8;
+      o[0] = (long long)ph_work; o[1] = (long long)ph_vm; o[2] = (long long)ph_bar; o[3] = nk;
+      o[4] = (long long)(ph_loop0 - ph_entry); o[5] = (long long)(ph_loop1 - ph_loop0);
+    }
+#endif
   } else {
   reads0(0, 0);
   int abuf = 0;                                  // t % 3
@@ -535,6 +597,17 @@ __device__ __forceinline__ void conv_deep_tile(const ConvParams& p, char* smem, 
       }
     }
   }
+#ifdef RS_SPLIT_PHASES
+  if constexpr (SPLIT) {
+    const unsigned long long ph_issued = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ph_drained = __builtin_amdgcn_s_memtime();
+    if (p.probe && lane == 0) {
+      long long* o = p.probe + ((long long)q * 8 + wave) * 8;
+      o[6] = (long long)(ph_issued - ph_loop1); o[7] = (long long)(ph_drained - ph_issued);
+    }
+  }
+#endif
 }
 
 
@@ -623,6 +696,18 @@ static int deep_tail_tiles(long long tiles) {
   return (r > 0 && 2 * r <= ncu) ? r : 0;
 }
 
+// The fragment reads of these kernels are inline asm whose results the compiler believes ready at once; the hand-placed s_waitcnt cover the
+// REGISTERS.  A register the allocator spills right after such a read is stored before the data has landed (seen in the ISA of a variant of the split
+// loop that the compiler peeled: scratch_store of a fragment one instruction after its ds_read_b128), so a build of these kernels that uses scratch is
+// refused at first launch instead of computing garbage.
+static int no_scratch(const void* kernel, const char* what) {
+  hipFuncAttributes a;
+  RS_HIP(hipFuncGetAttributes(&a, kernel));
+  RS_CHECK(a.localSizeBytes == 0, RS_ERR_UNSUPPORTED, "%s was built with %zu bytes of scratch per thread: its asm fragment reads must not be spilled (rebuild with the documented toolchain)",
+           what, (size_t)a.localSizeBytes);
+  return RS_OK;
+}
+
 // Inference kernel with tiles of 32 * NJF pixels (variants 15 / 16 / 17; no training epilogue, no split last round)
 template <int NJF>
 static int launch_deep_nj(ConvParams& p, hipStream_t stream) {
@@ -630,6 +715,8 @@ static int launch_deep_nj(ConvParams& p, hipStream_t stream) {
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, NJF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     if constexpr (NJF >= 5) RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, NJF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    { int rc = no_scratch((const void*)conv_deep_kernel<0, false, NJF>, "conv_deep_kernel"); if (rc) return rc; }
+    if constexpr (NJF >= 5) { int rc = no_scratch((const void*)conv_deep_kernel<0, false, NJF, true>, "conv_deep_kernel (split operands)"); if (rc) return rc; }
     done = true;
   }
   const long long nblk = (long long)(p.Cout / BN) * cdiv(p.M, 32 * NJF);
@@ -657,6 +744,11 @@ int launch_conv_deep(const ConvParams& p0, hipStream_t stream, int tile_px) {
            "conv_deep: the fused head needs Cout == 256, its bias and output, and no other epilogue option");
   RS_CHECK(p.out_stride <= 1, RS_ERR_UNSUPPORTED, "conv_deep: no strided scatter");
   RS_CHECK(!p.split || (p.wscale && (!p.head_w || p.head_scale) && !p.down && !p.res32 && !p.mask), RS_ERR_UNSUPPORTED, "conv_deep: the split-operand mode needs the row scales (the fused head's too) and has no training epilogue");
+  if (p.split) {       // the split loop addresses its LDS-DMA pieces as SGPR base + 32-bit byte offset: both planes within 4 GB of the tensor's base
+    const long long in_px = (long long)cdiv(p.M, p.Ho * p.Wo) * p.in_Hp * p.in_Wp;
+    RS_CHECK((p.in_lo + in_px * p.in_Cs) * 2 < (1ll << 32) && (p.w_lo + (long long)p.Cout * p.Kpad) * 2 < (1ll << 32), RS_ERR_UNSUPPORTED,
+             "conv_deep: split-operand tensor of more than 4 GB (input %lld elements per plane)", in_px * p.in_Cs);
+  }
   if (tile_px != 256) {
     RS_CHECK(tile_px >= 64 && tile_px <= 224 && tile_px % 32 == 0 && !p.down && !p.res32 && !p.mask, RS_ERR_ARG,
              "conv_deep: tile height %d (256, or 64 .. 224 in steps of 32 without training epilogue options)", tile_px);
@@ -675,6 +767,9 @@ int launch_conv_deep(const ConvParams& p0, hipStream_t stream, int tile_px) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    { int rc = no_scratch((const void*)conv_deep_kernel<0>, "conv_deep_kernel"); if (rc) return rc; }
+    { int rc = no_scratch((const void*)conv_deep_kernel<0, true>, "conv_deep_kernel (training epilogue)"); if (rc) return rc; }
+    { int rc = no_scratch((const void*)conv_deep_kernel<0, false, 8, true>, "conv_deep_kernel (split operands)"); if (rc) return rc; }
 #ifdef RS_DEEP_CEILING
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -732,6 +827,9 @@ int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const 
   for (int i = 0; i < nseg; ++i) {
     RS_CHECK(segs[i].in && segs[i].w && segs[i].bias && segs[i].out && m_per_image[i] > 0, RS_ERR_ARG, "conv_deep_multi: map %d incomplete", i);
     RS_CHECK(!common.split || segs[i].wscale, RS_ERR_ARG, "conv_deep_multi: map %d has no row scales (split-operand mode)", i);
+    RS_CHECK(!common.split || ((segs[i].in_lo + (long long)images * segs[i].in_Hp * segs[i].in_Wp * common.in_Cs) * 2 < (1ll << 32) &&
+                               (common.w_lo + (long long)common.Cout * common.Kpad) * 2 < (1ll << 32)),
+             RS_ERR_UNSUPPORTED, "conv_deep_multi: map %d: split-operand tensor of more than 4 GB", i);
     p.seg[i] = segs[i];
     p.seg[i].M = images * m_per_image[i];
     p.seg[i].tile0 = (int)tiles;
@@ -750,6 +848,8 @@ int launch_conv_deep_multi(const ConvParams& common, const ConvSeg* segs, const 
   if (!done) {
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RS_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<0, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    { int rc = no_scratch((const void*)conv_deep_kernel<0>, "conv_deep_kernel"); if (rc) return rc; }
+    { int rc = no_scratch((const void*)conv_deep_kernel<0, false, 8, true>, "conv_deep_kernel (split operands)"); if (rc) return rc; }
     done = true;
   }
   if (p.split) {
