@@ -527,6 +527,30 @@ def main():
             log(f"fp16 mode: {fp16_mode['tiles_per_s']:.0f} tiles/s")
         except Exception as ex:
             fp16_mode = {"error": f"{type(ex).__name__}: {ex}"}
+    # one tile at a time, as the reference's `predictor(im)` loop submits them ([EXT od] make_detections.py): device-resident latency of a batch of 1
+    single = None
+    if rank == 0 and world == 1:
+        try:
+            from proj_roadsurf_amd.engine import Engine
+            single = {"what": "ms per forward of ONE tile (batch 1, tile resident in HBM, one engine, no overlap between tiles): the latency of a `predictor(im)` call without its PCIe copies"}
+            for prec in ([args.precision] + (["fp16"] if args.precision != "fp16" else [])):
+                e1 = Engine(spec.replace(precision=prec), W, (T, T, C_in), max_batch=1, device=local_rank)
+                try:
+                    p1 = e1.upload_tiles(tiles[:1])
+                    for _ in range(5):
+                        e1.infer_device(p1, 1)
+                    e1.sync()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(40):
+                        e1.infer_device(p1, 1)
+                    e1.sync()
+                    torch.cuda.synchronize()
+                    single[prec + "_ms"] = (time.perf_counter() - t1) / 40 * 1e3
+                finally:
+                    e1.close()
+        except Exception as ex:
+            single = {"error": f"{type(ex).__name__}: {ex}"}
     trained = None
     if rank == 0 and world == 1 and args.weights == "random" and W_tr is not None:
         try:
@@ -674,6 +698,7 @@ def main():
             "reference_precision": ref,
             "parity": par,
             "fp16_mode": fp16_mode,
+            "single_tile_latency": single,
             "trained_like": trained if trained is not None else ({"skipped": trained_error} if trained_error else None),
             "training": training,
             "value_is": f"the {args.steps} timed steps after {args.warmup} warm-up steps (driver contract); sustained_tiles_per_s = the same loop "

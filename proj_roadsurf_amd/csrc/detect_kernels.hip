@@ -52,6 +52,15 @@ __device__ void bitonic_sort_desc(unsigned long long* s, int n, int tid) {
   }
 }
 
+// smallest power of two >= c inside [lo, hi]: the bitonic sorts of the merge kernels run over the entries that exist (the rest of the list is zero
+// keys, which a descending sort leaves where they are), not over the capacity -- 66 passes over 2 048 entries instead of 91 over 8 192 when a tile
+// keeps 2 000 candidates; at batch 1 these one-workgroup kernels are a third of the forward's latency
+__device__ __forceinline__ int sort_size(unsigned c, int lo, int hi) {
+  int n = lo;
+  while (n < hi && (unsigned)n < c) n <<= 1;
+  return n;
+}
+
 // Box2BoxTransform.apply_deltas for one box, one delta quadruple (fp32, detectron2 op order).
 __device__ __forceinline__ void apply_deltas(const float b[4], const float d[4], float wx, float wy, float ww, float wh,
                                              float scale_clamp, float out[4]) {
@@ -268,7 +277,9 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnParams p) {
 // NMS over a segment of <= CAP boxes already in priority order.  CAP 1024: the suppression mask (128 KB) lives in LDS;
 // CAP 2048 (training, PRE_NMS_TOPK_TRAIN 2000): 512 KB per segment in a global scratch buffer (L2-resident).
 // ---------------------------------------------------------------------------------------------
-template <int CAP>
+// GM: the suppression mask lives in global memory (NmsParams::scratch) instead of LDS -- needed for CAP 2048, and used for CAP 1024 when few segments
+// are launched (batch 1-3): the quadratic mask build is then shared by gridDim.y workgroups (mode 1) and the scan runs as a second launch (mode 2)
+template <int CAP, bool GM>
 __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
   constexpr int WPR = CAP / 64;                                       // mask words per row
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -276,14 +287,14 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
   float* sarea = (float*)(smem + CAP * 16);                           // CAP * 4
   unsigned long long* sremoved = (unsigned long long*)(smem + CAP * 20);   // WPR * 8
   const int s = blockIdx.x, tid = threadIdx.x;
-  unsigned long long* mask = CAP == 1024 ? (unsigned long long*)(smem + CAP * 20 + 256)
-                                         : p.scratch + (long long)s * CAP * WPR;
+  unsigned long long* mask = !GM ? (unsigned long long*)(smem + CAP * 20 + 256)
+                                 : p.scratch + (long long)s * CAP * WPR;
   int n = p.count[s];
   if (n > CAP) n = CAP;
   const float* boxes = p.boxes + (long long)s * p.cap * 4;
   const uint8_t* valid = p.valid ? p.valid + (long long)s * p.cap : nullptr;
   uint8_t* keep = p.keep + (long long)s * p.cap;
-  if (!(CAP != 1024 && p.mode == 1)) for (int i = tid; i < p.cap; i += 1024) keep[i] = 0;
+  if (!(GM && p.mode == 1)) for (int i = tid; i < p.cap; i += 1024) keep[i] = 0;
   if (tid < WPR) sremoved[tid] = 0ull;
   __syncthreads();
   for (int ti = tid; ti < n; ti += 1024) {
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
   // so that every task slot (row pair, word slot) carries the same load and all 16 waves stay busy.
   const int nh = (n + 1) >> 1;
   const int nhp = (nh + 63) & ~63;
-  const bool build = p.debug != 2 && !(CAP != 1024 && p.mode == 2);
+  const bool build = p.debug != 2 && !(GM && p.mode == 2);
   for (int idx = tid + blockIdx.y * 1024; idx < (nw + 2) * nhp && build; idx += 1024 * gridDim.y) {
     const int wq = idx / nhp, ip = idx - wq * nhp;
     if (ip >= nh) continue;
@@ -345,8 +356,8 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
     }
     mask[(long long)i * WPR + w] = bits;
   }
-  if (CAP != 1024 && p.mode == 1) return;                // mask build only: the scan is the next launch (mode 2)
-  if (CAP != 1024) __threadfence();       // mask rows in global memory: visible to the scanning wave after the barrier
+  if (GM && p.mode == 1) return;                // mask build only: the scan is the next launch (mode 2)
+  if (GM) __threadfence();       // mask rows in global memory: visible to the scanning wave after the barrier
   __syncthreads();
   // Greedy scan, one wave, 64 boxes (one mask word) per step: the intra-chunk part is resolved on
   // the scalar unit from the diagonal words (lane b holds row b), then the rows of the survivors
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(1024) void rpn_merge_kernel(const RpnMergeParams p)
     }
   }
   __syncthreads();
-  bitonic_sort_desc<1024>(list, SORTN, tid);
+  bitonic_sort_desc<1024>(list, sort_size(cnt, 1024, SORTN), tid);
   const int total = (int)cnt < p.post_topk ? (int)cnt : p.post_topk;
   if (tid == 0) p.prop_count[n] = total;
   for (int i = tid; i < p.cap; i += 1024) {
@@ -1340,7 +1351,7 @@ __global__ __launch_bounds__(1024) void det_merge_kernel(const DetMergeParams p)
     }
   }
   __syncthreads();
-  bitonic_sort_desc<1024>(list, 8192, tid);
+  bitonic_sort_desc<1024>(list, sort_size(cnt, 1024, 8192), tid);
   const int D = p.dets_per_image;
   const int nd = (int)cnt < D ? (int)cnt : D;
   float bn[4] = {0, 0, 0, 0}, bo[4] = {0, 0, 0, 0};
@@ -1603,26 +1614,35 @@ int launch_nms(const NmsParams& p, int segments, hipStream_t s) {
   const int lds_big = 2048 * 20 + 256;
   static bool done = false;
   if (!done) {
-    RS_HIP(hipFuncSetAttribute((const void*)nms_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    RS_HIP(hipFuncSetAttribute((const void*)nms_kernel<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
+    RS_HIP(hipFuncSetAttribute((const void*)nms_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    RS_HIP(hipFuncSetAttribute((const void*)nms_kernel<2048, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
     done = true;
   }
   RS_CHECK(p.cap > 0 && p.cap <= 2048 && (p.cap <= 1024 || p.scratch), RS_ERR_ARG, "nms: capacity %d (more than 1024 boxes need NmsParams::scratch)", p.cap);
   NmsParams q = p;
   q.debug = rs_debug().nms_debug;
-  if (p.cap <= 1024) hipLaunchKernelGGL(nms_kernel<1024>, dim3(segments), dim3(1024), lds, s, q);
-  else {
-    // few segments (images x levels) and a quadratic mask build: with one workgroup per segment most of the chip idles, so the
-    // rows of a segment are shared by `parts` workgroups and the (serial, cheap) scan runs as a second launch
-    int parts = segments >= 256 ? 1 : (256 + segments - 1) / segments;
-    if (parts > 16) parts = 16;
-    if (parts == 1) { q.mode = 0; hipLaunchKernelGGL(nms_kernel<2048>, dim3(segments), dim3(1024), lds_big, s, q); }
+  // few segments (images x levels / classes) and a quadratic mask build: with one workgroup per segment most of the chip idles, so the rows of a
+  // segment are shared by `parts` workgroups (mask in global memory) and the (serial, cheap) scan runs as a second launch.  Same tests, same
+  // greedy scan: identical keep flags.
+  int parts = segments >= 256 ? 1 : (256 + segments - 1) / segments;
+  if (parts > 16) parts = 16;
+  if (p.cap <= 1024) {
+    if (!p.scratch || segments > 32 || parts == 1) hipLaunchKernelGGL((nms_kernel<1024, false>), dim3(segments), dim3(1024), lds, s, q);
     else {
+      if (parts > 8) parts = 8;
       q.mode = 1;
-      hipLaunchKernelGGL(nms_kernel<2048>, dim3(segments, parts), dim3(1024), lds_big, s, q);
+      hipLaunchKernelGGL((nms_kernel<1024, true>), dim3(segments, parts), dim3(1024), 1024 * 20 + 256, s, q);
       q.mode = 2;
-      hipLaunchKernelGGL(nms_kernel<2048>, dim3(segments), dim3(1024), lds_big, s, q);
+      hipLaunchKernelGGL((nms_kernel<1024, true>), dim3(segments), dim3(1024), 1024 * 20 + 256, s, q);
     }
+  } else if (parts == 1) {
+    q.mode = 0;
+    hipLaunchKernelGGL((nms_kernel<2048, true>), dim3(segments), dim3(1024), lds_big, s, q);
+  } else {
+    q.mode = 1;
+    hipLaunchKernelGGL((nms_kernel<2048, true>), dim3(segments, parts), dim3(1024), lds_big, s, q);
+    q.mode = 2;
+    hipLaunchKernelGGL((nms_kernel<2048, true>), dim3(segments), dim3(1024), lds_big, s, q);
   }
   RS_HIP(hipGetLastError());
   return RS_OK;

@@ -796,6 +796,8 @@ int rs_engine::build() {
     NmsParams np = {};
     np.boxes = rp.cand_boxes; np.count = rp.cand_count; np.valid = rp.cand_valid; np.keep = cand_keep; np.cap = 1024;
     np.thresh = S.rpn_nms_thresh;
+    // suppression masks in global memory for launches of few segments (batch 1-3: launch_nms shares a segment's mask build between workgroups)
+    if ((rc = alloc((void**)&np.scratch, (size_t)(NB * L < 32 ? NB * L : 32) * 1024 * 16 * 8))) return rc;
     Stage st;
     st.name = "rpn.nms";
     st.fn = [np, L](int n, hipStream_t s) { return launch_nms(np, n * L, s); };
@@ -922,6 +924,7 @@ int rs_engine::build() {
   {
     NmsParams np = {};
     np.boxes = bc.seg_boxes; np.count = bc.seg_count; np.valid = nullptr; np.keep = seg_keep; np.cap = 1024; np.thresh = S.nms_thresh_test;
+    if ((rc = alloc((void**)&np.scratch, (size_t)(NB * K < 32 ? NB * K : 32) * 1024 * 16 * 8))) return rc;
     Stage st;
     st.name = "box.nms";
     st.fn = [np, K](int n, hipStream_t s) { return launch_nms(np, n * K, s); };
