@@ -350,6 +350,7 @@ def main():
                          "accumulate; meets the stated tolerance on the benched workload), fp16 = plain fp16 operands (2.7x faster; meets it on a "
                          "trained detector, not on the saturated random-weight workload), fp32 = the fp32 matrix cores")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the `fp16_mode` object of the default run")
+    ap.add_argument("--no-single-tile-leg", action="store_true", help="skip the `single_tile_latency` object (profiler runs: its batch-1 launches would enter the per-kernel averages)")
     ap.add_argument("--train-steps", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-stage table to stderr")
@@ -529,7 +530,7 @@ def main():
             fp16_mode = {"error": f"{type(ex).__name__}: {ex}"}
     # one tile at a time, as the reference's `predictor(im)` loop submits them ([EXT od] make_detections.py): device-resident latency of a batch of 1
     single = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_single_tile_leg:
         try:
             from proj_roadsurf_amd.engine import Engine
             single = {"what": "ms per forward of ONE tile (batch 1, tile resident in HBM, one engine, no overlap between tiles): the latency of a `predictor(im)` call without its PCIe copies"}

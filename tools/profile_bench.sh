@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$PREC
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--precision $PREC --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-reference-precision --no-trained-leg --no-train-leg --no-fp16-leg"
+ARGS="--precision $PREC --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-reference-precision --no-trained-leg --no-train-leg --no-fp16-leg --no-single-tile-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ROOT/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/bench_b16_kernel_stats.csv
 echo "[profile] kernel trace done"
