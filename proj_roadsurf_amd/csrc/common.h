@@ -203,6 +203,24 @@ struct BneckParams {
 };
 int launch_bneck_tail(const BneckParams& p, hipStream_t stream);
 
+// The same tail in the split-operand precision mode (bneck_split.hip): every tensor a hi plane with its lo plane `*_lo` ELEMENTS behind it, weights
+// row-scaled with the inverse scales s2 / s3 / s1 (ConvParams::split); identity shortcut only.
+struct BneckSplitParams {
+  const half_t* t1; long long t1_lo;        // conv2 input  [N][H+2][W+2][64 CB]
+  const half_t* w2; long long w2_lo;        // [64 CB][9 * 64 CB]
+  const float* b2; const float* s2;
+  const half_t* w3p; long long w3_lo;       // conv3 weight [256 CB][64 CB], K columns in the register-chaining order (weights.py _perm_k64, group = 64 CB)
+  const float* b3; const float* s3;
+  const half_t* x; long long x_lo;          // block input = residual [N][H+2][W+2][256 CB]
+  half_t* out; long long out_lo;            // block output
+  const half_t* w1p; long long w1_lo;       // next block's conv1 [64 CB][256 CB], K columns permuted per group of 64; nullptr = stop after conv3
+  const float* b1; const float* s1;
+  half_t* t1n; long long t1n_lo;            // next block's conv1 output [N][H+2][W+2][64 CB]
+  int M, H, W, Hp, Wp;
+  int CB;
+};
+int launch_bneck_tail_split(const BneckSplitParams& p, hipStream_t stream);
+
 // ------------------------------------------------------------------ raster voting (raster_vote.hip)
 int launch_mask_overlap(const uint8_t* det, int n_det, const uint8_t* lab, int n_lab, int h, int w, int* inter, int* lab_area, hipStream_t s);
 

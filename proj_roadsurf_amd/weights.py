@@ -559,6 +559,15 @@ def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False
             w3, wsc = T32[blk + ".conv3.w"], T32[blk + ".shortcut.w"]
             if w3.shape[1] % 64 == 0 and wsc.shape[1] % 64 == 0 and blk + ".conv3sc.b" in T:
                 T[blk + ".conv3sc.ws"], T[blk + ".conv3sc.wsi"] = split_planes(np.concatenate([w3, wsc], 1))
+        # fused bottleneck tails of the identity-shortcut blocks of res2 / res3 (csrc/bneck_split.hip): conv3 and the next block's conv1 with their
+        # K columns in the register-chaining order.  The row scale does not depend on the column order, so ".conv3p.wsi" equals ".conv3.wsi".
+        if spec.num_groups * spec.width_per_group == 64 and spec.res2_out_channels == 256:
+            for si, width in ((0, 64), (1, 128)):
+                for bi in range(1, spec.res_blocks[si]):
+                    blk = f"backbone.bottom_up.res{si + 2}.{bi}"
+                    T[blk + ".conv3p.ws"], T[blk + ".conv3p.wsi"] = split_planes(_perm_k64(T32[blk + ".conv3.w"], width))
+                    if bi >= 2:
+                        T[blk + ".conv1p.ws"], T[blk + ".conv1p.wsi"] = split_planes(_perm_k64(T32[blk + ".conv1.w"], 64))
     return serialize(T)
 
 
