@@ -383,11 +383,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # One rank per GPU is the contract.  With fewer devices than local ranks (a rehearsal of the N > 1 path on a one-GPU box) the ranks share
+    # devices round-robin and rendezvous over gloo (RCCL refuses two ranks on one device); the line then says so and is not a scaling point.
+    ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    shared = local_world > ndev
+    dev = local_rank % ndev
+    rdev = "cpu" if shared else "cuda"           # where the barrier / max-over-ranks tensors live
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with stdout_to_stderr():
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+            dist.init_process_group(backend="gloo" if shared else "nccl", rank=rank, world_size=world)
             dist.barrier()                       # the communicator (and RCCL's banner) comes up here, not inside the timed region
 
     from proj_roadsurf_amd.engine import LanePipeline
@@ -404,7 +411,7 @@ def main():
         if world != 1:
             raise SystemExit("--train measures one GPU (the 8-GPU data-parallel run is the driver's)")
         with stdout_to_stderr():
-            tl = training_leg(spec, synthetic_weights(spec, seed=0), local_rank, steps=args.steps, warmup=args.warmup,
+            tl = training_leg(spec, synthetic_weights(spec, seed=0), dev, steps=args.steps, warmup=args.warmup,
                               legs=tuple(["b8"] + [x for x in args.train_legs.split(",") if x]))
         b8 = tl["batch8"]
         print(json.dumps({"metric": "train_images_per_sec_512x512x3", "value": b8["images_per_s"], "unit": "images/s", "n_gpus": 1,
@@ -420,7 +427,7 @@ def main():
     def measure(W, tiles, want_stage_events, precision=None):
         """headline-style measurement of one (weights, tiles) workload: K-step region on the lane pipeline + detections of batch 0"""
         L = max(1, args.lanes)
-        pipe = LanePipeline(spec.replace(precision=precision or args.precision), W, (T, T, C_in), max_batch=B, device=local_rank, lanes=L)
+        pipe = LanePipeline(spec.replace(precision=precision or args.precision), W, (T, T, C_in), max_batch=B, device=dev, lanes=L)
         try:
             engs = pipe.engines
             ptrs = [e.upload_tiles(tiles) for e in engs]
@@ -432,7 +439,7 @@ def main():
                     e.set_profiling(args.profile_mode)   # HIP events around the launches, on each lane's stream, no host wait
             dt = timed_steps(pipe, ptrs, B, args.steps, 0, barrier, torch.cuda.synchronize)
             if world > 1:
-                tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dt = float(tmax.item())
             stages = None
@@ -457,7 +464,7 @@ def main():
                         pipe.submit(ptrs[pipe.k % L], B)
                     n_sus += 32
                     pipe.sync()
-                    stop = torch.tensor([1.0 if time.perf_counter() - ts >= args.sustain_seconds else 0.0], device="cuda")
+                    stop = torch.tensor([1.0 if time.perf_counter() - ts >= args.sustain_seconds else 0.0], device=rdev)
                     if world > 1:
                         dist.all_reduce(stop, op=dist.ReduceOp.MAX)    # every rank leaves the loop after the same number of steps
                     if float(stop.item()) > 0:
@@ -466,7 +473,7 @@ def main():
                 barrier()
                 dts = time.perf_counter() - ts
                 if world > 1:
-                    tm = torch.tensor([dts], dtype=torch.float64, device="cuda")
+                    tm = torch.tensor([dts], dtype=torch.float64, device=rdev)
                     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                     dts = float(tm.item())
                 sustained = {"tiles_per_s": world * B * n_sus / dts, "steps": n_sus, "seconds": dts}
@@ -514,7 +521,7 @@ def main():
     ref = par = fp16_mode = None
     PNAME = {"split": "split-operand (hi + lo fp16 planes, 3 MFMA products)", "fp16": "fp16-operand", "fp32": "fp32-MFMA"}
     if rank == 0 and not args.no_ref:
-        ref, dets32 = reference_precision_leg(spec, W, tiles, B, args.steps, args.warmup, local_rank)
+        ref, dets32 = reference_precision_leg(spec, W, tiles, B, args.steps, args.warmup, dev)
         par = parity_object(H["dets"], dets32, f"{PNAME[args.precision]} engine (the engine `value` is measured on) vs reference-precision (fp32 MFMA) engine, the benched batch of this line, GPU vs GPU")
         log(f"reference precision: {ref['tiles_per_s']:.0f} tiles/s; parity of the {args.precision} headline {par['matched_fw']:.3f} / {par['matched_bw']:.3f} of {par['n_fw']}")
     if rank == 0 and world == 1 and args.precision != "fp16" and not args.no_fp16_leg:
@@ -535,7 +542,7 @@ def main():
             from proj_roadsurf_amd.engine import Engine
             single = {"what": "ms per forward of ONE tile (batch 1, tile resident in HBM, one engine, no overlap between tiles): the latency of a `predictor(im)` call without its PCIe copies"}
             for prec in ([args.precision] + (["fp16"] if args.precision != "fp16" else [])):
-                e1 = Engine(spec.replace(precision=prec), W, (T, T, C_in), max_batch=1, device=local_rank)
+                e1 = Engine(spec.replace(precision=prec), W, (T, T, C_in), max_batch=1, device=dev)
                 try:
                     p1 = e1.upload_tiles(tiles[:1])
                     for _ in range(5):
@@ -562,14 +569,14 @@ def main():
                        "proposals_per_tile": Ht["nprop"], "detections_per_tile": Ht["ndet"], "pcie_inclusive_tiles_per_s": Ht["pcie"],
                        "precision": args.precision, "fp16_tiles_per_s": B * args.steps / Ht16["dt"], "fp16_pcie_inclusive_tiles_per_s": Ht16["pcie"]}
             if not args.no_ref:
-                rt, d32t = reference_precision_leg(spec, W_tr, tiles_tr, B, max(3, args.steps // 4), 1, local_rank)
+                rt, d32t = reference_precision_leg(spec, W_tr, tiles_tr, B, max(3, args.steps // 4), 1, dev)
                 trained["reference_precision_tiles_per_s"] = rt["tiles_per_s"]
                 # parity over a pool that makes the >= 0.98 bar decidable: 12 batches of fresh scenes (~1500 detections), both engines on the GPU
                 from proj_roadsurf_amd.engine import Engine
                 got, got16, want = list(Ht["dets"]), list(Ht16["dets"]), list(d32t)
-                eh = Engine(spec.replace(precision=args.precision), W_tr, (T, T, C_in), max_batch=B, device=local_rank)
-                e16 = Engine(spec.replace(precision="fp16"), W_tr, (T, T, C_in), max_batch=B, device=local_rank) if args.precision != "fp16" else eh
-                e32 = Engine(spec.replace(precision="fp32"), W_tr, (T, T, C_in), max_batch=B, device=local_rank)
+                eh = Engine(spec.replace(precision=args.precision), W_tr, (T, T, C_in), max_batch=B, device=dev)
+                e16 = Engine(spec.replace(precision="fp16"), W_tr, (T, T, C_in), max_batch=B, device=dev) if args.precision != "fp16" else eh
+                e32 = Engine(spec.replace(precision="fp32"), W_tr, (T, T, C_in), max_batch=B, device=dev)
                 try:
                     for k in range(1, 12):
                         more = synthetic_scenes(B, T, T, C_in, seed=555000 + 7919 * k, objects=(4, 12))[0]
@@ -593,7 +600,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_train_leg and C_in == 3 and T == 512:
         try:                                     # an optional leg never costs the headline: its failure is reported inside the line
             with stdout_to_stderr():
-                training = training_leg(spec, W_rand, local_rank)
+                training = training_leg(spec, W_rand, dev)
         except Exception as ex:
             training = {"error": f"{type(ex).__name__}: {ex}"}
             log(f"training leg failed: {ex}")
@@ -707,6 +714,7 @@ def main():
             "sustained_tiles_per_s": H["sustained"]["tiles_per_s"] if H["sustained"] else None,
             "sustained": H["sustained"],
             "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+            **({"rehearsal": f"{local_world} ranks share {ndev} device(s): gloo rendezvous instead of RCCL, `value` is NOT a scaling point"} if shared else {}),
             "pcie_inclusive_tiles_per_s": H["pcie"],
             "top_stages": [{"name": s["name"], "ms_per_step": s["ms_total"] / max(s["calls"], 1)} for s in by_time[:6]],
         }
