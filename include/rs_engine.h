@@ -212,10 +212,14 @@ int rs_op_bneck_tail(const void* t1, const void* w2, const float* b2, const void
 /* The identity-shortcut form of rs_op_bneck_tail in the split-operand precision mode (csrc/bneck_split.hip; rs_spec.precision == 2): every map is
  * a hi plane with its lo plane `*_lo` ELEMENTS behind it (value = hi + lo); every weight is [2 * rows][K] fp16 -- hi rows, then lo rows, of the
  * fp32 weight with each row scaled by a power of two (weights.py split_planes) -- and s2 / s3 / s1 hold the inverse scales per row.  Same shapes,
- * K orders and halo as rs_op_bneck_tail; w1p (with s1, b1, t1n) may be NULL. */
+ * K orders and halo as rs_op_bneck_tail; w1p (with s1, b1, t1n) may be NULL.  Projection-shortcut form (width 64 only): x = NULL and x0
+ * [n][h+2][w+2][64] (+ x0_lo) is the shortcut's input; w3p then is [2 * 256][128] -- the K columns of conv3 in the chained order followed by
+ * the shortcut's 64 in natural order, ONE scale per row over both (s3) -- and b3 the sum of the two biases:
+ * out = relu((w3 . t2 + wsc . x0) * s3 + b3). */
 int rs_op_bneck_tail_split(const void* t1, int64_t t1_lo, const void* w2, const float* s2, const float* b2, const void* w3p, const float* s3,
                            const float* b3, const void* x, int64_t x_lo, void* out, int64_t out_lo, const void* w1p, const float* s1,
-                           const float* b1, void* t1n, int64_t t1n_lo, int n, int h, int w, int width, void* stream);
+                           const float* b1, void* t1n, int64_t t1n_lo, const void* x0, int64_t x0_lo, int n, int h, int w, int width,
+                           void* stream);
 
 /* Raster voting: the overlay of R:scripts/road_segmentation/determine_class.py:97-120 on the tile grid.
  * det_masks [n_det][h][ceil(w/8)] and label_masks [n_labels][same] are bit-packed device buffers (rs_dets.masks layout; h*ceil(w/8)

@@ -17,13 +17,21 @@
 //
 // Unlike bneck_fused.hip this file takes no liberties with the compiler: operands are staged by LDS-DMA behind plain waits and barriers, the residual is a
 // plain global load.  Two workgroups per CU (64 KB of LDS each) overlap one's waits with the other's matrix work.
+//
+// Projection form (PROJ; the first block of res2, whose 1x1 shortcut reads the 64-channel stem output at the block's own resolution): no residual; the
+// shortcut's GEMM is two more K steps of conv3 -- w3p = [conv3 in the chained order | shortcut in natural order] under one scale per row -- whose B
+// fragments are read once per tile from a copy of the x0 tile staged over the retired conv2 stages.  At batch 16: conv2 0.200 + conv3 (dual source)
+// 0.268 + the next conv1 0.195 ms -> 0.455 ms.
+//
+// What bounds it (profiles/r04/tail_split_ablation.txt): every workgroup alternates a matrix-bound conv2 phase with an HBM-bound conv3 phase and the two
+// overlap badly across workgroups; a deeper-pipelined variant (three-stage ring, double-buffered pass slices, residual one pass ahead) measured the same.
 #include "common.h"
 
 namespace {
 
 constexpr int NJ = 2, NT = 256, BM = 4 * NJ * 16, PXW = NJ * 16;     // 4 waves x 32 pixels
 
-template <int CB>
+template <int CB, bool PROJ = false>
 struct SCfg {
   static constexpr int CBW = 64 * CB;              // bottleneck width
   static constexpr int C4 = 256 * CB;              // block input / output channels
@@ -31,7 +39,9 @@ struct SCfg {
   static constexpr int NPASS = 4 * CB;             // conv3 output channel groups of 64
   static constexpr int KS2 = 9 * 2 * CB;           // conv2 K steps of 32 channels x (hi, lo): 32-channel slice outer, taps inner
   static constexpr int STAGE = (BM + CBW) * 128;   // conv2 stage: activation rows + weight rows, 128 B = [32 hi | 32 lo] each
-  static constexpr int W3_BYTES = 2 * CB * 64 * 128;   // pass slice of W3p: 2 CB K steps x 64 rows x 128 B
+  static constexpr int S3 = 2 * CB + (PROJ ? 2 : 0);   // K steps of conv3 (+ the 64-channel projection shortcut)
+  static constexpr int W3K = CBW + (PROJ ? 64 : 0);    // K columns of a row of w3p
+  static constexpr int W3_BYTES = S3 * 64 * 128;       // pass slice of W3p: S3 K steps x 64 rows x 128 B
   static constexpr int W1_BYTES = 2 * CBW * 128;       // pass slice of W1p: 2 K steps x CBW rows x 128 B
   static constexpr int PASS_BYTES = W3_BYTES + W1_BYTES;
   static constexpr int LDS_BYTES = 2 * STAGE > PASS_BYTES ? 2 * STAGE : PASS_BYTES;     // CB 1: 48 KB, CB 2: 64 KB
@@ -57,9 +67,10 @@ __device__ __forceinline__ float relu_clamp(float v) { v = v > 0.f ? v : 0.f; re
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0);      \
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);
 
-template <int CB, bool NEXT>
+template <int CB, bool NEXT, bool PROJ>
 __global__ __launch_bounds__(NT, 2) void bneck_tail_split_kernel(const BneckSplitParams p) {
-  using G = SCfg<CB>;
+  using G = SCfg<CB, PROJ>;
+  static_assert(!PROJ || CB == 1, "projection form: 64-wide stage only");
   constexpr int CBW = G::CBW, C4 = G::C4, MIB = G::MIB, NPASS = G::NPASS, KS2 = G::KS2, STAGE = G::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -109,8 +120,8 @@ __global__ __launch_bounds__(NT, 2) void bneck_tail_split_kernel(const BneckSpli
       const int key = (row & 3) | (((row >> 4) & 1) << 2);
       const int d = lchk ^ key;
 #pragma unroll
-      for (int s = 0; s < 2 * CB; ++s)
-        glds16s(p.w3p + (long long)(pass * 64 + row) * CBW + s * 32 + (d & 3) * 8 + (d >> 2) * p.w3_lo, smem + s * 8192 + (ps * 32 + wave * 8) * 128);
+      for (int s = 0; s < G::S3; ++s)
+        glds16s(p.w3p + (long long)(pass * 64 + row) * G::W3K + s * 32 + (d & 3) * 8 + (d >> 2) * p.w3_lo, smem + s * 8192 + (ps * 32 + wave * 8) * 128);
     }
     if (NEXT) {
 #pragma unroll
@@ -153,6 +164,18 @@ __global__ __launch_bounds__(NT, 2) void bneck_tail_split_kernel(const BneckSpli
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   stage_tap(0, 0);
+  auto stage_x0 = [&](char* base) {      // the shortcut's input at the tile's own pixels (tap (1,1) of its haloed map), both 32-channel steps, rows swizzled like conv2's
+#pragma unroll
+    for (int ps = 0; ps < BM / 32; ++ps) {
+      int m = m0 + ps * 32 + wave * 8 + lrow;
+      if (m >= M) m = M - 1;
+      const int x = m % p.W, t = m / p.W, y = t % p.H, n = t / p.H;
+      const int d = lchk ^ lrow;
+      const half_t* xp = p.x0 + ((long long)(n * p.Hp + y + 1) * p.Wp + x + 1) * 64 + (d & 3) * 8 + (d >> 2) * p.x0_lo;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) glds16s(xp + s * 32, base + s * BM * 128 + (ps * 32 + wave * 8) * 128);
+    }
+  };
   for (int t = 0; t < KS2; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                // step t has landed; everyone is done reading the other buffer
@@ -184,6 +207,22 @@ __global__ __launch_bounds__(NT, 2) void bneck_tail_split_kernel(const BneckSpli
 #pragma unroll
       for (int j = 0; j < NJ; ++j) split8(acc[2 * s][j], acc[2 * s + 1][j], th[s][j], tl[s][j]);
   }
+  half8 x0h[PROJ ? 2 : 1][NJ], x0l[PROJ ? 2 : 1][NJ];      // projection form: B fragments of the shortcut's two K steps
+  if (PROJ) {
+    // staged over the conv2 stages once they are done with (a resident copy from the prologue on -- 80 KB of LDS -- measured the same: 0.455 / 0.453 ms)
+    const char* xb = smem;
+    __syncthreads();
+    stage_x0(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        x0h[s][j] = *(const half8*)(xb + s * BM * 128 + x_off[j] + ch_off);
+        x0l[s][j] = *(const half8*)(xb + s * BM * 128 + x_off[j] + cl_off);
+      }
+  }
   f32x4 acc3[MIB][NJ];         // t1n accumulators: channels 16 CB fq + 4 i + r of pixel (j, fi)
 #pragma unroll
   for (int i = 0; i < MIB; ++i)
@@ -197,11 +236,13 @@ __global__ __launch_bounds__(NT, 2) void bneck_tail_split_kernel(const BneckSpli
     const int cb = pass * 64 + fq * 16;             // this lane's 16 output channels of the pass
     // residual of the pass (block input, both planes): plain loads, in flight next to the slices
     half8 rh[NJ][2], rl[NJ][2];
+    if (!PROJ) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const half_t* xp = p.x + opix[j] * C4 + cb;
-      rh[j][0] = *(const half8*)xp; rh[j][1] = *(const half8*)(xp + 8);
-      rl[j][0] = *(const half8*)(xp + p.x_lo); rl[j][1] = *(const half8*)(xp + p.x_lo + 8);
+      for (int j = 0; j < NJ; ++j) {
+        const half_t* xp = p.x + opix[j] * C4 + cb;
+        rh[j][0] = *(const half8*)xp; rh[j][1] = *(const half8*)(xp + 8);
+        rl[j][0] = *(const half8*)(xp + p.x_lo); rl[j][1] = *(const half8*)(xp + p.x_lo + 8);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                // the pass slices have landed
@@ -216,13 +257,20 @@ __global__ __launch_bounds__(NT, 2) void bneck_tail_split_kernel(const BneckSpli
           const half8 wh = *(const half8*)(smem + s * 8192 + w_off[i] + ch_off), wl = *(const half8*)(smem + s * 8192 + w_off[i] + cl_off);
           RS_MFMA3(a2[i], wh, wl, th[s][j], tl[s][j])
         }
+        if (PROJ) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const half8 wh = *(const half8*)(smem + (2 * CB + s) * 8192 + w_off[i] + ch_off), wl = *(const half8*)(smem + (2 * CB + s) * 8192 + w_off[i] + cl_off);
+            RS_MFMA3(a2[i], wh, wl, x0h[s][j], x0l[s][j])
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x4 s3v = *(const f32x4*)(p.s3 + cb + i * 4), b3v = *(const f32x4*)(p.b3 + cb + i * 4);      // L1-resident: 2 x 256 CB floats per block
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float res = (float)rh[j][i >> 1][(i & 1) * 4 + r] + (float)rl[j][i >> 1][(i & 1) * 4 + r];
+          const float res = PROJ ? 0.f : (float)rh[j][i >> 1][(i & 1) * 4 + r] + (float)rl[j][i >> 1][(i & 1) * 4 + r];
           a2[i][r] = relu_clamp(a2[i][r] * s3v[r] + b3v[r] + res);
         }
       }
@@ -267,12 +315,12 @@ __global__ __launch_bounds__(NT, 2) void bneck_tail_split_kernel(const BneckSpli
   }
 }
 
-template <int CB>
+template <int CB, bool PROJ>
 int launch_split_cb(const BneckSplitParams& p, hipStream_t stream) {
-  using G = SCfg<CB>;
+  using G = SCfg<CB, PROJ>;
   const long long nblk = cdiv(p.M, BM);
   RS_CHECK(nblk < (1ll << 31), RS_ERR_ARG, "bneck_tail_split: grid too large");
-  const void* k = p.w1p ? (const void*)bneck_tail_split_kernel<CB, true> : (const void*)bneck_tail_split_kernel<CB, false>;
+  const void* k = p.w1p ? (const void*)bneck_tail_split_kernel<CB, true, PROJ> : (const void*)bneck_tail_split_kernel<CB, false, PROJ>;
   static bool attr[2] = {false, false};
   const int ai = p.w1p ? 1 : 0;
   if (!attr[ai]) {
@@ -288,9 +336,13 @@ int launch_split_cb(const BneckSplitParams& p, hipStream_t stream) {
 }  // namespace
 
 int launch_bneck_tail_split(const BneckSplitParams& p, hipStream_t stream) {
-  RS_CHECK(p.M > 0 && p.t1 && p.w2 && p.b2 && p.s2 && p.w3p && p.b3 && p.s3 && p.x && p.out, RS_ERR_ARG, "bneck_tail_split: null argument");
+  RS_CHECK(p.M > 0 && p.t1 && p.w2 && p.b2 && p.s2 && p.w3p && p.b3 && p.s3 && (p.x || p.x0) && !(p.x && p.x0) && p.out, RS_ERR_ARG, "bneck_tail_split: null argument");
   RS_CHECK(p.Hp == p.H + 2 && p.Wp == p.W + 2, RS_ERR_ARG, "bneck_tail_split: maps must carry a halo of 1");
   RS_CHECK(!p.w1p || (p.b1 && p.s1 && p.t1n), RS_ERR_ARG, "bneck_tail_split: next conv1 needs weights, scales, bias and output");
   RS_CHECK(p.CB == 1 || p.CB == 2, RS_ERR_UNSUPPORTED, "bneck_tail_split: bottleneck width %d (64 or 128)", 64 * p.CB);
-  return p.CB == 1 ? launch_split_cb<1>(p, stream) : launch_split_cb<2>(p, stream);
+  if (p.x0) {
+    RS_CHECK(p.CB == 1, RS_ERR_UNSUPPORTED, "bneck_tail_split: the projection-shortcut form exists for the 64-wide stage only");
+    return launch_split_cb<1, true>(p, stream);
+  }
+  return p.CB == 1 ? launch_split_cb<1, false>(p, stream) : launch_split_cb<2, false>(p, stream);
 }

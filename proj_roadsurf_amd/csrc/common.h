@@ -216,6 +216,10 @@ struct BneckSplitParams {
   const half_t* w1p; long long w1_lo;       // next block's conv1 [64 CB][256 CB], K columns permuted per group of 64; nullptr = stop after conv3
   const float* b1; const float* s1;
   half_t* t1n; long long t1n_lo;            // next block's conv1 output [N][H+2][W+2][64 CB]
+  // projection-shortcut form (first block of res2; CB = 1): x = nullptr and x0 [N][H+2][W+2][64] is the shortcut's input; w3p then is [256][128] =
+  // [conv3 (chained K order) | shortcut (natural K order)] with ONE power-of-two scale per row over both parts (w3_lo = 256 * 128), b3 the sum of the
+  // two biases: out = relu((W3 . t2 + Wsc . x0) * s3 + b3)
+  const half_t* x0; long long x0_lo;
   int M, H, W, Hp, Wp;
   int CB;
 };

@@ -601,19 +601,22 @@ int rs_engine::build() {
       // Split-operand mode: the same chain on hi + lo planes (bneck_split.hip), identity-shortcut blocks only.
       const bool tail_s = split && fuse_bneck && rs_debug().conv_deep && use_glds > 0 && bi > 0 && (bott == 64 || bott == 128) && cout == 4 * bott && stride == 1 &&
                           findw(wn + ".conv3p") != nullptr && find(wn + ".conv3p.wsi") != nullptr;
-      const bool tail_next = (tail || tail_s) && bi + 1 < S.res_blocks[si] &&
+      // ... and res2.0, whose projection shortcut reads the 64-channel stem output at the same resolution (conv3 | shortcut as one [256][128] operand)
+      const bool tail0_s = split && fuse_bneck && fuse_shortcut && rs_debug().conv_deep && use_glds > 0 && bi == 0 && bott == 64 && cout == 256 && stride == 1 &&
+                           cur.C == 64 && findw(wn + ".conv3scp") != nullptr && find(wn + ".conv3scp.wsi") != nullptr && find(wn + ".conv3sc.b") != nullptr;
+      const bool tail_next = (tail || tail_s || tail0_s) && bi + 1 < S.res_blocks[si] &&
                              findw(bu + "res" + std::to_string(si + 2) + "." + std::to_string(bi + 1) + ".conv1p") != nullptr;
       if (have_t1) t1 = t1_pre;
       else if ((rc = new_act(&t1, nm + ".conv1", NB, ch / s1, cw / s1, bott, 1))) return rc;
-      if (!tail && !tail_s) { if ((rc = new_act(&t2, nm + ".conv2", NB, oh, ow, bott, 1))) return rc; }
+      if (!tail && !tail_s && !tail0_s) { if ((rc = new_act(&t2, nm + ".conv2", NB, oh, ow, bott, 1))) return rc; }
       if ((rc = new_act(&out, bi == S.res_blocks[si] - 1 ? "res" + std::to_string(si + 2) : nm + ".out", NB, oh, ow, cout, 1))) return rc;
       const Act* resid = &cur;
       // Projection shortcut: in the fp16 path it is folded into conv3 as a second K source (one GEMM over
       // [conv2 out ; block input], no shortcut tensor written or re-read); the fp32 validation path and
       // RS_FUSE_SHORTCUT=0 keep the reference's two-convolution form.
       const bool proj = cur.C != cout;
-      const bool fuse_sc = proj && !tail0 && !f32 && fuse_shortcut && s3 == 1 && cur.C % 64 == 0 && findw(wn + ".conv3sc") != nullptr;
-      if (proj && !fuse_sc && !tail0) {
+      const bool fuse_sc = proj && !tail0 && !tail0_s && !f32 && fuse_shortcut && s3 == 1 && cur.C % 64 == 0 && findw(wn + ".conv3sc") != nullptr;
+      if (proj && !fuse_sc && !tail0 && !tail0_s) {
         if ((rc = new_act(&sc, nm + ".shortcut", NB, oh, ow, cout, 1))) return rc;
         if ((rc = add_conv(nm + ".shortcut", wn + ".shortcut", cur, sc, 1, stride, 0, false, nullptr, nullptr, cur.C))) return rc;
         resid = &sc;
@@ -650,23 +653,26 @@ int rs_engine::build() {
         st.fn = [bp, mpi](int n, hipStream_t s) mutable { bp.M = n * mpi; g_last_conv_variant = 13; return launch_bneck_tail(bp, s); };
         stages.push_back(st);
         have_t1 = tail_next;
-      } else if (tail_s) {
+      } else if (tail_s || tail0_s) {
         const std::string nn = "res" + std::to_string(si + 2) + "." + std::to_string(bi + 1);
         if (tail_next) { if ((rc = new_act(&t1_pre, nn + ".conv1", NB, oh, ow, bott, 1))) return rc; }
         const BlobEntry *w2 = findw(wn + ".conv2"), *b2 = find(wn + ".conv2.b"), *s2 = find(wn + ".conv2.wsi");
-        const BlobEntry *w3 = findw(wn + ".conv3p"), *b3 = find(wn + ".conv3.b"), *sc3 = find(wn + ".conv3p.wsi");
+        const BlobEntry *w3 = findw(wn + (tail0_s ? ".conv3scp" : ".conv3p")), *b3 = find(wn + (tail0_s ? ".conv3sc.b" : ".conv3.b")),
+                        *sc3 = find(wn + (tail0_s ? ".conv3scp.wsi" : ".conv3p.wsi"));
         const BlobEntry *w1 = tail_next ? findw(bu + nn + ".conv1p") : nullptr, *b1 = tail_next ? find(bu + nn + ".conv1.b") : nullptr,
                         *sc1 = tail_next ? find(bu + nn + ".conv1p.wsi") : nullptr;
         RS_CHECK(w2 && b2 && s2 && w3 && b3 && sc3 && (!tail_next || (w1 && b1 && sc1)), RS_ERR_BLOB, "weights of the fused split tail of %s missing", nm.c_str());
-        RS_CHECK(wrows(w2) == bott && w2->dims[1] == 9 * bott && wrows(w3) == cout && w3->dims[1] == bott && (!w1 || (wrows(w1) == bott && w1->dims[1] == cout)),
+        const int k3 = tail0_s ? bott + 64 : bott;
+        RS_CHECK(wrows(w2) == bott && w2->dims[1] == 9 * bott && wrows(w3) == cout && w3->dims[1] == k3 && (!w1 || (wrows(w1) == bott && w1->dims[1] == cout)),
                  RS_ERR_BLOB, "fused split tail of %s: weight shapes", nm.c_str());
-        RS_CHECK(t1.pad == 1 && cur.pad == 1 && out.pad == 1 && t1.H == oh && cur.H == oh && t1.C == bott && cur.C == cout, RS_ERR_ARG, "fused split tail of %s: geometry", nm.c_str());
+        RS_CHECK(t1.pad == 1 && cur.pad == 1 && out.pad == 1 && t1.H == oh && cur.H == oh && t1.C == bott && cur.C == (tail0_s ? 64 : cout), RS_ERR_ARG, "fused split tail of %s: geometry", nm.c_str());
         BneckSplitParams bp;
         memset(&bp, 0, sizeof bp);
         bp.t1 = t1.p; bp.t1_lo = t1.lo;
         bp.w2 = (const half_t*)w2->dev; bp.w2_lo = (long long)bott * 9 * bott; bp.b2 = (const float*)b2->dev; bp.s2 = (const float*)s2->dev;
-        bp.w3p = (const half_t*)w3->dev; bp.w3_lo = (long long)cout * bott; bp.b3 = (const float*)b3->dev; bp.s3 = (const float*)sc3->dev;
-        bp.x = cur.p; bp.x_lo = cur.lo; bp.out = out.p; bp.out_lo = out.lo;
+        bp.w3p = (const half_t*)w3->dev; bp.w3_lo = (long long)cout * k3; bp.b3 = (const float*)b3->dev; bp.s3 = (const float*)sc3->dev;
+        if (tail0_s) { bp.x0 = cur.p; bp.x0_lo = cur.lo; } else { bp.x = cur.p; bp.x_lo = cur.lo; }
+        bp.out = out.p; bp.out_lo = out.lo;
         if (tail_next) {
           bp.w1p = (const half_t*)w1->dev; bp.w1_lo = (long long)bott * cout; bp.b1 = (const float*)b1->dev; bp.s1 = (const float*)sc1->dev;
           bp.t1n = t1_pre.p; bp.t1n_lo = t1_pre.lo;
@@ -675,8 +681,8 @@ int rs_engine::build() {
         const int mpi = oh * ow;
         Stage st;
         st.name = nm + (tail_next ? ".conv2+conv3+next.conv1" : ".conv2+conv3");
-        st.flops_per_image = 2.0 * mpi * (9.0 * bott * bott + (double)bott * cout + (tail_next ? (double)cout * bott : 0.0));
-        st.bytes_per_image = 4.0 * mpi * ((double)bott + cout + cout + (tail_next ? (double)bott : 0.0));       // two planes of t1 + x in, out (+ t1n) out
+        st.flops_per_image = 2.0 * mpi * (9.0 * bott * bott + (double)k3 * cout + (tail_next ? (double)cout * bott : 0.0));
+        st.bytes_per_image = 4.0 * mpi * ((double)bott + (tail0_s ? 64.0 : (double)cout) + cout + (tail_next ? (double)bott : 0.0));       // two planes of t1 + x (or x0) in, out (+ t1n) out
         st.fn = [bp, mpi](int n, hipStream_t s) mutable { bp.M = n * mpi; g_last_conv_variant = 23; return launch_bneck_tail_split(bp, s); };
         stages.push_back(st);
         have_t1 = tail_next;
@@ -1698,15 +1704,15 @@ int rs_op_bneck_tail(const void* t1, const void* w2, const float* b2, const void
 
 int rs_op_bneck_tail_split(const void* t1, int64_t t1_lo, const void* w2, const float* s2, const float* b2, const void* w3p, const float* s3, const float* b3,
                            const void* x, int64_t x_lo, void* out, int64_t out_lo, const void* w1p, const float* s1, const float* b1, void* t1n, int64_t t1n_lo,
-                           int n, int h, int w, int width, void* stream) {
-  RS_CHECK(t1 && w2 && s2 && b2 && w3p && s3 && b3 && x && out && n > 0 && h > 0 && w > 0, RS_ERR_ARG, "bad argument");
+                           const void* x0, int64_t x0_lo, int n, int h, int w, int width, void* stream) {
+  RS_CHECK(t1 && w2 && s2 && b2 && w3p && s3 && b3 && (x || x0) && out && n > 0 && h > 0 && w > 0, RS_ERR_ARG, "bad argument");
   RS_CHECK(width == 64 || width == 128, RS_ERR_UNSUPPORTED, "bneck_tail_split: bottleneck width %d (64 or 128)", width);
   BneckSplitParams p;
   memset(&p, 0, sizeof p);
   p.t1 = (const half_t*)t1; p.t1_lo = t1_lo;
   p.w2 = (const half_t*)w2; p.w2_lo = (long long)width * 9 * width; p.s2 = s2; p.b2 = b2;
-  p.w3p = (const half_t*)w3p; p.w3_lo = 4ll * width * width; p.s3 = s3; p.b3 = b3;
-  p.x = (const half_t*)x; p.x_lo = x_lo; p.out = (half_t*)out; p.out_lo = out_lo;
+  p.w3p = (const half_t*)w3p; p.w3_lo = 4ll * width * (width + (x0 ? 64 : 0)); p.s3 = s3; p.b3 = b3;
+  p.x = (const half_t*)x; p.x_lo = x_lo; p.x0 = (const half_t*)x0; p.x0_lo = x0_lo; p.out = (half_t*)out; p.out_lo = out_lo;
   p.w1p = (const half_t*)w1p; p.w1_lo = 4ll * width * width; p.s1 = s1; p.b1 = b1; p.t1n = (half_t*)t1n; p.t1n_lo = t1n_lo;
   p.M = n * h * w; p.H = h; p.W = w; p.Hp = h + 2; p.Wp = w + 2; p.CB = width / 64;
   return launch_bneck_tail_split(p, (hipStream_t)stream);

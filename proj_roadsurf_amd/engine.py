@@ -116,7 +116,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_op_conv2d_dual.argtypes = [vp, vp, vp, vp, vp] + [i32] * 19 + [vp]
     i64 = C.c_int64
     lib.rs_op_conv2d_split.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp, i64] + [i32] * 16 + [vp]
-    lib.rs_op_bneck_tail_split.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.rs_op_bneck_tail_split.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]
     lib.rs_op_conv2d_dgrad.argtypes = [vp] * 7 + [i32] * 14 + [vp]
     lib.rs_op_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i32] * 13 + [vp]
     lib.rs_op_nms.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp]

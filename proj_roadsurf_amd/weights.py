@@ -566,8 +566,14 @@ def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False
                 for bi in range(1, spec.res_blocks[si]):
                     blk = f"backbone.bottom_up.res{si + 2}.{bi}"
                     T[blk + ".conv3p.ws"], T[blk + ".conv3p.wsi"] = split_planes(_perm_k64(T32[blk + ".conv3.w"], width))
-                    if bi >= 2:
+                    if bi >= (1 if si == 0 else 2):
                         T[blk + ".conv1p.ws"], T[blk + ".conv1p.wsi"] = split_planes(_perm_k64(T32[blk + ".conv1.w"], 64))
+            # res2.0: conv3 (chained K order) and its projection shortcut from the 64-channel stem output (natural K order) as ONE operand
+            # [256][128] under one scale per row -- the projection form of the same kernel (bias: ".conv3sc.b")
+            blk = "backbone.bottom_up.res2.0"
+            if T32[blk + ".shortcut.w"].shape == (256, 64) and blk + ".conv3sc.b" in T:
+                T[blk + ".conv3scp.ws"], T[blk + ".conv3scp.wsi"] = split_planes(
+                    np.concatenate([_perm_k64(T32[blk + ".conv3.w"], 64), T32[blk + ".shortcut.w"]], 1))
     return serialize(T)
 
 

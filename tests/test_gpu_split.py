@@ -267,9 +267,11 @@ def test_split_activations_are_two_planes_and_the_lane_pipeline_equals_one_engin
 # registers on hi + lo fragments, against the same chain in float64 on the values the planes hold.  The chain stores nothing in between, so the
 # reference rounds nothing in between either; the kernel's intermediate hi + lo splits (22 bits) are part of what the bound covers.
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,hw,with_next,width", [(2, (20, 28), True, 64), (1, (17, 23), False, 64), (3, (8, 8), True, 64),
-                                                  (2, (18, 22), True, 128), (1, (25, 13), False, 128)])
-def test_split_bneck_tail_vs_float64(gpu_required, n, hw, with_next, width):
+@pytest.mark.parametrize("n,hw,with_next,width,proj", [(2, (20, 28), True, 64, False), (1, (17, 23), False, 64, False), (3, (8, 8), True, 64, False),
+                                                       (2, (18, 22), True, 128, False), (1, (25, 13), False, 128, False),
+                                                       (2, (19, 27), True, 64, True), (1, (33, 16), False, 64, True)])
+def test_split_bneck_tail_vs_float64(gpu_required, n, hw, with_next, width, proj):
+    """proj: the first block of res2 -- no identity residual; the shortcut's 1x1 from the 64-channel block input rides in conv3's GEMM as 64 more K columns"""
     from proj_roadsurf_amd.weights import _perm_k64
     lib = load_library()
     dev = torch.device("cuda:0")
@@ -278,7 +280,8 @@ def test_split_bneck_tail_vs_float64(gpu_required, n, hw, with_next, width):
     cb, c4 = width, 4 * width
     val = lambda pl: pl[0].double() + pl[1].double()
     t1p = _planes(_halo(torch.relu(torch.randn(n, h, w, cb)), 1))
-    xp = _planes(_halo(torch.relu(torch.randn(n, h, w, c4)), 1))
+    xp = _planes(_halo(torch.relu(torch.randn(n, h, w, 64 if proj else c4)), 1))
+    wsc = torch.randn(c4, 64, 1, 1) / 8.0
     w2 = torch.randn(cb, cb, 3, 3) / (3.0 * cb ** 0.5) * torch.exp2(torch.randint(-6, 7, (cb, 1, 1, 1)).float())     # rows of very different scale:
     w3 = torch.randn(c4, cb, 1, 1) / cb ** 0.5 * torch.exp2(torch.randint(-6, 7, (1, cb, 1, 1)).float()) / 8.0        # the per-row weight scale matters
     w1 = torch.randn(cb, c4, 1, 1) / c4 ** 0.5
@@ -288,6 +291,8 @@ def test_split_bneck_tail_vs_float64(gpu_required, n, hw, with_next, width):
         m = _ohwi(wt.numpy().astype(np.float32), kin, np.float32)
         if perm:
             m = _perm_k64(m, perm)
+        if proj and name == "w3":
+            m = np.concatenate([m, _ohwi(wsc.numpy().astype(np.float32), 64, np.float32)], 1)
         ws, wsi = split_planes(m)
         packs[name] = (torch.from_numpy(ws).to(dev), torch.from_numpy(wsi).to(dev))
         # the value the kernel multiplies with: (hi + lo) / scale, in the natural K order
@@ -296,12 +301,13 @@ def test_split_bneck_tail_vs_float64(gpu_required, n, hw, with_next, width):
         assert np.abs(eff - m).max() <= 2.0 ** -21 * np.abs(m).max(axis=1).max()
     t1v, xv = val(t1p)[:, 1:-1, 1:-1].permute(0, 3, 1, 2), val(xp)[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
     t2 = torch.relu(F.conv2d(t1v, w2.double(), b2.double(), padding=1))
-    pre3 = F.conv2d(t2, w3.double(), b3.double()) + xv
+    pre3 = F.conv2d(t2, w3.double(), b3.double()) + (F.conv2d(xv, wsc.double()) if proj else xv)
     out = torch.relu(pre3)
     t1n = torch.relu(F.conv2d(out, w1.double(), b1.double()))
     # scale of the rounding noise: conv3's terms, the residual and what conv2's noise contributes through |W3|
     s2 = F.conv2d(t1v ** 2, w2.double() ** 2, None, padding=1).sqrt() + b2.double().abs().view(1, -1, 1, 1)
-    s3 = F.conv2d(t2 ** 2, w3.double() ** 2).sqrt() + F.conv2d(s2 ** 2, w3.double() ** 2).sqrt() + xv.abs() + b3.double().abs().view(1, -1, 1, 1) + 1e-30
+    s3 = (F.conv2d(t2 ** 2, w3.double() ** 2).sqrt() + F.conv2d(s2 ** 2, w3.double() ** 2).sqrt() + b3.double().abs().view(1, -1, 1, 1) + 1e-30 +
+          (F.conv2d(xv ** 2, wsc.double() ** 2).sqrt() if proj else xv.abs()))
     s1 = F.conv2d(out ** 2, w1.double() ** 2).sqrt() + F.conv2d(s3 ** 2, w1.double() ** 2).sqrt() + b1.double().abs().view(1, -1, 1, 1) + 1e-30
     t1d, xd = t1p.to(dev), xp.to(dev)
     outd = torch.zeros((2, n, h + 2, w + 2, c4), dtype=torch.float16, device=dev)
@@ -310,9 +316,10 @@ def test_split_bneck_tail_vs_float64(gpu_required, n, hw, with_next, width):
     torch.cuda.synchronize()
     P = lambda t: C.c_void_p(t.data_ptr())
     rc = lib.rs_op_bneck_tail_split(P(t1d), t1d[0].numel(), P(packs["w2"][0]), P(packs["w2"][1]), P(b2d), P(packs["w3"][0]), P(packs["w3"][1]), P(b3d),
-                                    P(xd), xd[0].numel(), P(outd), outd[0].numel(),
+                                    None if proj else P(xd), xd[0].numel(), P(outd), outd[0].numel(),
                                     P(packs["w1"][0]) if with_next else None, P(packs["w1"][1]) if with_next else None, P(b1d) if with_next else None,
-                                    P(t1nd) if with_next else None, t1nd[0].numel() if with_next else 0, n, h, w, width, None)
+                                    P(t1nd) if with_next else None, t1nd[0].numel() if with_next else 0,
+                                    P(xd) if proj else None, xd[0].numel() if proj else 0, n, h, w, width, None)
     _check(lib, rc, "rs_op_bneck_tail_split")
     torch.cuda.synchronize()
     go = outd.cpu()
@@ -321,7 +328,7 @@ def test_split_bneck_tail_vs_float64(gpu_required, n, hw, with_next, width):
     hi = go[0][:, 1:-1, 1:-1]
     same = (hi == (go[0].float() + go[1].float())[:, 1:-1, 1:-1].half())[hi.abs() >= 2.0 ** -10]      # below, lo sits on the 2^-24 grid (see the two-plane test)
     assert float((~same).float().mean()) <= 5e-4, "hi plane is not fp16(value)"
-    assert _err(gv[:, 1:-1, 1:-1].permute(0, 3, 1, 2), out, s3) <= TOL(9 * cb) + TOL(cb)
+    assert _err(gv[:, 1:-1, 1:-1].permute(0, 3, 1, 2), out, s3) <= TOL(9 * cb) + TOL(cb + (64 if proj else 0))
     if with_next:
         gt = t1nd.cpu()
         tv = gt[0].double() + gt[1].double()

@@ -34,7 +34,7 @@ def main():
                 rc = lib.rs_op_bneck_tail_split(P(t1), t1[0].numel(), P(packs[0][0]), P(packs[0][1]), P(packs[0][2]), P(packs[1][0]), P(packs[1][1]), P(packs[1][2]),
                                                 P(x), x[0].numel(), P(out), out[0].numel(),
                                                 P(packs[2][0]) if with_next else None, P(packs[2][1]) if with_next else None, P(packs[2][2]) if with_next else None,
-                                                P(t1n) if with_next else None, t1n[0].numel() if with_next else 0, n, hw, hw, width, None)
+                                                P(t1n) if with_next else None, t1n[0].numel() if with_next else 0, None, 0, n, hw, hw, width, None)
                 _check(lib, rc, "rs_op_bneck_tail_split")
             for _ in range(3):
                 run()
