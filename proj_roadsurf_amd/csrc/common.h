@@ -181,6 +181,19 @@ struct StemPoolParams {
   int Hq, Wq;           // pooled size
 };
 int launch_stem_pool(const StemPoolParams& p, hipStream_t stream);
+// The same launch in the split-operand precision mode: input and pooled output as hi + lo planes, the weight fragments as [2 planes][7][4][64][8]
+// (hi plane first) of the row-scaled matrix with the inverse scales in wscale.
+struct StemPoolSplitParams {
+  const half_t* in; long long in_lo;
+  const half_t* wf;
+  const float* wscale;
+  const float* bias;
+  half_t* out; long long out_lo;
+  int N, in_Hp, in_Wp;
+  int Hc, Wc;
+  int Hq, Wq;
+};
+int launch_stem_pool_split(const StemPoolSplitParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------ fused bottleneck tail (bneck_fused.hip)
 // conv2 (3x3 64->64) + conv3 (1x1 64->256, + residual + ReLU) [+ the next block's conv1 (1x1 256->64)] of an identity-shortcut

@@ -558,6 +558,21 @@ int rs_engine::build() {
     st.bytes_per_image = 2.0 * ((double)pad_h * pad_w * 4 + (double)h4 * w4 * 64);
     st.fn = [sp](int n, hipStream_t s) mutable { sp.N = n; g_last_conv_variant = 21; return launch_stem_pool(sp, s); };
     stages.push_back(st);
+  } else if (fuse_stem && split && use_glds > 0 && S.stem_out_channels == 64 && x0.C == 4 && x0.pad == 3 && stem_w && stem_b && find(bu + "stem.conv1.wsi") &&
+             (long long)stem_w->dims[0] * stem_w->dims[1] == 2 * 7 * 4 * 64 * 8 && (pad_h & 3) == 0 && (pad_w & 3) == 0) {
+    // the same launch on hi + lo planes (stem_fused.hip stem_pool_split_kernel): bit-identical to the stand-alone split stem + split max-pool
+    StemPoolSplitParams sp;
+    memset(&sp, 0, sizeof sp);
+    sp.in = x0.p; sp.in_lo = x0.lo; sp.wf = (const half_t*)stem_w->dev; sp.wscale = (const float*)find(bu + "stem.conv1.wsi")->dev;
+    sp.bias = (const float*)stem_b->dev; sp.out = c1.p; sp.out_lo = c1.lo;
+    sp.in_Hp = x0.Hp(); sp.in_Wp = x0.Wp();
+    sp.Hc = h2; sp.Wc = w2; sp.Hq = h4; sp.Wq = w4;
+    Stage st;
+    st.name = "stem.conv1+maxpool";
+    st.flops_per_image = 2.0 * h2 * w2 * 49.0 * S.in_channels * 64;
+    st.bytes_per_image = 4.0 * ((double)pad_h * pad_w * 4 + (double)h4 * w4 * 64);
+    st.fn = [sp](int n, hipStream_t s) mutable { sp.N = n; g_last_conv_variant = 21; return launch_stem_pool_split(sp, s); };
+    stages.push_back(st);
   } else {
   if ((rc = add_conv("stem.conv1", bu + "stem.conv1", x0, stem, 7, 2, 3, true, nullptr, nullptr, S.in_channels))) return rc;
   {

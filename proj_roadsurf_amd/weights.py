@@ -548,6 +548,18 @@ def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False
         for k, v in T32.items():
             if k.endswith(".w") and k != "roi_heads.mask_head.predictor.w":
                 T[k + "s"], T[k + "si"] = split_planes(v)
+        # the stem matrix in MFMA A-fragment order for the fused stem (csrc/stem_fused.hip stem_pool_split_kernel): hi plane [7][4][64][8], then lo plane;
+        # the row scales are those of ".stem.conv1.wsi"
+        sn = "backbone.bottom_up.stem.conv1"
+        if sn + ".ws" in T and T[sn + ".ws"].shape == (128, 256):
+            lane = np.arange(64)
+            frag = np.empty((2, 7, 4, 64, 8), np.float16)
+            for pl in range(2):
+                m = T[sn + ".ws"][pl * 64:(pl + 1) * 64]
+                for kh in range(7):
+                    for mi in range(4):
+                        frag[pl, kh, mi] = m[(mi * 16 + (lane & 15))[:, None], (kh * 32 + (lane >> 4) * 8)[:, None] + np.arange(8)[None, :]]
+            T["backbone.bottom_up.stem.conv1f.ws"] = np.ascontiguousarray(frag.reshape(2 * 7 * 4 * 64, 8))
         # the RPN's 16 x 256 head with its K columns in the register-chaining order: it runs inside the epilogue of the RPN's 3x3 convolution
         hp = "proposal_generator.rpn_head."
         if T32[hp + "heads.w"].shape == (16, 256):

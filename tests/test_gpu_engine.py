@@ -591,12 +591,13 @@ def test_engine_launches_the_tabled_variants(gpu_required):
         eng.close()
 
 
-def test_fused_stem_changes_no_bit(gpu_required, monkeypatch):
+@pytest.mark.parametrize("precision", ["fp16", "split"])
+def test_fused_stem_changes_no_bit(gpu_required, monkeypatch, precision):
     """conv 7x7 s2 + ReLU + max-pool in one launch (csrc/stem_fused.hip: conv outputs of an 8x8 pooled patch kept in LDS) against the
     stand-alone stem conv followed by the pooling kernel (RS_FUSE_STEM=0): the pooled map and the detections are bit-identical -- same
-    MFMA K order, same fp16 rounding before the max.  3-band and 4-band tiles, up- and down-scaling, a non-square input."""
+    MFMA K order, same fp16 rounding before the max (split mode: the same three passes over K, the same (hi, lo) pair per value).  3-band and 4-band tiles, up- and down-scaling, a non-square input."""
     for shape, kw in (((512, 512, 3), {}), ((1024, 1024, 4), {}), ((300, 420, 3), dict(min_size_test=320, max_size_test=533))):
-        spec = EngineSpec(num_classes=2, **kw)
+        spec = EngineSpec(num_classes=2, precision=precision, **kw)
         if shape[2] == 4:
             spec = spec.replace(pixel_mean=(103.53, 116.28, 123.675, 110.0), pixel_std=(1.0, 1.0, 1.0, 1.0))
         W = synthetic_weights(spec, seed=0)
@@ -607,7 +608,7 @@ def test_fused_stem_changes_no_bit(gpu_required, monkeypatch):
             eng = Engine(spec, W, shape, max_batch=2)
             try:
                 dets = eng.infer(tiles)
-                outs.append((dets, eng.tensor("stem").copy(), list(eng.stage_variants())))
+                outs.append((dets, eng.tensor("stem").copy(), list(eng.stage_variants())))      # split mode: fp32(hi) + fp32(lo), exact and one-to-one
             finally:
                 eng.close()
         (d1, s1, n1), (d0, s0, n0) = outs
