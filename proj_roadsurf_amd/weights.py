@@ -531,6 +531,11 @@ def master_to_d2(spec: EngineSpec, base: Dict[str, np.ndarray], fetch) -> Dict[s
 
 
 def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False) -> bytes:
+    return serialize(packed_tensors(spec, W, train))
+
+
+def packed_tensors(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False) -> Dict[str, np.ndarray]:
+    """Every tensor of the blob ``pack_weights`` serialises, by name (the precision modes add theirs to the fp16 set)."""
     T = engine_tensors(spec, W)
     if train:
         T.update(train_tensors(spec, W))
@@ -586,7 +591,7 @@ def pack_weights(spec: EngineSpec, W: Dict[str, np.ndarray], train: bool = False
             if T32[blk + ".shortcut.w"].shape == (256, 64) and blk + ".conv3sc.b" in T:
                 T[blk + ".conv3scp.ws"], T[blk + ".conv3scp.wsi"] = split_planes(
                     np.concatenate([_perm_k64(T32[blk + ".conv3.w"], 64), T32[blk + ".shortcut.w"]], 1))
-    return serialize(T)
+    return T
 
 
 def split_planes(w32: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:

@@ -127,6 +127,48 @@ def test_pack_weights_blob_roundtrip_and_bn_fold():
     assert T["roi_heads.mask_head.deconv.w"].shape == (1024, 256)
 
 
+def test_split_mode_weight_planes():
+    """The split-operand mode's operands (weights.packed_tensors, precision "split"): hi + lo planes of the row-scaled fp32 weight carry it to 2^-21 of the
+    row maximum; the chained-order and fragment-order copies the fused kernels read (csrc/bneck_split.hip, stem_fused.hip) are permutations of the plain ones
+    under the SAME row scales."""
+    spec = EngineSpec(num_classes=2, precision="split")
+    W = Wt.synthetic_weights(spec, 0)
+    T = Wt.packed_tensors(spec, W)
+    T32 = Wt.engine_tensors(spec, W, w_dtype=np.float32)
+    n = 0
+    for k, w32 in T32.items():
+        if not k.endswith(".w") or k + "s" not in T:
+            continue
+        ws, wsi = T[k + "s"], T[k + "si"]
+        rows = w32.shape[0]
+        assert ws.dtype == np.float16 and ws.shape == (2 * rows, w32.shape[1]) and wsi.shape == (rows,)
+        assert np.all(np.exp2(np.round(np.log2(wsi))) == wsi), k                      # powers of two: the epilogue's multiply is exact
+        back = (ws[:rows].astype(np.float64) + ws[rows:].astype(np.float64)) * wsi[:, None].astype(np.float64)
+        bound = 2.0 ** -21 * np.abs(w32).max(axis=1, keepdims=True) + 1e-30
+        assert np.all(np.abs(back - w32) <= bound), k
+        hi_max = np.abs(ws[:rows].astype(np.float32)).max(axis=1)
+        assert np.all((hi_max == 0) | ((hi_max >= 2.0 ** 13) & (hi_max < 2.0 ** 14 + 8))), k      # the scale puts the row maximum in [2^13, 2^14)
+        n += 1
+    assert n >= 60
+    bu = "backbone.bottom_up."
+    # chained K order = a column permutation, row by row; the row scale does not see the order
+    for blk, group in ((bu + "res2.1", 64), (bu + "res2.2", 64), (bu + "res3.1", 128), (bu + "res3.3", 128)):
+        assert np.array_equal(T[blk + ".conv3p.ws"], Wt._perm_k64(T[blk + ".conv3.ws"], group))
+        assert np.array_equal(T[blk + ".conv3p.wsi"], T[blk + ".conv3.wsi"])
+    for blk in (bu + "res2.1", bu + "res2.2", bu + "res3.2", bu + "res3.3"):
+        assert np.array_equal(T[blk + ".conv1p.ws"], Wt._perm_k64(T[blk + ".conv1.ws"], 64))
+        assert np.array_equal(T[blk + ".conv1p.wsi"], T[blk + ".conv1.wsi"])
+    assert bu + "res3.1.conv1p.ws" not in T and bu + "res3.0.conv3p.ws" not in T          # res3.0 has no fused tail, so nothing chains into res3.1's conv1
+    # projection form of res2.0: [conv3 chained | shortcut natural] under the scales of the dual-source operand
+    sc, scp = T[bu + "res2.0.conv3sc.ws"], T[bu + "res2.0.conv3scp.ws"]
+    assert scp.shape == (512, 128) and np.array_equal(scp[:, 64:], sc[:, 64:]) and np.array_equal(scp[:, :64], Wt._perm_k64(sc[:, :64], 64))
+    assert np.array_equal(T[bu + "res2.0.conv3scp.wsi"], T[bu + "res2.0.conv3sc.wsi"])
+    # fused stem: fragment (plane, kh, block) = 64 lanes x 8 halfs, lane l = row block*16 + (l & 15), k = kh*32 + (l >> 4)*8 ..
+    sf, sw = T[bu + "stem.conv1f.ws"].reshape(2, 7, 4, 64, 8), T[bu + "stem.conv1.ws"]
+    for pl, kh, mi, lane in ((0, 0, 0, 0), (1, 6, 3, 63), (0, 3, 2, 37), (1, 2, 1, 20)):
+        assert np.array_equal(sf[pl, kh, mi, lane], sw[pl * 64 + mi * 16 + (lane & 15), kh * 32 + (lane >> 4) * 8: kh * 32 + (lane >> 4) * 8 + 8])
+
+
 def test_checkpoint_loader_pth_weights_only(tmp_path):
     import torch
     W = {"roi_heads.box_predictor.cls_score.weight": torch.zeros(3, 1024)}
