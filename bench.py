@@ -355,8 +355,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-stage table to stderr")
     ap.add_argument("--lanes", type=int, default=2,
-                    help="independent engine contexts (own stream + activation buffers); consecutive batches alternate lanes so "
-                         "one batch's latency-bound detection glue overlaps the next batch's convolutions")
+                    help="independent engine contexts (own stream + activation buffers); consecutive batches alternate lanes, the hardware interleaves "
+                         "the lanes' kernels (one lane's latency-bound glue and HBM-bound tile prologues / epilogues run beside the other's matrix work)")
+    ap.add_argument("--shared-stream", action="store_true",
+                    help="rounds 2-4 form of the lanes: convolutions of all lanes serialised on one stream, only the detection glue on side streams")
     ap.add_argument("--profile-mode", type=int, default=3,
                     help="HIP-event stage timing during the timed steps: 3 = every 4th step (default), 2 = every step, 0 = off")
     ap.add_argument("--no-fp32-mode", "--no-reference-precision", dest="no_ref", action="store_true",
@@ -427,7 +429,7 @@ def main():
     def measure(W, tiles, want_stage_events, precision=None):
         """headline-style measurement of one (weights, tiles) workload: K-step region on the lane pipeline + detections of batch 0"""
         L = max(1, args.lanes)
-        pipe = LanePipeline(spec.replace(precision=precision or args.precision), W, (T, T, C_in), max_batch=B, device=dev, lanes=L)
+        pipe = LanePipeline(spec.replace(precision=precision or args.precision), W, (T, T, C_in), max_batch=B, device=dev, lanes=L, shared_stream=args.shared_stream)
         try:
             engs = pipe.engines
             ptrs = [e.upload_tiles(tiles) for e in engs]
@@ -479,6 +481,20 @@ def main():
                 sustained = {"tiles_per_s": world * B * n_sus / dts, "steps": n_sus, "seconds": dts}
             for e in engs:
                 e.set_profiling(0)
+            # Per-kernel durations need launches that do not overlap: with independent lanes two kernels share the chip in the timed region and a
+            # launch's HIP-event duration there is its time on a shared chip.  So the same K steps run once more on ONE lane, stage events on its stream.
+            stages_serial = None
+            if want_stage_events and L > 1 and not pipe.shared:
+                e0 = engs[0]
+                for _ in range(2):
+                    e0.infer_device(ptrs[0], B)
+                e0.sync()
+                e0.set_profiling(2)
+                for _ in range(args.steps):
+                    e0.infer_device(ptrs[0], B)
+                e0.sync()
+                stages_serial = e0.stage_times()
+                e0.set_profiling(0)
             # PCIe-inclusive rate of the streaming host interface (pinned H2D of the tiles + forward + D2H of boxes/scores/packed
             # mask crops + host-side collection into Instances, LanePipeline.run); reported beside the headline, never as `value`
             nb = 8
@@ -492,8 +508,8 @@ def main():
             eng.infer_device(ptrs[0], B)
             dets = eng.fetch(B)
             nprop = eng.tensor("proposal_count", n=B)
-            return {"dt": dt, "stages": stages, "sustained": sustained, "pcie": pcie, "dets": dets, "nprop": float(np.mean(nprop)),
-                    "ndet": float(np.mean([len(d) for d in dets])), "lanes": L}
+            return {"dt": dt, "stages": stages, "stages_serial": stages_serial, "sustained": sustained, "pcie": pcie, "dets": dets, "nprop": float(np.mean(nprop)),
+                    "ndet": float(np.mean([len(d) for d in dets])), "lanes": L, "shared_stream": pipe.shared}
         finally:
             pipe.close()
 
@@ -610,25 +626,34 @@ def main():
         # the mask head's stages are sized for DETECTIONS_PER_IMAGE entries per tile but run on the detections there are (device-side row
         # count): their algorithmic FLOP / bytes count the rows that exist (all 100 on the saturated random-weight workload, ~8 on a trained one)
         mask_fill = min(1.0, float(H["ndet"]) / float(spec.detections_per_image)) if spec.detections_per_image else 1.0
-        stages = [dict(s, flops=s["flops"] * mask_fill, bytes=s["bytes"] * mask_fill) if s["name"].startswith("mask.") else s for s in stages]
+        def fill(st):
+            return [dict(s, flops=s["flops"] * mask_fill, bytes=s["bytes"] * mask_fill) if s["name"].startswith("mask.") else s for s in st]
+
+        def kernel_groups(st):
+            """group the GEMM stages by the kernel symbol (tile variant) they launched"""
+            gr = {}
+            for s in st:
+                if s["flops"] > 0 and s["calls"] > 0:
+                    g = gr.setdefault(s["kernel"] or "?", {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                    g["ms"] += s["ms_total"]
+                    g["flops"] += s["flops"] * s["calls"]
+                    g["bytes"] += s["bytes"] * s["calls"]
+                    g["launches"] += s["calls"]
+            return gr
+        stages_region = fill(stages)                       # stage events of the timed region (independent lanes: launches of the two lanes overlap)
+        serial = H.get("stages_serial") is not None
+        stages = fill(H["stages_serial"]) if serial else stages_region
         conv = [s for s in stages if s["flops"] > 0 and s["calls"] > 0]
         by_time = sorted(stages, key=lambda s: -s["ms_total"])
         tot_ms = sum(s["ms_total"] for s in stages)
-        # group the GEMM stages by the kernel symbol (tile variant) they launched; the dominant kernel is the
-        # one with the largest share of the step
-        groups = {}
-        for s in conv:
-            g = groups.setdefault(s["kernel"] or "?", {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-            g["ms"] += s["ms_total"]
-            g["flops"] += s["flops"] * s["calls"]
-            g["bytes"] += s["bytes"] * s["calls"]
-            g["launches"] += s["calls"]
+        groups = kernel_groups(stages)
         if not groups:                           # --profile-mode 0: no stage timing, no roofline
             groups = {"(stage timing off)": {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0}}
-        dom = max(groups, key=lambda k: groups[k]["ms"])
+        dom = max(groups, key=lambda k: groups[k]["ms"])        # the dominant kernel is the one with the largest share of the step
         G = groups[dom]
         achieved = G["flops"] / (G["ms"] * 1e-3) / 1e12 if G["ms"] > 0 else 0.0
         total_flops_step = sum(s["flops"] for s in conv)
+        GR = kernel_groups(stages_region).get(dom) if serial else None
         traffic, traffic_src = None, None
         # split-operand mode: three fp16 MFMA products per real product, so the roof of ALGORITHMIC FLOP/s is a third of the matrix peak
         split = args.precision == "split"
@@ -677,6 +702,13 @@ def main():
                     "algorithmic_bytes_per_launch_avg": G["bytes"] / max(G["launches"], 1), "launches": G["launches"],
                     "avg_launch_ms": G["ms"] / max(G["launches"], 1), "flops_per_launch_avg": G["flops"] / max(G["launches"], 1),
                     "share_of_step_time": G["ms"] / tot_ms if tot_ms else None,
+                    "measured_on": ("the same K steps on ONE lane right after the timed region, HIP events on its stream (launches do not overlap there): in the timed "
+                                    "region the lanes run on independent streams, two kernels share the chip and a launch's duration is not the kernel's own "
+                                    "-- those numbers are in `in_timed_region`" if serial else "HIP events around every launch of the timed region, on the stream it runs on"),
+                    "in_timed_region": ({"avg_launch_ms": GR["ms"] / max(GR["launches"], 1), "launches": GR["launches"],
+                                         "achieved_on_a_shared_chip": GR["flops"] / (GR["ms"] * 1e-3) / 1e12 if GR["ms"] else 0.0,
+                                         "sum_of_stage_ms_per_step": sum(s["ms_total"] / s["calls"] for s in stages_region if s["calls"]),
+                                         "note": "stage durations of the two lanes overlap: their sum exceeds ms_per_step"} if GR else None),
                     "whole_path_tflops": total_flops_step * args.steps * world / dt / 1e12,
                     "other_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0,
                                           "share_of_step_time": v["ms"] / tot_ms if tot_ms else None, "launches": v["launches"]}
@@ -699,7 +731,7 @@ def main():
             "precision_mode": args.precision, "data": "synthetic",
             "config": {"workload": f"Mask R-CNN R50-FPN inference, batch {B} of {T}x{T} {C_in}-band tiles per GPU "
                                    f"(BASELINE configs[{1 if C_in == 3 else 3}]), 800x800 network input; {wl}",
-                       "batch_per_gpu": B, "lanes": H["lanes"], "tile": [T, T, C_in], "num_classes": 2, "weights": args.weights,
+                       "batch_per_gpu": B, "lanes": H["lanes"], "lane_streams": "one shared stream" if H["shared_stream"] else "independent", "tile": [T, T, C_in], "num_classes": 2, "weights": args.weights,
                        "proposals_per_tile": H["nprop"], "detections_per_tile": H["ndet"],
                        "sharding": "tiles across ranks, no data-path collective"},
             "roofline": roofline,

@@ -601,27 +601,34 @@ class Engine:
 
 
 class LanePipeline:
-    """Two engines ("lanes") on one shared wide stream, fed alternately so that consecutive batches overlap:
-    the convolutions of both lanes stay serialised on the shared stream (two chip-filling kernels gain nothing
-    from running together), while each lane's latency-bound detection glue (RPN top-k/NMS/merge, box NMS/merge)
-    runs on its own side stream behind the other lane's convolutions.  Enqueue order for batch k on lane k mod 2:
+    """Several engines ("lanes") fed alternately so that consecutive batches overlap on one GPU.  The reference processes one tile at a time
+    and has no counterpart ([EXT d2: engine/defaults.py]).  Two forms:
 
-        phase0(k)   backbone, FPN, RPN heads  -> glue G1(k) on the side stream
-        phase2(k-1) mask head of the previous batch (hides G1(k))
-        phase1(k)   box head                  -> glue G2(k) on the side stream, hidden by phase0(k+1)
+    * independent lanes (default): every lane is a complete engine on its OWN stream and a batch is one ``infer_device`` on its lane; the
+      hardware interleaves the workgroups of the lanes' kernels.  On one stream every CU reaches the HBM-bound prologue / epilogue of a
+      ``conv_deep`` tile together and the matrix pipe idles meanwhile; kernels of two queues run out of phase, and one
+      lane's latency-bound detection glue runs beside the other's convolutions.  Measured against the phased form (``tools/ubench/two_pipes.py``,
+      one box): split mode 905 -> 954 tiles/s at batch 16, 821 -> 891 at batch 8; fp16 2 189 -> 2 241 and 1 796 -> 2 068.
+    * ``shared_stream=True`` (rounds 2-4): the lanes' convolutions serialised on ONE wide stream, each lane's glue on its own side stream
+      behind the other lane's convolutions.  Enqueue order for batch k on lane k mod 2:
 
-    Results of batch k are complete once phase2(k) has run, i.e. after ``submit`` of batch k+1 or ``flush``.
-    The reference processes one tile at a time and has no counterpart ([EXT d2: engine/defaults.py])."""
+          phase0(k)   backbone, FPN, RPN heads  -> glue G1(k) on the side stream
+          phase2(k-1) mask head of the previous batch (hides G1(k))
+          phase1(k)   box head                  -> glue G2(k) on the side stream, hidden by phase0(k+1)
+
+      Results of batch k are complete once phase2(k) has run, i.e. after ``submit`` of batch k+1 or ``flush``."""
 
     def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], max_batch: int = 16,
-                 device: int = 0, lanes: int = 2):
+                 device: int = 0, lanes: int = 2, shared_stream: bool = False):
         if lanes not in (1, 2, 3, 4):
             raise ValueError("lanes must be 1..4")
         blob = pack_weights(spec, weights)           # folding + fragment orders once, not once per lane (0.3 s of host time each)
+        self.shared = bool(shared_stream) and lanes > 1
         first = Engine(spec, weights, tile_shape, max_batch, device, blob=blob)
-        self.engines = [first] + [Engine(spec, weights, tile_shape, max_batch, device, stream=first.stream, blob=blob) for _ in range(lanes - 1)]
+        self.engines = [first] + [Engine(spec, weights, tile_shape, max_batch, device, stream=first.stream if self.shared else None, blob=blob)
+                                  for _ in range(lanes - 1)]
         self.k = 0
-        self._pending: Optional[Tuple[int, int, int]] = None     # (lane, tiles ptr, n) whose phase 2 is still to be enqueued
+        self._pending: Optional[Tuple[int, int, int]] = None     # shared form: (lane, tiles ptr, n) whose phase 2 is still to be enqueued
 
     def lane_of_next(self) -> Engine:
         return self.engines[self.k % len(self.engines)]
@@ -631,7 +638,7 @@ class LanePipeline:
         lane = self.k % len(self.engines)
         e = self.engines[lane]
         self.k += 1
-        if len(self.engines) == 1:
+        if not self.shared:
             e.infer_device(tiles_dev_ptr, n)
             return lane
         e.infer_phase(tiles_dev_ptr, n, 0)
@@ -652,8 +659,10 @@ class LanePipeline:
 
     def run(self, batches) -> "Iterator[List[Instances]]":
         """Stream host batches ((n,h,w,c) uint8 arrays) through the lanes and yield their detections in order.  Uploads go
-        through pinned staging on the wide stream, every batch's results come back on its lane's copy stream behind an event,
-        and the generator runs two batches ahead of what it yields, so host-side collection overlaps the GPU:
+        through pinned staging on the lane's stream, every batch's results come back on its lane's copy stream behind an event,
+        and the generator runs ``lanes`` batches ahead of what it yields, so host-side collection overlaps the GPU.  Independent lanes:
+            submit(k): upload(k), forward(k), fetch_async(k);   then collect + yield batch k - lanes
+        shared stream:
             submit(k): upload(k), phase0(k), phase2(k-1) + fetch_async(k-1), phase1(k);   then collect + yield batch k-2."""
         L = len(self.engines)
         inflight = []                               # (lane, n) of submitted batches not yet yielded
@@ -689,6 +698,21 @@ class LanePipeline:
             ptr = e.upload_async(np.ascontiguousarray(tiles))
             t1 = clock()
             T["upload"] += t1 - t0
+            if not self.shared:
+                e.infer_device(ptr, n)
+                T["enqueue"] += clock() - t1
+                res = None
+                if done is not None:                # the lane's previous results leave its pinned buffers BEFORE the next copy into them is enqueued
+                    t0 = clock()
+                    res = self.engines[done[0]].collect_results(done[1])
+                    T["collect"] += clock() - t0
+                t1 = clock()
+                e.fetch_async(n)
+                T["enqueue"] += clock() - t1
+                inflight.append((lane, n))
+                if res is not None:
+                    yield res
+                continue
             e.infer_phase(ptr, n, 0)
             if self._pending is not None:
                 pl, pp, pn = self._pending

@@ -255,23 +255,25 @@ def test_batch_independence_and_determinism(small):
     assert np.array_equal(single._packed, dets[1]._packed)
 
 
-def test_lane_pipeline_equals_single_engine(small):
-    """Phase-interleaved two-lane pipeline (rs_engine_infer_phase on a shared wide stream, glue on side streams):
-    five batches of different tiles through alternating lanes give bit-identical detections to the single engine."""
+@pytest.mark.parametrize("shared", [False, True])
+def test_lane_pipeline_equals_single_engine(small, shared):
+    """Two-lane pipeline, both forms -- independent lanes (each a whole engine on its own stream; the default) and the phase-interleaved form
+    (rs_engine_infer_phase on a shared wide stream, glue on side streams): five batches of different tiles through alternating lanes give
+    bit-identical detections to the single engine."""
     from proj_roadsurf_amd.engine import LanePipeline
     spec, W, tiles, eng, _ = small
     batches = [synthetic_tiles(3, 256, 256, 3, seed=500 + k) for k in range(5)]
     want = [eng.infer(b) for b in batches]
-    pipe = LanePipeline(spec, W, (256, 256, 3), max_batch=4, lanes=2)
+    pipe = LanePipeline(spec, W, (256, 256, 3), max_batch=4, lanes=2, shared_stream=shared)
     try:
-        assert pipe.engines[1].stream == pipe.engines[0].stream
+        assert (pipe.engines[1].stream == pipe.engines[0].stream) == shared
         got = [None] * len(batches)
         prev = None
         for k, b in enumerate(batches):
             lane = pipe.lane_of_next()
             lane_idx = pipe.submit(lane.upload_tiles(b), len(b))
             assert lane_idx == k % 2
-            if prev is not None:                       # batch k-1 is complete once batch k has been submitted
+            if prev is not None:                       # shared form: batch k-1 is complete once batch k has been submitted (fetch waits for the lane's own work)
                 got[prev[0]] = pipe.engines[prev[1]].fetch(3)
             prev = (k, lane_idx)
         pipe.flush()
@@ -286,15 +288,15 @@ def test_lane_pipeline_equals_single_engine(small):
 
 
 def test_lane_pipeline_streaming_host_interface(small):
-    """LanePipeline.run: host batches in, detections out, two batches of look-ahead, pinned staging + asynchronous result
+    """LanePipeline.run: host batches in, detections out, `lanes` batches of look-ahead, pinned staging + asynchronous result
     copies (rs_engine_upload_async / fetch_async / fetch_wait) -- same detections as the synchronous single engine, in order,
-    including a ragged last batch; also with a single lane."""
+    including a ragged last batch; independent lanes (two, three), the shared-stream form, and a single lane."""
     from proj_roadsurf_amd.engine import LanePipeline
     spec, W, tiles, eng, _ = small
     batches = [synthetic_tiles(3 if k != 6 else 2, 256, 256, 3, seed=900 + k) for k in range(7)]
     want = [eng.infer(b) for b in batches]
-    for lanes in (2, 1):
-        pipe = LanePipeline(spec, W, (256, 256, 3), max_batch=4, lanes=lanes)
+    for lanes, shared in ((2, False), (2, True), (3, False), (1, False)):
+        pipe = LanePipeline(spec, W, (256, 256, 3), max_batch=4, lanes=lanes, shared_stream=shared)
         try:
             got = list(pipe.run(iter(batches)))
             assert len(got) == len(want)
