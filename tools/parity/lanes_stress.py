@@ -44,7 +44,12 @@ def main():
                     same_as_want = all(np.array_equal(x._packed, y._packed) for x, y in zip(want[order[i - L]], again))
                     dev = e.tensor("masks", n=B)
                     dev_eq_want = all(np.array_equal(dev[t][: len(want[order[i - L]][t])], want[order[i - L]][t]._packed) for t in range(B))
-                    print(f"  refetch: equals first fetch {same_as_first}, equals solo {same_as_want}; device buffer via rs_engine_tensor equals solo {dev_eq_want}", flush=True)
+                    import time
+                    time.sleep(0.2)
+                    dev2 = e.tensor("masks", n=B)
+                    dev2_eq_want = all(np.array_equal(dev2[t][: len(want[order[i - L]][t])], want[order[i - L]][t]._packed) for t in range(B))
+                    print(f"  refetch: equals first fetch {same_as_first}, equals solo {same_as_want}; device buffer via rs_engine_tensor equals solo {dev_eq_want}; "
+                          f"0.2 s later {dev2_eq_want}", flush=True)
             e.infer_device(e.upload_tiles(batches[bi]), B)
         for i in range(L):
             e = pipe.engines[(2 * L - L + i) % L]
@@ -78,9 +83,9 @@ def main():
                     bad["probs_maxdiff"] = max(bad.get("probs_maxdiff", 0.0), float(np.abs(pa.astype(np.float64) - pb.astype(np.float64)).max()))
     for li, e in enumerate(pipe.engines):
         if "paste_dbg" in e.tensor_names():
-            print(f"  lane {li} paste_dbg [stale box, stale prob, stale slot, stale total, probes] =", e.tensor("paste_dbg")[:8].tolist(), flush=True)
+            print(f"  lane {li} paste_dbg [stale box, stale prob, stale slot, stale total, probes] =", e.tensor("paste_dbg")[:10].tolist(), flush=True)
     if "paste_dbg" in solo.tensor_names():
-        print("  solo paste_dbg =", solo.tensor("paste_dbg")[:8].tolist(), flush=True)
+        print("  solo paste_dbg =", solo.tensor("paste_dbg")[:10].tolist(), flush=True)
     print(f"{prec} lanes {L} tile {T}: {n} tile results, differing: {bad}, most differing mask bits in one tile {worst}", flush=True)
     pipe.close()
     solo.close()
