@@ -83,9 +83,9 @@ def main():
                     bad["probs_maxdiff"] = max(bad.get("probs_maxdiff", 0.0), float(np.abs(pa.astype(np.float64) - pb.astype(np.float64)).max()))
     for li, e in enumerate(pipe.engines):
         if "paste_dbg" in e.tensor_names():
-            print(f"  lane {li} paste_dbg [stale box, stale prob, stale slot, stale total, probes] =", e.tensor("paste_dbg")[:10].tolist(), flush=True)
+            print(f"  lane {li} paste_dbg [last generation whose successor ran, threads that ran after their successor] =", e.tensor("paste_dbg")[:2].tolist(), flush=True)
     if "paste_dbg" in solo.tensor_names():
-        print("  solo paste_dbg =", solo.tensor("paste_dbg")[:10].tolist(), flush=True)
+        print("  solo paste_dbg =", solo.tensor("paste_dbg")[:2].tolist(), flush=True)
     print(f"{prec} lanes {L} tile {T}: {n} tile results, differing: {bad}, most differing mask bits in one tile {worst}", flush=True)
     pipe.close()
     solo.close()
