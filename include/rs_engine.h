@@ -132,6 +132,8 @@ int rs_engine_fetch(rs_engine* e, int n, rs_dets* out_host);
  * (DefaultPredictor is synchronous, one image per call: [EXT d2: engine/defaults.py]). */
 int rs_engine_infer_phase(rs_engine* e, const uint8_t* tiles_dev, int n, int phase);
 int rs_engine_phase_count(void);
+/* Diagnostic (tools/parity/lanes_stress3.py): enqueue only the stages whose name contains `substr`, on the engine's stream, on the data of the last forward. */
+int rs_debug_run_stages_matching(rs_engine* e, const char* substr, int n);
 
 /* Asynchronous host interface (what a streaming caller -- make_detections.py over a tile list -- uses instead of rs_engine_infer):
  * pinned host memory, the upload enqueued on the engine's stream in front of the forward, and the results copied back on a

@@ -1379,6 +1379,18 @@ int rs_engine_infer_phase(rs_engine* e, const uint8_t* tiles_dev, int n, int pha
 }
 int rs_engine_phase_count(void) { return RS_NUM_PHASES; }
 
+// Diagnostic: enqueue, on the engine's wide stream, only the stages whose name contains `substr` (in list order, on the data the last forward left).
+int rs_debug_run_stages_matching(rs_engine* e, const char* substr, int n) {
+  RS_CHECK(e && substr && n >= 1 && n <= e->max_batch, RS_ERR_ARG, "bad argument");
+  RS_HIP(hipSetDevice(e->device));
+  for (Stage& st : e->stages)
+    if (st.name.find(substr) != std::string::npos) {
+      int rc = st.fn(n, e->stream);
+      if (rc) return rc;
+    }
+  return RS_OK;
+}
+
 int rs_engine_sync(rs_engine* e) {
   RS_CHECK(e, RS_ERR_ARG, "null engine");
   RS_HIP(hipStreamSynchronize(e->stream));

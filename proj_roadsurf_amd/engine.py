@@ -102,6 +102,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_engine_stream.argtypes = [vp]
     lib.rs_engine_stream.restype = vp
     lib.rs_engine_set_profiling.argtypes = [vp, i32]
+    lib.rs_debug_run_stages_matching.argtypes = [vp, C.c_char_p, i32]
     lib.rs_engine_stage_count.argtypes = [vp]
     lib.rs_engine_stage_info.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_double), i32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rs_engine_stage_kernel.argtypes = [vp, i32, C.c_char_p]
