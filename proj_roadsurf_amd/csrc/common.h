@@ -37,6 +37,27 @@ void rs_set_error(const char* fmt, ...);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// IEEE-correct fp32 a / b WITHOUT v_div_scale_f32 / v_div_fmas_f32 / v_div_fixup_f32.  The compiler's expansion of `/` returns wrong quotients in a wave whose
+// SIMD is shared with waves of ANOTHER kernel that issue MFMAs (found in round 4 with two engines on independent streams: the paste kernel's masks; reproduced
+// stand-alone by tools/ubench/coexec_probe.hip, where the same arithmetic with this function is bit-stable and bit-identical to the undisturbed `/`).  Same iteration as
+// the compiler's (reciprocal refined once, quotient refined twice with the exact remainder), without its exponent scaling -- exact for the O(1) magnitudes of box
+// coordinates, probabilities and losses; zero / infinite divisors and infinite / NaN dividends get IEEE's answer from the plain product with the hardware reciprocal.
+// Every fp32 division of device code that can run beside another stream's convolutions goes through it (detection glue, pre-processing, losses).
+#if defined(__HIPCC__)
+__device__ __forceinline__ float rs_fdiv(float a, float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, y0, 1.0f);
+  const float y = __builtin_fmaf(e, y0, y0);
+  const float q0 = a * y;
+  const float r0 = __builtin_fmaf(-b, q0, a);
+  const float q1 = __builtin_fmaf(r0, y, q0);
+  const float r1 = __builtin_fmaf(-b, q1, a);
+  const float q = __builtin_fmaf(r1, y, q1);
+  const bool special = !(__builtin_fabsf(b) > 0.f && __builtin_fabsf(b) < __builtin_inff() && __builtin_fabsf(a) < __builtin_inff());
+  return special ? a * y0 : q;
+}
+#endif
+
 // Debug / experiment switches.  Every RS_* environment variable the library understands is read in ONE place
 // (engine.hip: rs_debug_reload(), run by rs_engine_create / rs_trainer_create and on first use); production sets none
 // of them and the defaults below ARE the shipped configuration.  tools/ubench/* and a few tests flip them.

@@ -68,8 +68,8 @@ __device__ __forceinline__ void apply_deltas(const float b[4], const float d[4],
   const float heights = b[3] - b[1];
   const float ctr_x = b[0] + 0.5f * widths;
   const float ctr_y = b[1] + 0.5f * heights;
-  const float dx = d[0] / wx, dy = d[1] / wy;
-  float dw = d[2] / ww, dh = d[3] / wh;
+  const float dx = rs_fdiv(d[0], wx), dy = rs_fdiv(d[1], wy);
+  float dw = rs_fdiv(d[2], ww), dh = rs_fdiv(d[3], wh);
   dw = dw > scale_clamp ? scale_clamp : dw;
   dh = dh > scale_clamp ? scale_clamp : dh;
   const float pcx = dx * widths + ctr_x;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsParams p) {
         const float tu = thr * uni;
         if (inter > tu * 1.00001f) return true;
         if (!(inter > tu * 0.99999f)) return false;
-        return (inter / uni) > thr;
+        return rs_fdiv(inter, uni) > thr;
       };
       unsigned lo = 0u, hi = 0u;
       if (j0 > i && j0 + 64 <= n) {                 // word entirely right of the diagonal and inside n
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(1024) void rpn_merge_kernel(const RpnMergeParams p)
     if (i < total && i < p.cap) {
       const float* b = p.prop_boxes + ((long long)n * p.cap + i) * 4;
       const float area = (b[2] - b[0]) * (b[3] - b[1]);
-      const float v = sqrtf(area) / 224.0f + 1e-8f;
+      const float v = rs_fdiv(sqrtf(area), 224.0f) + 1e-8f;
       const unsigned lvl = v >= 2.0f ? 3u : (v >= 1.0f ? 2u : (v >= 0.5f ? 1u : 0u));
       unsigned yq = (unsigned)fmaxf(b[1], 0.f), xq = (unsigned)fmaxf(b[0], 0.f);
       yq = yq > 8191u ? 8191u : yq; xq = xq > 8191u ? 8191u : xq;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   // assign_boxes_to_levels: floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [2,5]; evaluated with
   // exact power-of-two thresholds instead of log2 (identical wherever log2 is exact at 2^k).
   const float area = (x2 - x1) * (y2 - y1);
-  const float v = sqrtf(area) / 224.0f + 1e-8f;
+  const float v = rs_fdiv(sqrtf(area), 224.0f) + 1e-8f;
   int lvl = v >= 2.0f ? 3 : (v >= 1.0f ? 2 : (v >= 0.5f ? 1 : 0));
   if (lvl > p.nlevels - 1) lvl = p.nlevels - 1;
   if (p.out_level) { if (tid == 0) p.out_level[entry] = lvl; }
@@ -523,10 +523,10 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   const float roi_end_h = y2 * sc - 0.5f;
   const float roi_w = roi_end_w - roi_start_w;
   const float roi_h = roi_end_h - roi_start_h;
-  const float bin_h = roi_h / (float)P;
-  const float bin_w = roi_w / (float)P;
-  int gh = (int)ceilf(roi_h / (float)P);
-  int gw = (int)ceilf(roi_w / (float)P);
+  const float bin_h = rs_fdiv(roi_h, (float)P);
+  const float bin_w = rs_fdiv(roi_w, (float)P);
+  int gh = (int)ceilf(rs_fdiv(roi_h, (float)P));
+  int gw = (int)ceilf(rs_fdiv(roi_w, (float)P));
   if (gh < 0) gh = 0;
   if (gw < 0) gw = 0;
   const float count = (float)((gh * gw) > 1 ? (gh * gw) : 1);
@@ -547,12 +547,12 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
   if (fast) {
     for (int t = tid; t < P * gh; t += 256) {
       const int ph = t / gh, iy = t - ph * gh;
-      const float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+      const float y = roi_start_h + (float)ph * bin_h + rs_fdiv(((float)iy + 0.5f) * bin_h, (float)gh);
       prep(y, H, (W + 2) * 256, s_lo[0][t], s_hi[0][t], s_l[0][t], s_h[0][t]);
     }
     for (int t = tid; t < P * gw; t += 256) {
       const int pw = t / gw, ix = t - pw * gw;
-      const float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+      const float x = roi_start_w + (float)pw * bin_w + rs_fdiv(((float)ix + 0.5f) * bin_w, (float)gw);
       prep(x, W, 256, s_lo[1][t], s_hi[1][t], s_l[1][t], s_h[1][t]);
     }
   }
@@ -569,14 +569,14 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
       int ylo, yhi; float ly, hy;
       if (fast) { const int t = ph * gh + iy; ylo = s_lo[0][t]; yhi = s_hi[0][t]; ly = s_l[0][t]; hy = s_h[0][t]; }
       else {
-        const float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+        const float y = roi_start_h + (float)ph * bin_h + rs_fdiv(((float)iy + 0.5f) * bin_h, (float)gh);
         prep(y, H, (W + 2) * 256, ylo, yhi, ly, hy);
       }
       for (int ix = 0; ix < gw; ++ix) {
         int xlo, xhi; float lx, hx;
         if (fast) { const int t = pw * gw + ix; xlo = s_lo[1][t]; xhi = s_hi[1][t]; lx = s_l[1][t]; hx = s_h[1][t]; }
         else {
-          const float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+          const float x = roi_start_w + (float)pw * bin_w + rs_fdiv(((float)ix + 0.5f) * bin_w, (float)gw);
           prep(x, W, 256, xlo, xhi, lx, hx);
         }
         const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
@@ -617,13 +617,13 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiAlignParams p) 
     if (live) {
       char* op = out + (((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + l32 * 8) * es;
       if (p.f32 == 1) {
-        ((f32x4*)op)[0] = f32x4{acc[0] / count, acc[1] / count, acc[2] / count, acc[3] / count};
-        ((f32x4*)op)[1] = f32x4{acc[4] / count, acc[5] / count, acc[6] / count, acc[7] / count};
+        ((f32x4*)op)[0] = f32x4{rs_fdiv(acc[0], count), rs_fdiv(acc[1], count), rs_fdiv(acc[2], count), rs_fdiv(acc[3], count)};
+        ((f32x4*)op)[1] = f32x4{rs_fdiv(acc[4], count), rs_fdiv(acc[5], count), rs_fdiv(acc[6], count), rs_fdiv(acc[7], count)};
       } else {
         half8 o, ol;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const float f = acc[c] / count;
+          const float f = rs_fdiv(acc[c], count);
           o[c] = (half_t)f;
           ol[c] = (half_t)(f - (float)o[c]);
         }
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256, SPLIT ? 4 : 6) void roi_align_win_kernel(const
   const float* r = p.rois + (long long)slot * 4;
   const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
   const float area = (x2 - x1) * (y2 - y1);
-  const float v = sqrtf(area) / 224.0f + 1e-8f;
+  const float v = rs_fdiv(sqrtf(area), 224.0f) + 1e-8f;
   int lvl = v >= 2.0f ? 3 : (v >= 1.0f ? 2 : (v >= 0.5f ? 1 : 0));
   if (lvl > p.nlevels - 1) lvl = p.nlevels - 1;
   if (p.out_level) { if (tid == 0) p.out_level[entry] = lvl; }
@@ -706,10 +706,10 @@ __global__ __launch_bounds__(256, SPLIT ? 4 : 6) void roi_align_win_kernel(const
   const float roi_start_h = y1 * sc - 0.5f;
   const float roi_w = (x2 * sc - 0.5f) - roi_start_w;
   const float roi_h = (y2 * sc - 0.5f) - roi_start_h;
-  const float bin_h = roi_h / (float)P;
-  const float bin_w = roi_w / (float)P;
-  int gh = (int)ceilf(roi_h / (float)P);
-  int gw = (int)ceilf(roi_w / (float)P);
+  const float bin_h = rs_fdiv(roi_h, (float)P);
+  const float bin_w = rs_fdiv(roi_w, (float)P);
+  int gh = (int)ceilf(rs_fdiv(roi_h, (float)P));
+  int gw = (int)ceilf(rs_fdiv(roi_w, (float)P));
   if (gh < 0) gh = 0;
   if (gw < 0) gw = 0;
   const float count = (float)((gh * gw) > 1 ? (gh * gw) : 1);
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256, SPLIT ? 4 : 6) void roi_align_win_kernel(const
     int base = 0, len = 0;
     bool have = false, overflow = false;
     for (int i = 0; i < g; ++i) {
-      float c = start + (float)b * bin + ((float)i + 0.5f) * bin / (float)g;
+      float c = start + (float)b * bin + rs_fdiv(((float)i + 0.5f) * bin, (float)g);
       if (c < -1.0f || c > (float)size) continue;          // torchvision: sample contributes 0
       if (c <= 0.f) c = 0.f;
       int lo = (int)c, hi;
@@ -781,14 +781,14 @@ __global__ __launch_bounds__(256, SPLIT ? 4 : 6) void roi_align_win_kernel(const
     } else {
       // window larger than the table (very elongated RoI): per-sample evaluation, torchvision's order
       for (int iy = 0; iy < gh; ++iy) {
-        float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+        float y = roi_start_h + (float)ph * bin_h + rs_fdiv(((float)iy + 0.5f) * bin_h, (float)gh);
         if (y < -1.0f || y > (float)H) continue;
         if (y <= 0.f) y = 0.f;
         int ylo = (int)y, yhi;
         if (ylo >= H - 1) { yhi = ylo = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
         const float ly = y - (float)ylo, hy = 1.f - ly;
         for (int ix = 0; ix < gw; ++ix) {
-          float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+          float x = roi_start_w + (float)pw * bin_w + rs_fdiv(((float)ix + 0.5f) * bin_w, (float)gw);
           if (x < -1.0f || x > (float)W) continue;
           if (x <= 0.f) x = 0.f;
           int xlo = (int)x, xhi;
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, SPLIT ? 4 : 6) void roi_align_win_kernel(const
     half8 o, ol;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const float f = acc[c] / count;
+      const float f = rs_fdiv(acc[c], count);
       o[c] = (half_t)f;
       if constexpr (SPLIT) ol[c] = (half_t)(f - (float)o[c]);
     }
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
   const float* r = p.rois + (long long)slot * 4;
   const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
   const float area = (x2 - x1) * (y2 - y1);
-  const float v = sqrtf(area) / 224.0f + 1e-8f;
+  const float v = rs_fdiv(sqrtf(area), 224.0f) + 1e-8f;
   int lvl = v >= 2.0f ? 3 : (v >= 1.0f ? 2 : (v >= 0.5f ? 1 : 0));
   if (lvl > p.nlevels - 1) lvl = p.nlevels - 1;
   const int H = p.H[lvl], W = p.W[lvl];
@@ -858,10 +858,10 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
   const float roi_start_h = y1 * sc - 0.5f;
   const float roi_w = (x2 * sc - 0.5f) - roi_start_w;
   const float roi_h = (y2 * sc - 0.5f) - roi_start_h;
-  const float bin_h = roi_h / (float)P;
-  const float bin_w = roi_w / (float)P;
-  int gh = (int)ceilf(roi_h / (float)P);
-  int gw = (int)ceilf(roi_w / (float)P);
+  const float bin_h = rs_fdiv(roi_h, (float)P);
+  const float bin_w = rs_fdiv(roi_w, (float)P);
+  int gh = (int)ceilf(rs_fdiv(roi_h, (float)P));
+  int gw = (int)ceilf(rs_fdiv(roi_w, (float)P));
   if (gh < 0) gh = 0;
   if (gw < 0) gw = 0;
   const float count = (float)((gh * gw) > 1 ? (gh * gw) : 1);
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
     int base = 0, len = 0;
     bool have = false, overflow = false;
     for (int i = 0; i < g; ++i) {
-      float c = start + (float)b * bin + ((float)i + 0.5f) * bin / (float)g;
+      float c = start + (float)b * bin + rs_fdiv(((float)i + 0.5f) * bin, (float)g);
       if (c < -1.0f || c > (float)size) continue;
       if (c <= 0.f) c = 0.f;
       int lo = (int)c, hi;
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
           if (wgt == 0.f) continue;
           const G* gp = gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + ln;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] += wgt * ((float)gp[c * 64] / count);
+          for (int c = 0; c < 4; ++c) acc[c] += wgt * rs_fdiv((float)gp[c * 64], count);
         }
       }
       float* d = dfl + ((long long)(oy + ty) * (W + 2) + ox + tx) * 256;
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
     const G* gp = gout + ((long long)(ph + p.out_pad) * PP + pw + p.out_pad) * 256 + ln;
     float gsc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) gsc[c] = (float)gp[c * 64] / count;
+    for (int c = 0; c < 4; ++c) gsc[c] = rs_fdiv((float)gp[c * 64], count);
     const int ny = s_len[0][ph], nx = s_len[1][pw];
     if (ny >= 0 && nx >= 0) {
       float* f0 = dfl + ((long long)s_base[0][ph] * (W + 2) + s_base[1][pw]) * 256;
@@ -989,14 +989,14 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiAlignParams
       }
     } else {
       for (int iy = 0; iy < gh; ++iy) {
-        float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+        float y = roi_start_h + (float)ph * bin_h + rs_fdiv(((float)iy + 0.5f) * bin_h, (float)gh);
         if (y < -1.0f || y > (float)H) continue;
         if (y <= 0.f) y = 0.f;
         int ylo = (int)y, yhi;
         if (ylo >= H - 1) { yhi = ylo = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
         const float ly = y - (float)ylo, hy = 1.f - ly;
         for (int ix = 0; ix < gw; ++ix) {
-          float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+          float x = roi_start_w + (float)pw * bin_w + rs_fdiv(((float)ix + 0.5f) * bin_w, (float)gw);
           if (x < -1.0f || x > (float)W) continue;
           if (x <= 0.f) x = 0.f;
           int xlo = (int)x, xhi;
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(64) void roi_bwd_prep_kernel(const RoiAlignParams p
   const float* r = p.rois + (long long)slot * 4;
   const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
   const float area = (x2 - x1) * (y2 - y1);
-  const float v = sqrtf(area) / 224.0f + 1e-8f;
+  const float v = rs_fdiv(sqrtf(area), 224.0f) + 1e-8f;
   int lvl = v >= 2.0f ? 3 : (v >= 1.0f ? 2 : (v >= 0.5f ? 1 : 0));
   if (lvl > p.nlevels - 1) lvl = p.nlevels - 1;
   const int H = p.H[lvl], W = p.W[lvl];
@@ -1067,10 +1067,10 @@ __global__ __launch_bounds__(64) void roi_bwd_prep_kernel(const RoiAlignParams p
   const float roi_start_h = y1 * sc - 0.5f;
   const float roi_w = (x2 * sc - 0.5f) - roi_start_w;
   const float roi_h = (y2 * sc - 0.5f) - roi_start_h;
-  const float bin_h = roi_h / (float)P;
-  const float bin_w = roi_w / (float)P;
-  int gh = (int)ceilf(roi_h / (float)P);
-  int gw = (int)ceilf(roi_w / (float)P);
+  const float bin_h = rs_fdiv(roi_h, (float)P);
+  const float bin_w = rs_fdiv(roi_w, (float)P);
+  int gh = (int)ceilf(rs_fdiv(roi_h, (float)P));
+  int gw = (int)ceilf(rs_fdiv(roi_w, (float)P));
   if (gh < 0) gh = 0;
   if (gw < 0) gw = 0;
   const float count = (float)((gh * gw) > 1 ? (gh * gw) : 1);
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(64) void roi_bwd_prep_kernel(const RoiAlignParams p
     int base = 0, len = 0;
     bool have = false, overflow = false;
     for (int i = 0; i < g; ++i) {
-      float c = start + (float)b * bin + ((float)i + 0.5f) * bin / (float)g;
+      float c = start + (float)b * bin + rs_fdiv(((float)i + 0.5f) * bin, (float)g);
       if (c < -1.0f || c > (float)size) continue;
       if (c <= 0.f) c = 0.f;
       int lo = (int)c, hi;
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(const RoiAlignParam
     const int* src = &T->base[0][0];
 #pragma unroll
     for (int i = 0; i < TW; ++i) { const int o = tid + i * 256; treg[i] = o < RS_ROI_BWD_TABW ? src[o] : 0; }
-    tinv = 1.0f / T->count;
+    tinv = rs_fdiv(1.0f, T->count);
   };
   auto commit = [&](int k) {
 #pragma unroll
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(1024) void box_candidates_kernel(const BoxCandParam
     for (int c = 1; c <= K; ++c) mx = fmaxf(mx, pr[c]);
     float sum = 0.f;
     for (int c = 0; c <= K; ++c) sum += expf(pr[c] - mx);
-    score = expf(pr[k] - mx) / sum;
+    score = rs_fdiv(expf(pr[k] - mx), sum);
     const float* pb = p.prop_boxes + ((long long)n * p.cap + tid) * 4;
     float b[4] = {pb[0], pb[1], pb[2], pb[3]};
     const float* dp = pr + (K + 1) + k * 4;
@@ -1448,7 +1448,7 @@ __global__ __launch_bounds__(256) void mask_predict_kernel(const MaskPredictPara
   s += __shfl_xor(s, 1, 16);
   if (sub == 0) {
     const float logit = s + p.b[cls];
-    const float prob = 1.f / (1.f + expf(-logit));
+    const float prob = rs_fdiv(1.f, 1.f + expf(-logit));
     p.out[(long long)slot * SS + (pix - (long long)entry * SS)] = prob;
   }
 }
@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(256) void mask_sigmoid_kernel(const MaskPredictPara
   const int slot = p.slot_list[entry];
   float* o = p.out + (long long)slot * SS + (gid - (long long)entry * SS);
   const float logit = *o + p.b[p.det_classes[slot]];
-  *o = 1.f / (1.f + expf(-logit));
+  *o = rs_fdiv(1.f, 1.f + expf(-logit));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1487,20 +1487,20 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
   const int S = p.S;
   unsigned int word = 0;
   // img_y = (y + 0.5 - y0) / (y1 - y0) * 2 - 1 ; iy = ((img_y + 1) * S - 1) / 2
-  const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.f - 1.f;
-  const float iy = ((gy + 1.f) * (float)S - 1.f) / 2.f;
+  const float gy = rs_fdiv((float)y + 0.5f - y0, y1 - y0) * 2.f - 1.f;
+  const float iy = ((gy + 1.f) * (float)S - 1.f) * 0.5f;
   const float fy = floorf(iy);
   const int iy0 = (int)fy, iy1 = iy0 + 1;
   const float wy1 = iy - fy, wy0 = 1.f - wy1;
   // conservative column range that can sample inside the SxS map (one mask texel of margin on both sides)
-  const float margin = fabsf(x1 - x0) / (float)S + 1.f;
+  const float margin = rs_fdiv(fabsf(x1 - x0), (float)S) + 1.f;
   const int xa = xw * 32, xz = xa + 31;
   if (iy1 >= 0 && iy0 < S && (float)xz + 0.5f >= fminf(x0, x1) - margin && (float)xa + 0.5f <= fmaxf(x0, x1) + margin) {
     for (int b = 0; b < 32; ++b) {
       const int x = xa + b;
       if (x >= p.out_w) break;
-      const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
-      const float ix = ((gx + 1.f) * (float)S - 1.f) / 2.f;
+      const float gx = rs_fdiv((float)x + 0.5f - x0, x1 - x0) * 2.f - 1.f;
+      const float ix = ((gx + 1.f) * (float)S - 1.f) * 0.5f;
       const float fx = floorf(ix);
       const int ix0 = (int)fx, ix1 = ix0 + 1;
       if (ix1 < 0 || ix0 >= S) continue;

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) 
 #pragma unroll
       for (int q = 0; q < 4; ++q) if (q == cs) v = p.need_v ? (vacc[q] >> 22) : val[q];
       if (p.need_v) v = v < 0 ? 0 : (v > 255 ? 255 : v);
-      const float f = ((float)v - p.mean[c]) / p.stdv[c];
+      const float f = rs_fdiv((float)v - p.mean[c], p.stdv[c]);
       o[c] = (half_t)f;
       of[c] = f;
     }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreprocParam
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (q == cs) v = NV ? (vacc[q] >> 22) : val[q];
         if (NV) v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        const float f = ((float)v - p.mean[c]) / p.stdv[c];
+        const float f = rs_fdiv((float)v - p.mean[c], p.stdv[c]);
         o[c] = (half_t)f;
         of[c] = f;
       }

@@ -26,7 +26,7 @@ __device__ __forceinline__ float bce_with_logits(float x, float t) {
   // torch: max(x,0) - x*t + log1p(exp(-|x|))
   return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
 }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return rs_fdiv(1.f, 1.f + expf(-x)); }
 __device__ __forceinline__ float sgnf(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
 
 __device__ __forceinline__ void get_deltas(const float s[4], const float t[4], float wx, float wy, float ww, float wh, float out[4]) {
@@ -34,10 +34,10 @@ __device__ __forceinline__ void get_deltas(const float s[4], const float t[4], f
   const float scx = s[0] + 0.5f * sw, scy = s[1] + 0.5f * sh;
   const float tw = t[2] - t[0], th = t[3] - t[1];
   const float tcx = t[0] + 0.5f * tw, tcy = t[1] + 0.5f * th;
-  out[0] = wx * (tcx - scx) / sw;
-  out[1] = wy * (tcy - scy) / sh;
-  out[2] = ww * logf(tw / sw);
-  out[3] = wh * logf(th / sh);
+  out[0] = rs_fdiv(wx * (tcx - scx), sw);
+  out[1] = rs_fdiv(wy * (tcy - scy), sh);
+  out[2] = ww * logf(rs_fdiv(tw, sw));
+  out[3] = wh * logf(rs_fdiv(th, sh));
 }
 
 __device__ __forceinline__ void block_sum_to(float v, float* dst) {
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
     float gl = 0.f, gd[4] = {0.f, 0.f, 0.f, 0.f};
     if (label >= 0) {
       const float x = p.head[row + a], t = (float)label;
-      lc = bce_with_logits(x, t) / p.normalizer;
-      gl = (sigmoidf(x) - t) / p.normalizer;
+      lc = rs_fdiv(bce_with_logits(x, t), p.normalizer);
+      gl = rs_fdiv(sigmoidf(x) - t, p.normalizer);
       if (label == 1) {
         const float* an = p.anchors + ((long long)p.level_off + i) * 4;
         const long long ai = (long long)n * p.total_anchors + p.level_off + i;
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
         get_deltas(s, t4, 1.f, 1.f, 1.f, 1.f, tgt);
         for (int d = 0; d < 4; ++d) {
           const float diff = p.head[row + p.A + a * 4 + d] - tgt[d];
-          ll += fabsf(diff) / p.normalizer;
-          gd[d] = sgnf(diff) / p.normalizer;
+          ll += rs_fdiv(fabsf(diff), p.normalizer);
+          gd[d] = rs_fdiv(sgnf(diff), p.normalizer);
         }
       }
     }
@@ -109,10 +109,10 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
       float sum = 0.f;
       for (int c = 0; c <= K; ++c) sum += expf(pr[c] - mx);
       const float lse = mx + logf(sum);
-      lc = (lse - pr[cls]) / n_valid;
+      lc = rs_fdiv(lse - pr[cls], n_valid);
       for (int c = 0; c <= K; ++c) {
         const float sm = expf(pr[c] - lse);
-        g[c] = (G)((sm - (c == cls ? 1.f : 0.f)) / n_valid * p.loss_scale);
+        g[c] = (G)(rs_fdiv(sm - (c == cls ? 1.f : 0.f), n_valid) * p.loss_scale);
       }
       if (cls < K) {
         const float* pb = p.proposals + (long long)r * 4;
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const BoxLossParams p) {
         get_deltas(s, t4, p.wx, p.wy, p.ww, p.wh, tgt);
         for (int d = 0; d < 4; ++d) {
           const float diff = pr[K + 1 + cls * 4 + d] - tgt[d];
-          ll += fabsf(diff) / n_valid;
-          g[K + 1 + cls * 4 + d] = (G)(sgnf(diff) / n_valid * p.loss_scale);
+          ll += rs_fdiv(fabsf(diff), n_valid);
+          g[K + 1 + cls * 4 + d] = (G)(rs_fdiv(sgnf(diff), n_valid) * p.loss_scale);
         }
       }
     }
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const MaskLossParams p) 
     if (cls >= 0 && cls < p.cs) {
       const float x = p.logits[i * p.cs + cls], t = (float)p.targets[i];
       const float norm = (float)n_masks * (float)per;
-      l = bce_with_logits(x, t) / norm;
-      g[cls] = (G)((sigmoidf(x) - t) / norm * p.loss_scale);
+      l = rs_fdiv(bce_with_logits(x, t), norm);
+      g[cls] = (G)(rs_fdiv(sigmoidf(x) - t, norm) * p.loss_scale);
     }
   }
   block_sum_to(l, p.loss_out);
@@ -259,7 +259,7 @@ __device__ __forceinline__ float iou_d2(const float a[4], float area_a, const fl
   const float w = fminf(a[2], b[2]) - fmaxf(a[0], b[0]);
   const float h = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
   const float inter = fmaxf(w, 0.f) * fmaxf(h, 0.f);
-  return inter > 0.f ? inter / (area_a + area_b - inter) : 0.f;
+  return inter > 0.f ? rs_fdiv(inter, area_a + area_b - inter) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void match_kernel(const MatchParams p) {
