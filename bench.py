@@ -355,11 +355,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-stage table to stderr")
     ap.add_argument("--lanes", type=int, default=2,
-                    help="independent engine contexts (own activation buffers); consecutive batches alternate lanes so "
-                         "one batch's latency-bound detection glue overlaps the next batch's convolutions")
-    ap.add_argument("--independent-lanes", action="store_true",
-                    help="EXPERIMENTAL: every lane on its own stream instead of the shared wide stream (faster, but a few 64-byte pieces of the mask output "
-                         "were seen to keep the previous batch's content: LanePipeline docstring); the line is labelled and roofline comes from a one-lane pass")
+                    help="independent engine contexts (own stream + activation buffers); consecutive batches alternate lanes, the hardware interleaves "
+                         "the lanes' kernels (one lane's latency-bound glue and HBM-bound tile prologues / epilogues run beside the other's matrix work)")
+    ap.add_argument("--shared-stream", action="store_true",
+                    help="rounds 2-4 form of the lanes: convolutions of all lanes serialised on one stream, only the detection glue on side streams")
     ap.add_argument("--profile-mode", type=int, default=3,
                     help="HIP-event stage timing during the timed steps: 3 = every 4th step (default), 2 = every step, 0 = off")
     ap.add_argument("--no-fp32-mode", "--no-reference-precision", dest="no_ref", action="store_true",
@@ -430,7 +429,7 @@ def main():
     def measure(W, tiles, want_stage_events, precision=None):
         """headline-style measurement of one (weights, tiles) workload: K-step region on the lane pipeline + detections of batch 0"""
         L = max(1, args.lanes)
-        pipe = LanePipeline(spec.replace(precision=precision or args.precision), W, (T, T, C_in), max_batch=B, device=dev, lanes=L, shared_stream=not args.independent_lanes)
+        pipe = LanePipeline(spec.replace(precision=precision or args.precision), W, (T, T, C_in), max_batch=B, device=dev, lanes=L, shared_stream=args.shared_stream)
         try:
             engs = pipe.engines
             ptrs = [e.upload_tiles(tiles) for e in engs]

@@ -605,22 +605,24 @@ class LanePipeline:
     """Several engines ("lanes") fed alternately so that consecutive batches overlap on one GPU.  The reference processes one tile at a time
     and has no counterpart ([EXT d2: engine/defaults.py]).  Two forms:
 
-    * ``shared_stream=True`` (default): the lanes' convolutions serialised on ONE wide stream, each lane's latency-bound detection glue (RPN
-      top-k / NMS / merge, box NMS / merge) on its own side stream behind the other lane's convolutions.  Enqueue order for batch k on lane k mod 2:
+    * independent lanes (default since the end of round 4): every lane is a complete engine on its OWN stream and a batch is one ``infer_device``
+      on its lane; the hardware interleaves the workgroups of the lanes' kernels.  On one stream every CU reaches the HBM-bound prologue / epilogue of
+      a ``conv_deep`` tile together and the matrix pipe idles meanwhile; kernels of two queues run out of phase, and one lane's
+      latency-bound detection glue runs beside the other's convolutions.  Against the phased form (``tools/ubench/two_pipes.py``, one box): split mode
+      905 -> 954 tiles/s at batch 16, 821 -> 891 at batch 8; fp16 2 189 -> 2 241 and 1 796 -> 2 068.  Bit-identical to a single engine -- once the
+      device code stopped using the compiler's fp32 division sequence, which returns wrong quotients beside another kernel's MFMA waves
+      (csrc/common.h ``rs_fdiv``; ``tools/parity/lanes_stress.py``: 8 400 tile results, none differing).
+    * ``shared_stream=True`` (rounds 2-4): the lanes' convolutions serialised on ONE wide stream, each lane's glue on its own side stream
+      behind the other lane's convolutions.  Enqueue order for batch k on lane k mod 2:
 
           phase0(k)   backbone, FPN, RPN heads  -> glue G1(k) on the side stream
           phase2(k-1) mask head of the previous batch (hides G1(k))
           phase1(k)   box head                  -> glue G2(k) on the side stream, hidden by phase0(k+1)
 
-      Results of batch k are complete once phase2(k) has run, i.e. after ``submit`` of batch k+1 or ``flush``.
-    * ``shared_stream=False`` (EXPERIMENTAL, opt-in): every lane a complete engine on its OWN stream, a batch one ``infer_device`` on its lane; the
-      hardware interleaves the lanes' kernels.  5 % (split, batch 16) to 15 % (fp16, batch 8) faster (``tools/ubench/two_pipes.py``), but NOT
-      bit-reproducible on the MI355X boxes of this pool: in about 1 of 500 tile results one or a few 64-byte pieces of the packed mask canvas keep
-      the previous batch's content (boxes, scores, classes and mask probabilities were never seen to differ; ``tools/parity/lanes_stress.py``,
-      DESIGN.md 3.4).  Not used for any reported number."""
+      Results of batch k are complete once phase2(k) has run, i.e. after ``submit`` of batch k+1 or ``flush``."""
 
     def __init__(self, spec: EngineSpec, weights: Dict[str, np.ndarray], tile_shape: Tuple[int, int, int], max_batch: int = 16,
-                 device: int = 0, lanes: int = 2, shared_stream: bool = True):
+                 device: int = 0, lanes: int = 2, shared_stream: bool = False):
         if lanes not in (1, 2, 3, 4):
             raise ValueError("lanes must be 1..4")
         blob = pack_weights(spec, weights)           # folding + fragment orders once, not once per lane (0.3 s of host time each)
