@@ -169,6 +169,32 @@ def test_split_mode_weight_planes():
         assert np.array_equal(sf[pl, kh, mi, lane], sw[pl * 64 + mi * 16 + (lane & 15), kh * 32 + (lane >> 4) * 8: kh * 32 + (lane >> 4) * 8 + 8])
 
 
+def test_no_compiler_division_sequence_in_device_code(tmp_path):
+    """No code object of librs_engine.so contains v_div_scale_f32 / v_div_fmas_f32 / v_div_fixup_f32: the compiler's expansion of fp32 `/` returns wrong
+    quotients in a wave that shares its SIMD with another kernel's MFMA waves (tools/ubench/coexec_probe.hip), so device code divides through
+    csrc/common.h rs_fdiv.  A `/` on floats slipping back into a kernel shows up here, on the CPU, before it shows up as a wrong mask word once in 500 tiles."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "proj_roadsurf_amd", "librs_engine.so")
+    if not os.path.exists(objdump) or not os.path.exists(lib):
+        pytest.skip("llvm-objdump or the built library is not here")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    cos = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(cos) >= 10, cos
+    found = {}
+    n_mfma = 0
+    for f in cos:
+        asm = subprocess.run([objdump, "-d", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        n_mfma += asm.count("v_mfma_")
+        k = sum(asm.count(ins) for ins in ("v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32"))
+        if k:
+            found[f] = k
+    assert n_mfma > 1000            # the disassembly is that of the kernels
+    assert not found, f"compiler fp32 division sequence in device code (use rs_fdiv): {found}"
+
+
 def test_checkpoint_loader_pth_weights_only(tmp_path):
     import torch
     W = {"roi_heads.box_predictor.cls_score.weight": torch.zeros(3, 1024)}
