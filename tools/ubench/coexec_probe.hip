@@ -21,6 +21,24 @@ __device__ __forceinline__ float div_nr(float a, float b) {
   return __builtin_fmaf(r, y, q);
 }
 
+// which of the three instructions?  3 = the software iteration followed by v_div_fixup_f32 alone; 4 = v_div_scale_f32 on both operands (a scale of 1 for these
+// magnitudes), the software iteration, no v_div_fmas_f32 / v_div_fixup_f32; 5 = v_div_scale + the iteration with v_div_fmas_f32 as its last step, no fixup
+__device__ __forceinline__ float div_var(float a, float b, int which) {
+  if (which == 3) return __builtin_amdgcn_div_fixupf(div_nr(a, b), b, a);
+  if (which == 4) {
+    bool f0, f1;
+    const float bs = __builtin_amdgcn_div_scalef(a, b, false, &f0), as = __builtin_amdgcn_div_scalef(a, b, true, &f1);
+    return div_nr(as, bs);
+  }
+  bool f0, f1;
+  const float bs = __builtin_amdgcn_div_scalef(a, b, false, &f0), as = __builtin_amdgcn_div_scalef(a, b, true, &f1);
+  float y = __builtin_amdgcn_rcpf(bs);
+  y = __builtin_fmaf(__builtin_fmaf(-bs, y, 1.0f), y, y);
+  const float q0 = as * y;
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-bs, q0, as), y, q0);
+  return __builtin_amdgcn_div_fmasf(__builtin_fmaf(-bs, q1, as), y, q1, f1);
+}
+
 template <int DIV>
 __global__ __launch_bounds__(256) void paste_like(const float* probs, const float* boxes, unsigned* out, int n_det, int H, int Ww, int S, float thr) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -33,7 +51,7 @@ __global__ __launch_bounds__(256) void paste_like(const float* probs, const floa
   const float x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
   const float* m = probs + (long long)det * S * S;
   unsigned word = 0;
-  const float gy = (DIV == 0 ? ((float)y + 0.5f - y0) / (y1 - y0) : DIV == 2 ? div_nr((float)y + 0.5f - y0, y1 - y0) : ((float)y + 0.5f - y0) * __builtin_amdgcn_rcpf(y1 - y0)) * 2.f - 1.f;
+  const float gy = (DIV == 0 ? ((float)y + 0.5f - y0) / (y1 - y0) : DIV == 2 ? div_nr((float)y + 0.5f - y0, y1 - y0) : DIV >= 3 ? div_var((float)y + 0.5f - y0, y1 - y0, DIV) : ((float)y + 0.5f - y0) * __builtin_amdgcn_rcpf(y1 - y0)) * 2.f - 1.f;
   const float iy = ((gy + 1.f) * (float)S - 1.f) * 0.5f;
   const float fy = floorf(iy);
   const int iy0 = (int)fy, iy1 = iy0 + 1;
@@ -41,7 +59,7 @@ __global__ __launch_bounds__(256) void paste_like(const float* probs, const floa
   if (iy1 >= 0 && iy0 < S) {
     for (int b = 0; b < 32; ++b) {
       const int x = xw * 32 + b;
-      const float gx = (DIV == 0 ? ((float)x + 0.5f - x0) / (x1 - x0) : DIV == 2 ? div_nr((float)x + 0.5f - x0, x1 - x0) : ((float)x + 0.5f - x0) * __builtin_amdgcn_rcpf(x1 - x0)) * 2.f - 1.f;
+      const float gx = (DIV == 0 ? ((float)x + 0.5f - x0) / (x1 - x0) : DIV == 2 ? div_nr((float)x + 0.5f - x0, x1 - x0) : DIV >= 3 ? div_var((float)x + 0.5f - x0, x1 - x0, DIV) : ((float)x + 0.5f - x0) * __builtin_amdgcn_rcpf(x1 - x0)) * 2.f - 1.f;
       const float ix = ((gx + 1.f) * (float)S - 1.f) * 0.5f;
       const float fx = floorf(ix);
       const int ix0 = (int)fx, ix1 = ix0 + 1;
@@ -151,6 +169,9 @@ int main(int argc, char** argv) {
   auto launch_a = [&](unsigned* o) {
     if (divk == 1) hipLaunchKernelGGL(paste_like<1>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
     else if (divk == 2) hipLaunchKernelGGL(paste_like<2>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
+    else if (divk == 3) hipLaunchKernelGGL(paste_like<3>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
+    else if (divk == 4) hipLaunchKernelGGL(paste_like<4>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
+    else if (divk == 5) hipLaunchKernelGGL(paste_like<5>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
     else hipLaunchKernelGGL(paste_like<0>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
   };
   launch_a(out[0]);
