@@ -460,6 +460,9 @@ void rs_resize_shape(int h, int w, int short_edge, int max_size, int* new_h, int
 int rs_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs);
 
 int rs_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes);
+/* out[i] = a[i] / b[i] (device pointers) through csrc/common.h rs_fdiv, the division every kernel of the library uses instead of the compiler's
+ * v_div_scale / v_div_fmas / v_div_fixup sequence; exported for its test. */
+int rs_op_fdiv(const float* a, const float* b, float* out, int64_t n, void* stream);
 int rs_memcpy_h2d(void* dst_dev, const void* src_host, size_t nbytes);
 const char* rs_last_error(void);
 int rs_abi_version(void);

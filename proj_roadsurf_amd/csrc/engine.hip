@@ -1284,6 +1284,18 @@ extern "C" {
 const char* rs_last_error(void) { return g_err; }
 int rs_abi_version(void) { return RS_ABI_VERSION; }
 
+// rs_fdiv (common.h) as an operator, for its test: out[i] = a[i] / b[i] through the device code's division
+__global__ void fdiv_kernel(const float* a, const float* b, float* out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = rs_fdiv(a[i], b[i]);
+}
+int rs_op_fdiv(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  RS_CHECK(a && b && out && n > 0, RS_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(fdiv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)n);
+  RS_HIP(hipGetLastError());
+  return RS_OK;
+}
+
 int rs_memcpy_d2h(void* dst, const void* src, size_t n) {
   RS_HIP(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
   return RS_OK;

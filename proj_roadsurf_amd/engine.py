@@ -144,6 +144,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rs_vec_free.restype = None
     lib.rs_rasterize_polygons_within_box.argtypes = [f64p, i32p, i32, f64p, i32, u8p]
     lib.rs_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    lib.rs_op_fdiv.argtypes = [vp, vp, vp, C.c_int64, vp]
     lib.rs_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
     if path is None:
         _LIB = lib

@@ -418,3 +418,33 @@ def test_conv1x1_register_weights_is_bit_identical_to_the_tiled_kernel(gpu_requi
     for variant in (22, 23, 25, 26):    # the shipped form / 64-pixel tiles with eight waves / 32-pixel tiles, two workgroups per CU / 64-pixel tiles, four waves
         c = run_conv(x, w, b, relu=relu, res=res, up=up, variant=variant)
         assert torch.equal(a, c), f"variant {variant}: {int((a != c).sum())} of {a.numel()} elements differ, max {float((a - c).abs().max())}"
+
+
+def test_device_division_equals_ieee_division(gpu_required):
+    """csrc/common.h rs_fdiv -- what every kernel divides with since the compiler's fp32 division sequence turned out to return wrong quotients beside another
+    kernel's MFMA waves -- against IEEE division (numpy float32, correctly rounded) on 8 million operand pairs: bit-identical over 24 decades of
+    magnitude on either side (1e-12 .. 1e12, quotients 1e-24 .. 1e24: far beyond box coordinates, probabilities and losses), on exact cases, and on the special
+    values (zero / infinite divisor, infinite / NaN dividend)."""
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7)
+    n = 1 << 22
+    mant = lambda: (1.0 + rng.random(n)).astype(np.float32) * rng.choice(np.array([-1.0, 1.0], np.float32), n)
+    a = mant() * np.exp2(rng.integers(-40, 41, n)).astype(np.float32)
+    b = mant() * np.exp2(rng.integers(-40, 41, n)).astype(np.float32)
+    # the magnitudes the kernels see: pixel coordinates over box sizes, probabilities, small integers
+    a2 = np.concatenate([rng.uniform(-2000, 2000, n // 2), rng.integers(-1000, 1000, n // 2)]).astype(np.float32)
+    b2 = np.concatenate([rng.uniform(1e-3, 2000, n // 2), rng.integers(1, 1000, n // 2)]).astype(np.float32)
+    sa = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 3.0, 0.0, np.inf, 1e30, 1.0], np.float32)
+    sb = np.array([1.0, 2.0, 0.0, -0.0, 2.0, np.inf, 1.0, np.nan, 0.0, 0.0, np.inf, -np.inf], np.float32)
+    for x, y in ((a, b), (a2, b2), (sa, sb)):
+        xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+        od = torch.empty_like(xd)
+        torch.cuda.synchronize()
+        _check(lib, lib.rs_op_fdiv(C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(od.data_ptr()), x.size, None), "rs_op_fdiv")
+        torch.cuda.synchronize()
+        got = od.cpu().numpy()
+        with np.errstate(all="ignore"):
+            want = (x / y).astype(np.float32)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert bool(same.all()), f"{int((~same).sum())} of {x.size} quotients differ, first: {x[~same][:3]} / {y[~same][:3]} -> {got[~same][:3]} against {want[~same][:3]}"
