@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void paste_like(const float* probs, const floa
   const float x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
   const float* m = probs + (long long)det * S * S;
   unsigned word = 0;
-  const float gy = (DIV == 0 ? ((float)y + 0.5f - y0) / (y1 - y0) : DIV == 2 ? div_nr((float)y + 0.5f - y0, y1 - y0) : DIV >= 3 ? div_var((float)y + 0.5f - y0, y1 - y0, DIV) : ((float)y + 0.5f - y0) * __builtin_amdgcn_rcpf(y1 - y0)) * 2.f - 1.f;
+  const float gy = (DIV == 0 ? ((float)y + 0.5f - y0) / (y1 - y0) : DIV == 2 || DIV >= 6 ? div_nr((float)y + 0.5f - y0, y1 - y0) : DIV >= 3 ? div_var((float)y + 0.5f - y0, y1 - y0, DIV) : ((float)y + 0.5f - y0) * __builtin_amdgcn_rcpf(y1 - y0)) * 2.f - 1.f;
   const float iy = ((gy + 1.f) * (float)S - 1.f) * 0.5f;
   const float fy = floorf(iy);
   const int iy0 = (int)fy, iy1 = iy0 + 1;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void paste_like(const float* probs, const floa
   if (iy1 >= 0 && iy0 < S) {
     for (int b = 0; b < 32; ++b) {
       const int x = xw * 32 + b;
-      const float gx = (DIV == 0 ? ((float)x + 0.5f - x0) / (x1 - x0) : DIV == 2 ? div_nr((float)x + 0.5f - x0, x1 - x0) : DIV >= 3 ? div_var((float)x + 0.5f - x0, x1 - x0, DIV) : ((float)x + 0.5f - x0) * __builtin_amdgcn_rcpf(x1 - x0)) * 2.f - 1.f;
+      const float gx = (DIV == 0 ? ((float)x + 0.5f - x0) / (x1 - x0) : DIV == 2 || DIV >= 6 ? div_nr((float)x + 0.5f - x0, x1 - x0) : DIV >= 3 ? div_var((float)x + 0.5f - x0, x1 - x0, DIV) : ((float)x + 0.5f - x0) * __builtin_amdgcn_rcpf(x1 - x0)) * 2.f - 1.f;
       const float ix = ((gx + 1.f) * (float)S - 1.f) * 0.5f;
       const float fx = floorf(ix);
       const int ix0 = (int)fx, ix1 = ix0 + 1;
@@ -71,6 +71,11 @@ __global__ __launch_bounds__(256) void paste_like(const float* probs, const floa
       if (iy1 < S && ix0 >= 0) v += m[iy1 * S + ix0] * (wx0 * wy1);
       if (iy1 < S && ix1 < S) v += m[iy1 * S + ix1] * (wx1 * wy1);
       if (v >= thr) word |= 1u << b;
+      // flavours 6-9: other compiler-expanded functions, their low result bits mixed into the word (division by the written-out iteration)
+      if (DIV == 6) word ^= (__float_as_uint(sqrtf(fabsf(gx) + 1.f)) & 1u) << b;
+      if (DIV == 7) word ^= (__float_as_uint(expf(gx * 0.25f)) & 1u) << b;
+      if (DIV == 8) word ^= (__float_as_uint(logf(fabsf(gx) + 0.5f)) & 1u) << b;
+      if (DIV == 9) word ^= ((unsigned)((long long)(gx * 1000.f) / (long long)(b + 3)) & 1u) << b;
     }
   }
   out[gid] = word;
@@ -172,6 +177,10 @@ int main(int argc, char** argv) {
     else if (divk == 3) hipLaunchKernelGGL(paste_like<3>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
     else if (divk == 4) hipLaunchKernelGGL(paste_like<4>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
     else if (divk == 5) hipLaunchKernelGGL(paste_like<5>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
+    else if (divk == 6) hipLaunchKernelGGL(paste_like<6>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
+    else if (divk == 7) hipLaunchKernelGGL(paste_like<7>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
+    else if (divk == 8) hipLaunchKernelGGL(paste_like<8>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
+    else if (divk == 9) hipLaunchKernelGGL(paste_like<9>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
     else hipLaunchKernelGGL(paste_like<0>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
   };
   launch_a(out[0]);
