@@ -105,6 +105,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("config_file", help="YAML with a 'make_detections.py' section (R:config/config_obj_detec.yaml)")
     ap.add_argument("--batch", type=int, default=16, help="tiles per engine call")
+    ap.add_argument("--lanes", type=int, default=2, help="engine contexts fed alternately, each on its own stream (engine.LanePipeline); 2 keeps the GPU busy while the host collects a batch")
     ap.add_argument("--synthetic-weights", action="store_true",
                     help="use seeded synthetic weights instead of model_weights.pth_file (demo / smoke tests)")
     ap.add_argument("--host-workers", type=int, default=None,
@@ -168,7 +169,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         log.info("inference in %s", {"fp32": "reference precision (fp32 on the matrix cores)", "split": "reference-equivalent precision (hi + lo fp16 operand planes, three products)",
                                      "fp16": "fp16 operands / fp32 accumulate"}[args.precision])
     from .engine import Predictor      # fails loudly without librs_engine.so / a HIP device
-    predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank)
+    predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank, lanes=args.lanes)
 
     # decode (PIL), GPU forward and vectorisation (C++, rs_vectorize_masks) overlap across batches (shard.run_sharded)
     busy = {"decode": 0.0, "predict": 0.0, "vectorise": 0.0}      # seconds summed over the threads that ran each stage
@@ -264,7 +265,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                 # the COCO sizes (or the band count of the first tile) did not hold for every file: this dataset again on the thread path
                 log.warning("%s: %s -- running the dataset again with thread decoding", dataset, ex)
                 predictor.close()
-                predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank)
+                predictor = Predictor(spec, W, max_batch=args.batch, device=local_rank, lanes=args.lanes)
                 per_tile = run_sharded(images, predict_batch, args.batch, rank, world, gather=False, prepare=prepare, finish=finish,
                                        workers=args.host_workers, predict_stream=predict_stream, prepared_source=None)
         except BaseException:

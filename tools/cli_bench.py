@@ -28,6 +28,7 @@ def main():
                          "synthetic scenes (a handful of clean objects per tile, like a trained detector on real tiles)")
     ap.add_argument("--train-steps", type=int, default=300)
     ap.add_argument("--precision", choices=["fp16", "split", "fp32"], default="fp16", help="make_detections --precision")
+    ap.add_argument("--lanes", type=int, default=2)
     args = ap.parse_args()
     import yaml
     from PIL import Image
@@ -69,7 +70,7 @@ def main():
         t0 = time.time()
         rc = make_detections.main([os.path.join(td, "config.yaml"), *extra, "--batch", str(args.batch),
                                    "--host-workers", str(args.host_workers), "--vector-threads", str(args.vector_threads),
-                                   "--decode-procs", str(args.decode_procs), "--precision", args.precision])
+                                   "--decode-procs", str(args.decode_procs), "--precision", args.precision, "--lanes", str(args.lanes)])
         dt = time.time() - t0
         os.chdir(cwd)
         size = os.path.getsize(os.path.join(wd, "oth_detections_at_0dot05_threshold.gpkg"))
