@@ -497,7 +497,7 @@ def main():
                 e0.set_profiling(0)
             # PCIe-inclusive rate of the streaming host interface (pinned H2D of the tiles + forward + D2H of boxes/scores/packed
             # mask crops + host-side collection into Instances, LanePipeline.run); reported beside the headline, never as `value`
-            nb = 8
+            nb = 24                                 # long enough that filling and draining the two lanes is a small part of it
             for _ in pipe.run(tiles for _ in range(2)):
                 pass
             t1 = time.perf_counter()
