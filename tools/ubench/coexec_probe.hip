@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void paste_like(const float* probs, const floa
       if (DIV == 7) word ^= (__float_as_uint(expf(gx * 0.25f)) & 1u) << b;
       if (DIV == 8) word ^= (__float_as_uint(logf(fabsf(gx) + 0.5f)) & 1u) << b;
       if (DIV == 9) word ^= ((unsigned)((long long)(gx * 1000.f) / (long long)(b + 3)) & 1u) << b;
+      if (DIV == 10) word ^= ((unsigned)__double2loint((double)gx / ((double)fabsf(x1 - x0) + 1.0)) & 1u) << b;      // the compiler's fp64 division
     }
   }
   out[gid] = word;
@@ -181,6 +182,7 @@ int main(int argc, char** argv) {
     else if (divk == 7) hipLaunchKernelGGL(paste_like<7>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
     else if (divk == 8) hipLaunchKernelGGL(paste_like<8>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
     else if (divk == 9) hipLaunchKernelGGL(paste_like<9>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
+    else if (divk == 10) hipLaunchKernelGGL(paste_like<10>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
     else hipLaunchKernelGGL(paste_like<0>, dim3(grid), dim3(256), 0, a, probs, boxes, o, n_det, H, Ww, S, 0.5f);
   };
   launch_a(out[0]);
