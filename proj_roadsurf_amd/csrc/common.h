@@ -85,6 +85,7 @@ struct RsDebug {
   int deep_tail = 1;              // RS_DEEP_TAIL             conv_deep: split the tiles of a last round that fills at most half the chip
   int fuse_rpn_heads = 1;         // RS_FUSE_RPN_HEADS        objectness + delta heads inside the epilogue of the merged RPN 3x3 launch
   int merge_levels = 1;           // RS_MERGE_LEVELS          FPN output convs of all levels / the RPN 3x3 over all levels as one launch each
+  int graph_small = 1;            // RS_GRAPH_SMALL           forwards of ONE tile replay a hipGraph (the reference's predictor(im) loop: launch gaps are 5 % of its latency)
   int use_graph = 0;              // RS_USE_GRAPH
   int train_roi_side = -1;        // RS_TRAIN_ROI_SIDE        -1: trainer default
   int train_side = -1;            // RS_TRAIN_SIDE            -1: trainer default (on)

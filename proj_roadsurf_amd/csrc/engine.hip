@@ -30,7 +30,7 @@ void rs_debug_reload() {
   rd("RS_CONV_DEEP", &d.conv_deep); rd("RS_CONV_WIDE_PX", &d.conv_wide_px); rd("RS_CONV_WREG", &d.conv_wreg); rd("RS_WREG_DBG", &d.wreg_dbg); rd("RS_ROI_BWD_ATOMIC", &d.roi_bwd_atomic); rd("RS_WREG_WAVES", &d.wreg_waves); rd("RS_STEM_SMALL_TILE", &d.stem_small_tile); rd("RS_DEEP_DBG", &d.deep_dbg);
   rd("RS_DECONV_VARIANT", &d.deconv_variant); rd("RS_FUSE_MASK_PREDICTOR", &d.fuse_mask_predictor); rd("RS_SIDE_STREAM", &d.side_stream);
   rd("RS_NARROW_ROIALIGN", &d.narrow_roialign); rd("RS_USE_GLDS", &d.use_glds); rd("RS_FUSE_SHORTCUT", &d.fuse_shortcut); rd("RS_MERGE_LEVELS", &d.merge_levels); rd("RS_FUSE_RPN_HEADS", &d.fuse_rpn_heads); rd("RS_DEEP_TAIL", &d.deep_tail); rd("RS_DEEP_TILE_PX", &d.deep_tile_px); rd("RS_FUSE_BNECK", &d.fuse_bneck); rd("RS_FUSE_STEM", &d.fuse_stem);
-  rd("RS_USE_GRAPH", &d.use_graph); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
+  rd("RS_USE_GRAPH", &d.use_graph); rd("RS_GRAPH_SMALL", &d.graph_small); rd("RS_TRAIN_ROI_SIDE", &d.train_roi_side);
   rd("RS_TRAIN_SIDE", &d.train_side); rd("RS_WGRAD_TARGET", &d.wgrad_target); rd("RS_WGRAD_CB", &d.wgrad_cb);
   rd("RS_SELECT_DEBUG", &d.select_debug); rd("RS_NMS_DEBUG", &d.nms_debug); rd("RS_ROI_WINDOW", &d.roi_window); rd("RS_ROI_ORDER", &d.roi_order);
   g_debug = d;
@@ -256,7 +256,7 @@ struct rs_engine {
                const int* m_count = nullptr, const Act* in2 = nullptr, int stride2 = 1, DeferredConv* defer = nullptr);
   int add_merged_convs(const std::string& name, const std::vector<DeferredConv>& d);
   int run(const uint8_t* tiles, int n, int phase = -1);
-  int run_stages(int n, bool record, int phase = -1);
+  int run_stages(int n, bool record, int phase = -1, bool all_wide = false);
   int assign_phases();
   int use_graph = 0;
   int fuse_shortcut = 1;
@@ -1175,10 +1175,17 @@ int rs_engine::assign_phases() {
   return RS_OK;
 }
 
-int rs_engine::run_stages(int n, bool record, int phase) {
+int rs_engine::run_stages(int n, bool record, int phase, bool all_wide) {
   for (size_t si = 0; si < stages.size(); ++si) {
     Stage& st = stages[si];
     if (phase >= 0 && st.phase != phase) continue;
+    if (all_wide) {                     // one-tile graph capture: every stage on the wide stream, in list order (the side stream hides nothing at one tile)
+      g_last_conv_variant = -2;
+      int rc = st.fn(n, stream);
+      if (rc) return rc;
+      st.variant = g_last_conv_variant;
+      continue;
+    }
     if (st.narrow != on_narrow) {       // hand the dependency chain over to the other stream
       hipStream_t from = on_narrow ? narrow : stream, to = st.narrow ? narrow : stream;
       RS_HIP(hipEventRecord(st.handoff, from));
@@ -1238,7 +1245,10 @@ int rs_engine::run(const uint8_t* tiles, int n, int phase) {
     copy_pending = false;
   }
   const bool record = cur_record;
-  if (phase >= 0 || record || !use_graph || !warmed.count(n)) {
+  // One tile per call (what the reference's predictor(im) loop submits): the ~110 launches replay from a hipGraph captured with every stage on the wide
+  // stream -- same kernels, same order, same bits; 2.25 -> 2.13 ms fp16, 3.76 -> 3.67 ms split (tools/ubench/single_tile_latency.py).  Larger batches stay eager.
+  const bool small = n == 1 && rs_debug().graph_small != 0 && !on_narrow;
+  if (phase >= 0 || record || !(use_graph || small) || !warmed.count(n)) {
     int rc = run_stages(n, record, phase);
     if (rc) return rc;
     if (phase < 0) warmed.insert(n);
@@ -1249,7 +1259,7 @@ int rs_engine::run(const uint8_t* tiles, int n, int phase) {
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     RS_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    int rc = run_stages(n, false);
+    int rc = run_stages(n, false, -1, !use_graph);
     hipError_t he = hipStreamEndCapture(stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     RS_HIP(he);
