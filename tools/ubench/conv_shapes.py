@@ -19,8 +19,11 @@ B = int(os.environ.get("BATCH", "16"))
 shapes = [("res4.x.conv1", B, 50, 50, 1024, 1, 256), ("res4.0.conv1", B, 50, 50, 512, 1, 256), ("res4.x.conv2", B, 50, 50, 256, 3, 256),
           ("res4.x.conv3", B, 50, 50, 256, 1, 1024), ("fpn_lateral4", B, 50, 50, 1024, 1, 256), ("fpn_lateral3", B, 100, 100, 512, 1, 256),
           ("res5.x.conv1", B, 25, 25, 2048, 1, 512), ("res5.x.conv2", B, 25, 25, 512, 3, 512), ("res5.x.conv3", B, 25, 25, 512, 1, 2048),
-          ("fpn_lateral5", B, 25, 25, 2048, 1, 256), ("fpn_lateral2", B, 200, 200, 256, 1, 256), ("box.fc2", B * 10, 10, 10, 1024, 1, 1024), ("mask.fcn", B * 100, 14, 14, 256, 3, 256)]
+          ("fpn_lateral5", B, 25, 25, 2048, 1, 256), ("fpn_lateral2", B, 200, 200, 256, 1, 256), ("box.fc2", B * 10, 10, 10, 1024, 1, 1024), ("box.fc1", B * 10, 10, 10, 12544, 1, 1024), ("mask.fcn", B * 100, 14, 14, 256, 3, 256)]
+only = os.environ.get("SHAPES")
 for name, N, H, W, Cin, k, Cout in shapes:
+    if only and not any(name.startswith(x) for x in only.split(",")):
+        continue
     pad = k // 2
     x = torch.randn(N, H + 2 * pad, W + 2 * pad, Cin, device=dev).half()
     w = (torch.randn(Cout, k * k * Cin, device=dev) * 0.02).half()
