@@ -316,6 +316,42 @@ def test_independent_lanes_are_bit_reproducible_under_load(gpu_required):
         solo.close()
 
 
+def test_two_engines_driven_from_two_host_threads(gpu_required):
+    """calls on different engines may come from different host threads at the same time (ctypes drops the GIL around every call; the
+    library keeps its error text and its last-variant note per thread).  Two threads, each with its own engine, 12 forwards of different batches each,
+    every result against the same engine run alone."""
+    import threading
+    spec = EngineSpec(num_classes=2)
+    W = synthetic_weights(spec, seed=0)
+    B, T = 3, 256
+    batches = [synthetic_tiles(B, T, T, 3, seed=810 + k) for k in range(4)]
+    solo = Engine(spec, W, (T, T, 3), max_batch=4)
+    engs = [Engine(spec, W, (T, T, 3), max_batch=4) for _ in range(2)]
+    try:
+        want = [solo.infer(b) for b in batches]
+        errors = []
+
+        def work(ti):
+            try:
+                for r in range(12):
+                    bi = (r + 2 * ti) % len(batches)
+                    got = engs[ti].infer(batches[bi])
+                    if not all(_same_instances(a, b) for a, b in zip(want[bi], got)):
+                        errors.append((ti, r, bi))
+            except Exception as ex:          # noqa: BLE001
+                errors.append((ti, repr(ex)))
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+    finally:
+        for e in engs:
+            e.close()
+        solo.close()
+
+
 def test_lane_pipeline_streaming_host_interface(small):
     """LanePipeline.run: host batches in, detections out, `lanes` batches of look-ahead, pinned staging + asynchronous result
     copies (rs_engine_upload_async / fetch_async / fetch_wait) -- same detections as the synchronous single engine, in order,
