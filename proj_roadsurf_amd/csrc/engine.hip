@@ -1247,7 +1247,8 @@ int rs_engine::run(const uint8_t* tiles, int n, int phase) {
   const bool record = cur_record;
   // One tile per call (what the reference's predictor(im) loop submits): the ~110 launches replay from a hipGraph captured with every stage on the wide
   // stream -- same kernels, same order, same bits; 2.25 -> 2.13 ms fp16, 3.76 -> 3.67 ms split (tools/ubench/single_tile_latency.py).  Larger batches stay eager.
-  const bool small = n == 1 && rs_debug().graph_small != 0 && !on_narrow;
+  // (inference engines on the one network geometry only: a trainer's forward engine re-reads host state per step -- per-image sizes, their resize tables)
+  const bool small = n == 1 && rs_debug().graph_small != 0 && !on_narrow && img_new_h.empty() && !frozen_fusions_only;
   if (phase >= 0 || record || !(use_graph || small) || !warmed.count(n)) {
     int rc = run_stages(n, record, phase);
     if (rc) return rc;
